@@ -1,0 +1,186 @@
+/* mot_abi.h -- C ABI of the MI355X-native per-frame tracker update.
+ *
+ * Drop-in boundary for the hot path of huangfcn/multiple-object-tracking
+ * (FHOG -> KCF detect/train, Kalman predict/correct, association cost +
+ * Munkres).  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Two layers are exported by libmot_amd.so:
+ *
+ *  (1) the BATCH ABI (this file, prefix mot_): all live tracks of a frame are
+ *      processed by one kernel launch per stage.  This is what a maintainer
+ *      binds from top/td.cpp's tracker thread (td.cpp:306-748) and what the
+ *      synthetic driver / bench / multi-GPU path call.
+ *
+ *  (2) the reference's own per-object interface with identical C++ linkage
+ *      (td.cpp:229-234; implemented in trackers/kcf.cpp:455-491,
+ *      trackers/kalman.cpp:131-163, trackers/hungarian/hungarian.cpp:29):
+ *          void* tracker_new(bbox_t*);
+ *          void  tracker_predict(void*, float* rgb, bbox_t*);
+ *          void  tracker_update (void*, float* rgb, bbox_t*);
+ *          void  tracker_delete (void*);
+ *          void  assignmentoptimal(int*, double*, double*, int, int);
+ *      exported (Itanium-mangled, struct tag _bbox_pos_s) by
+ *      libmot_dropin_kcf.so / libmot_dropin_kalman.so -- link-time back-end
+ *      selection exactly like the reference (yolo3tracker.vcxproj:134-138).
+ *      They are batch-of-one wrappers over (1); see include/mot_dropin.hpp.
+ *
+ * Error convention: the reference's functions are void and never report
+ * errors.  The batch ABI returns int: 0 = MOT_OK, negative
+ * = error; mot_last_error() gives a message.  There is NO CPU fallback: if no
+ * HIP device / kernel image is available every call fails with MOT_ERR_DEVICE.
+ */
+#ifndef MOT_ABI_H
+#define MOT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Bit-identical to top/cnntype.h:36-41 (note the field order l,t,b,r; inclusive coords). */
+#ifndef MOT_BBOX_T_DEFINED
+#define MOT_BBOX_T_DEFINED
+typedef struct _bbox_pos_s {
+    int l, t, b, r;
+    int type;
+    float score;
+} bbox_t;
+#endif
+
+/* top/cnntype.h:5-6 */
+#define MOT_FRAME_W 1280
+#define MOT_FRAME_H 720
+
+enum {
+    MOT_OK = 0,
+    MOT_ERR_ARG = -1,      /* bad argument (null pointer, size out of range, unknown id) */
+    MOT_ERR_DEVICE = -2,   /* HIP runtime / no device / kernel launch failure */
+    MOT_ERR_CAPACITY = -3, /* more tracks / detections than the context was created for */
+    MOT_ERR_STATE = -4     /* call not valid in the current state (e.g. no frame bound) */
+};
+
+enum { MOT_TRACKER_KCF = 0, MOT_TRACKER_KALMAN = 1 }; /* trackers/kcf.cpp | trackers/kalman.cpp */
+
+/* FHOG arithmetic flavour.  INTEL_APPROX reproduces the as-compiled reference
+ * (libhog/sse.hpp:40-41 rcpps/rsqrtps, bit-exact table emulation); EXACT uses
+ * 1/x and 1/sqrt(x). */
+enum { MOT_FHOG_INTEL_APPROX = 0, MOT_FHOG_EXACT = 1 };
+
+enum { MOT_FFT_AUTO = 0, MOT_FFT_GENERIC = 1 }; /* AUTO: radix-4x5 register FFT where the size allows */
+
+typedef struct mot_config {
+    int device;        /* HIP device ordinal */
+    int tracker_kind;  /* MOT_TRACKER_* */
+    int fhog_mode;     /* MOT_FHOG_* */
+    int fft_mode;      /* MOT_FFT_* */
+    int max_tracks;    /* capacity of the live-track list (reference: 256, td.cpp:12) */
+    int max_dets;      /* capacity of a detection list (reference: 128, cnntype.h:46) */
+    int rank, world;   /* track sharding: this context owns KCF/Kalman state of tracks with tid % world == rank */
+    void* stream;      /* hipStream_t to launch on, or NULL to create a private stream */
+    int reserved[6];   /* must be zero */
+} mot_config;
+
+typedef struct mot_ctx mot_ctx; /* opaque */
+
+void mot_config_default(mot_config* cfg);
+int mot_ctx_create(const mot_config* cfg, mot_ctx** out);
+int mot_ctx_destroy(mot_ctx* ctx);
+const char* mot_last_error(void);
+void* mot_ctx_stream(mot_ctx* ctx); /* the hipStream_t all work is enqueued on */
+int mot_ctx_sync(mot_ctx* ctx);
+
+/* ---- frame binding (replaces the cv::Mat data pointer of td.cpp:330,350) ----
+ * 1280x720x3 u8 BGR, row stride 3840 (top/drawlib.c:9-10). */
+int mot_frame_upload(mot_ctx* ctx, const uint8_t* host_bgr);      /* H2D copy into the context's frame */
+int mot_frame_bind_device(mot_ctx* ctx, const void* device_bgr);  /* use a frame already resident in HBM */
+
+/* ---- per-stage batch calls: one launch for n tracks ----------------------
+ * ids are handles returned by mot_tracks_new.  boxes are host arrays.
+ * mot_tracks_new replaces tracker_new (+ the first tracker_update with eta=1
+ * issued by td.cpp:631-640 for KCF; needs a bound frame).
+ * mot_predict_batch replaces the loop td.cpp:344-384 (crop+resize, tracker_predict);
+ *   clamp != 0 applies td.cpp:378-381 to the returned boxes.
+ * mot_update_batch replaces td.cpp:512-582's tracker_update calls (crop at boxes[i]). */
+int mot_tracks_new(mot_ctx* ctx, const bbox_t* boxes, int n, int* ids_out);
+int mot_predict_batch(mot_ctx* ctx, const int* ids, int n, bbox_t* boxes_out, int clamp);
+int mot_update_batch(mot_ctx* ctx, const int* ids, int n, const bbox_t* boxes);
+int mot_delete_batch(mot_ctx* ctx, const int* ids, int n);
+
+/* Same stages fed with caller-supplied gray patches instead of the bound frame:
+ * patches[i] is the column-major rows x cols float patch the reference passes as
+ * `float* rgb` (trackers/kcf.cpp:455-476).  Used by the per-object drop-in layer. */
+int mot_tracks_new_nofirst(mot_ctx* ctx, const bbox_t* boxes, int n, int* ids_out); /* tracker_new only */
+int mot_predict_batch_patches(mot_ctx* ctx, const int* ids, int n, const float* const* patches, bbox_t* boxes_out);
+int mot_update_batch_patches(mot_ctx* ctx, const int* ids, int n, const float* const* patches, const bbox_t* boxes);
+
+/* ---- association: td.cpp:386-470 + trackers/hungarian/hungarian.cpp:29 ----
+ * mot_assign: builds the td.cpp cost matrix on device from the two box lists
+ *   (rows = the smaller side exactly as td.cpp:388-457), runs Munkres, returns
+ *   assignment[row] = col or -1 (nRows = min(nT,nD) entries... see below) and the cost.
+ *   assigned_trackers[nT] / assigned_detected[nD] are the scatter of td.cpp:472-502.
+ * mot_assignment_optimal: Munkres on a caller-supplied column-major float64 cost
+ *   matrix -- same contract as assignmentoptimal(). */
+int mot_assign(mot_ctx* ctx, const bbox_t* trk, int nT, const bbox_t* det, int nD,
+               int* assigned_trackers, int* assigned_detected, double* cost_out);
+int mot_assignment_optimal(mot_ctx* ctx, int* assignment, double* cost, const double* dist, int nRows, int nCols);
+int mot_cost_matrix(mot_ctx* ctx, const bbox_t* trk, int nT, const bbox_t* det, int nD, double* dist_out);
+
+/* ---- whole tracker-thread iteration (td.cpp:344-644) -----------------------
+ * Runs predict -> clamp -> cost -> Munkres -> update assigned / unassigned ->
+ * delete lost -> spawn, on the bound frame.  Outputs (all optional, host):
+ *   predicted[n_before]          clamped predicted boxes, old track order
+ *   assigned_trackers[n_before]  detection index or -1, old track order
+ *   live_boxes / live_tids       the track list after lifecycle (n returned via n_live)
+ * In a sharded context (world > 1) the caller must pass gathered predictions via
+ * mot_step_begin / mot_step_finish instead (see below). */
+int mot_step_frame(mot_ctx* ctx, const bbox_t* dets, int nD,
+                   bbox_t* predicted, int* assigned_trackers, int* n_before,
+                   bbox_t* live_boxes, unsigned* live_tids, int* n_live);
+
+/* Split form for multi-GPU: begin = predict the local shard into a device
+ * buffer laid out for one all-gather; finish = association + update + lifecycle.
+ *   mot_step_begin   writes ceil(max_tracks/world) bbox_t slots for this rank to
+ *                    *local_boxes_dev (device pointer owned by the context).
+ *   mot_step_finish  takes the all-gathered buffer (world * slots bbox_t, device)
+ *                    -- for world == 1 pass the pointer returned by begin. */
+int mot_step_begin(mot_ctx* ctx, void** local_boxes_dev, int* slots_per_rank);
+int mot_step_finish(mot_ctx* ctx, const void* gathered_boxes_dev, const bbox_t* dets, int nD,
+                    bbox_t* predicted, int* assigned_trackers, int* n_before,
+                    bbox_t* live_boxes, unsigned* live_tids, int* n_live);
+
+/* ---- steady-state device-resident loop (bench / serving) -------------------
+ * Same per-frame semantics as mot_step_frame, but detections come from device
+ * memory, nothing is copied back and no host synchronisation happens: the
+ * frame's kernels are only enqueued.  Lifecycle (delete/spawn) is executed on
+ * device as well.  mot_live_count() synchronises and returns the track count. */
+int mot_step_frame_device(mot_ctx* ctx, const void* frame_dev, const void* dets_dev /* bbox_t[nD] */, int nD);
+int mot_step_begin_device(mot_ctx* ctx, const void* frame_dev, void** local_boxes_dev, int* slots_per_rank);
+int mot_step_finish_device(mot_ctx* ctx, const void* gathered_boxes_dev, const void* dets_dev, int nD);
+int mot_live_count(mot_ctx* ctx, int* n_live);
+int mot_live_tracks(mot_ctx* ctx, bbox_t* boxes, unsigned* tids, int* ages, int* n_live);
+
+/* ---- introspection for parity tests --------------------------------------- */
+int mot_get_response(mot_ctx* ctx, int id, float* out, int* f_rows, int* f_cols); /* kcf_t::response (kcf.cpp:58) */
+int mot_get_model(mot_ctx* ctx, int id, float* xm_out /* 31*f_cols*(f_rows/2+1)*2 */, float* alpha_out);
+int mot_get_kalman_state(mot_ctx* ctx, int id, double* x6, double* P36);
+int mot_get_pos(mot_ctx* ctx, int id, bbox_t* pos);
+/* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
+int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);
+/* crop + gray + resize only (top/td.cpp:348-364) on the bound frame. */
+int mot_crop_patch(mot_ctx* ctx, const bbox_t* box, int rows, int cols, float* patch_out);
+
+/* ---- timing helpers: HIP events on the context's stream --------------------
+ * (bench.py measures kernels on the stream they are launched on.) */
+int mot_timer_create(mot_ctx* ctx, int n_events);
+int mot_timer_record(mot_ctx* ctx, int idx);
+int mot_timer_elapsed_ms(mot_ctx* ctx, int idx_start, int idx_stop, float* ms);
+/* per-stage device time of the most recent mot_profile_frame_device() call:
+ * [0]=predict kernel [1]=cost/init [2]=munkres [3]=scatter/lifecycle [4]=update kernel, in ms */
+int mot_profile_frame_device(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD, float* stage_ms5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOT_ABI_H */

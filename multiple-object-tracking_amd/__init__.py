@@ -1,0 +1,304 @@
+"""multiple-object-tracking_amd -- host-side mirror of the MI355X tracker ABI.
+
+Thin ctypes binding of ``libmot_amd.so`` (include/mot_abi.h).  The names follow
+the reference's tracker interface (``tracker_new / tracker_predict /
+tracker_update / tracker_delete / assignmentoptimal``, top/td.cpp:229-234) and
+its tracker-thread loop (td.cpp:306-748).  There is no CPU implementation in
+this package: if the HIP library is missing or no GPU is present every call
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmot_amd.so")
+DROPIN_KCF_PATH = os.path.join(_HERE, "libmot_dropin_kcf.so")
+DROPIN_KALMAN_PATH = os.path.join(_HERE, "libmot_dropin_kalman.so")
+
+FRAME_W, FRAME_H = 1280, 720
+TRACKER_KCF, TRACKER_KALMAN = 0, 1
+FHOG_INTEL_APPROX, FHOG_EXACT = 0, 1
+FFT_AUTO, FFT_GENERIC = 0, 1
+
+
+class BBox(C.Structure):
+    """bbox_t, top/cnntype.h:36-41 (field order l,t,b,r)."""
+    _fields_ = [("l", C.c_int), ("t", C.c_int), ("b", C.c_int), ("r", C.c_int), ("type", C.c_int), ("score", C.c_float)]
+
+    def tup(self):
+        return (self.l, self.t, self.b, self.r, self.type)
+
+
+BBOX_DTYPE = np.dtype([("l", "<i4"), ("t", "<i4"), ("b", "<i4"), ("r", "<i4"), ("type", "<i4"), ("score", "<f4")])
+
+
+class MotConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("tracker_kind", C.c_int), ("fhog_mode", C.c_int), ("fft_mode", C.c_int),
+                ("max_tracks", C.c_int), ("max_dets", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+                ("stream", C.c_void_p), ("reserved", C.c_int * 6)]
+
+
+class MotError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libmot_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MotError(f"{LIB_PATH} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.mot_last_error.restype = C.c_char_p
+    lib.mot_ctx_stream.restype = C.c_void_p
+    lib.mot_ctx_stream.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a
+
+
+def boxes_array(boxes) -> np.ndarray:
+    """list of (l,t,b,r[,type[,score]]) / structured array -> contiguous BBOX_DTYPE array"""
+    if isinstance(boxes, np.ndarray) and boxes.dtype == BBOX_DTYPE:
+        return np.ascontiguousarray(boxes)
+    out = np.zeros(len(boxes), BBOX_DTYPE)
+    for i, b in enumerate(boxes):
+        if isinstance(b, BBox):
+            out[i] = (b.l, b.t, b.b, b.r, b.type, b.score)
+        else:
+            b = tuple(b)
+            out[i] = (b[0], b[1], b[2], b[3], b[4] if len(b) > 4 else 0, b[5] if len(b) > 5 else 0.9)
+    return out
+
+
+class MotContext:
+    """One tracker context = one GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, tracker_kind=TRACKER_KCF, device=0, max_tracks=256, max_dets=128, fhog_mode=FHOG_INTEL_APPROX,
+                 fft_mode=FFT_AUTO, rank=0, world=1, stream=None):
+        self.lib = load_library()
+        cfg = MotConfig()
+        self.lib.mot_config_default(C.byref(cfg))
+        cfg.device, cfg.tracker_kind, cfg.max_tracks, cfg.max_dets = device, tracker_kind, max_tracks, max_dets
+        cfg.fhog_mode, cfg.fft_mode, cfg.rank, cfg.world = fhog_mode, fft_mode, rank, world
+        cfg.stream = stream
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._chk(self.lib.mot_ctx_create(C.byref(cfg), C.byref(self._h)))
+        self.max_tracks, self.max_dets, self.world, self.rank = max_tracks, max_dets, world, rank
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MotError(f"mot error {rc}: {self.lib.mot_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.mot_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.mot_ctx_stream(self._h) or 0)
+
+    def sync(self):
+        self._chk(self.lib.mot_ctx_sync(self._h))
+
+    # ---- frame ----
+    def frame_upload(self, frame_bgr: np.ndarray):
+        f = np.ascontiguousarray(frame_bgr, dtype=np.uint8)
+        assert f.shape == (FRAME_H, FRAME_W, 3)
+        self._chk(self.lib.mot_frame_upload(self._h, _vp(f)))
+
+    def frame_bind_device(self, dev_ptr: int):
+        self._chk(self.lib.mot_frame_bind_device(self._h, C.c_void_p(dev_ptr)))
+
+    # ---- batch stages ----
+    def tracks_new(self, boxes, first_update=True) -> np.ndarray:
+        b = boxes_array(boxes)
+        ids = np.zeros(len(b), np.int32)
+        fn = self.lib.mot_tracks_new if first_update else self.lib.mot_tracks_new_nofirst
+        self._chk(fn(self._h, _vp(b), len(b), _vp(ids)))
+        return ids
+
+    def predict_batch(self, ids, clamp=True, boxes_inout=None) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, np.int32)
+        out = boxes_array(boxes_inout).copy() if boxes_inout is not None else np.zeros(len(ids), BBOX_DTYPE)
+        self._chk(self.lib.mot_predict_batch(self._h, _vp(ids), len(ids), _vp(out), int(clamp)))
+        return out
+
+    def update_batch(self, ids, boxes):
+        ids = np.ascontiguousarray(ids, np.int32)
+        b = boxes_array(boxes)
+        self._chk(self.lib.mot_update_batch(self._h, _vp(ids), len(ids), _vp(b)))
+
+    def delete_batch(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._chk(self.lib.mot_delete_batch(self._h, _vp(ids), len(ids)))
+
+    def _patch_ptrs(self, patches):
+        keep = [np.ascontiguousarray(p, np.float32) for p in patches]
+        arr = (C.c_void_p * len(keep))(*[p.ctypes.data for p in keep])
+        return keep, arr
+
+    def predict_batch_patches(self, ids, patches, boxes_inout=None) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, np.int32)
+        keep, arr = self._patch_ptrs(patches)
+        out = boxes_array(boxes_inout).copy() if boxes_inout is not None else np.zeros(len(ids), BBOX_DTYPE)
+        self._chk(self.lib.mot_predict_batch_patches(self._h, _vp(ids), len(ids), arr, _vp(out)))
+        return out
+
+    def update_batch_patches(self, ids, patches, boxes):
+        ids = np.ascontiguousarray(ids, np.int32)
+        keep, arr = self._patch_ptrs(patches)
+        b = boxes_array(boxes)
+        self._chk(self.lib.mot_update_batch_patches(self._h, _vp(ids), len(ids), arr, _vp(b)))
+
+    # ---- association ----
+    def assign(self, trk, det, want_cost=True):
+        t, d = boxes_array(trk), boxes_array(det)
+        at = np.full(max(len(t), 1), -1, np.int32)
+        ad = np.full(max(len(d), 1), -1, np.int32)
+        cost = C.c_double(0.0)
+        self._chk(self.lib.mot_assign(self._h, _vp(t), len(t), _vp(d), len(d), _vp(at), _vp(ad), C.byref(cost) if want_cost else None))
+        return at[:len(t)], ad[:len(d)], cost.value
+
+    def assignment_optimal(self, dist: np.ndarray, n_rows: int, n_cols: int):
+        """assignmentoptimal(): dist is column-major float64 [n_rows x n_cols]"""
+        d = np.ascontiguousarray(dist, np.float64).ravel()
+        assert d.size == n_rows * n_cols
+        a = np.full(max(n_rows, 1), -1, np.int32)
+        cost = C.c_double(0.0)
+        self._chk(self.lib.mot_assignment_optimal(self._h, _vp(a), C.byref(cost), _vp(d), n_rows, n_cols))
+        return a[:n_rows], cost.value
+
+    def cost_matrix(self, trk, det) -> np.ndarray:
+        t, d = boxes_array(trk), boxes_array(det)
+        out = np.zeros(len(t) * len(d), np.float64)
+        self._chk(self.lib.mot_cost_matrix(self._h, _vp(t), len(t), _vp(d), len(d), _vp(out)))
+        return out
+
+    # ---- frame loop ----
+    def step_frame(self, dets):
+        d = boxes_array(dets)
+        cap = self.max_tracks + 1
+        pred = np.zeros(cap, BBOX_DTYPE); at = np.zeros(cap, np.int32); live = np.zeros(cap, BBOX_DTYPE); tids = np.zeros(cap, np.uint32)
+        nb, nl = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_step_frame(self._h, _vp(d), len(d), _vp(pred), _vp(at), C.byref(nb), _vp(live), _vp(tids), C.byref(nl)))
+        return dict(predicted=pred[:nb.value].copy(), assigned=at[:nb.value].copy(), live=live[:nl.value].copy(), tids=tids[:nl.value].copy())
+
+    def step_begin(self):
+        ptr, spr = C.c_void_p(), C.c_int(0)
+        self._chk(self.lib.mot_step_begin(self._h, C.byref(ptr), C.byref(spr)))
+        return int(ptr.value or 0), spr.value
+
+    def step_finish(self, gathered_dev_ptr, dets):
+        d = boxes_array(dets)
+        cap = self.max_tracks + 1
+        pred = np.zeros(cap, BBOX_DTYPE); at = np.zeros(cap, np.int32); live = np.zeros(cap, BBOX_DTYPE); tids = np.zeros(cap, np.uint32)
+        nb, nl = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_step_finish(self._h, C.c_void_p(gathered_dev_ptr) if gathered_dev_ptr else None, _vp(d), len(d),
+                                           _vp(pred), _vp(at), C.byref(nb), _vp(live), _vp(tids), C.byref(nl)))
+        return dict(predicted=pred[:nb.value].copy(), assigned=at[:nb.value].copy(), live=live[:nl.value].copy(), tids=tids[:nl.value].copy())
+
+    # device-resident steady-state loop
+    def step_frame_device(self, frame_dev: int, dets_dev: int, n_dets: int):
+        self._chk(self.lib.mot_step_frame_device(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets))
+
+    def step_begin_device(self, frame_dev: int):
+        ptr, spr = C.c_void_p(), C.c_int(0)
+        self._chk(self.lib.mot_step_begin_device(self._h, C.c_void_p(frame_dev), C.byref(ptr), C.byref(spr)))
+        return int(ptr.value or 0), spr.value
+
+    def step_finish_device(self, gathered_dev: int, dets_dev: int, n_dets: int):
+        self._chk(self.lib.mot_step_finish_device(self._h, C.c_void_p(gathered_dev), C.c_void_p(dets_dev), n_dets))
+
+    def profile_frame_device(self, frame_dev: int, dets_dev: int, n_dets: int) -> np.ndarray:
+        ms = np.zeros(5, np.float32)
+        self._chk(self.lib.mot_profile_frame_device(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets, _vp(ms)))
+        return ms
+
+    def live_count(self) -> int:
+        n = C.c_int(0)
+        self._chk(self.lib.mot_live_count(self._h, C.byref(n)))
+        return n.value
+
+    def live_tracks(self):
+        cap = self.max_tracks + 1
+        boxes = np.zeros(cap, BBOX_DTYPE); tids = np.zeros(cap, np.uint32); ages = np.zeros(cap, np.int32); n = C.c_int(0)
+        self._chk(self.lib.mot_live_tracks(self._h, _vp(boxes), _vp(tids), _vp(ages), C.byref(n)))
+        return boxes[:n.value].copy(), tids[:n.value].copy(), ages[:n.value].copy()
+
+    # ---- introspection ----
+    def get_response(self, tid: int) -> np.ndarray:
+        fr, fc = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_get_response(self._h, int(tid), None, C.byref(fr), C.byref(fc)))
+        out = np.zeros(fr.value * fc.value, np.float32)
+        self._chk(self.lib.mot_get_response(self._h, int(tid), _vp(out), C.byref(fr), C.byref(fc)))
+        return out
+
+    def get_model(self, tid: int):
+        fr, fc = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_get_response(self._h, int(tid), None, C.byref(fr), C.byref(fc)))
+        nbins = fc.value * (fr.value // 2 + 1)
+        xm = np.zeros(31 * nbins * 2, np.float32); alpha = np.zeros(nbins, np.float32)
+        self._chk(self.lib.mot_get_model(self._h, int(tid), _vp(xm), _vp(alpha)))
+        return xm, alpha
+
+    def get_kalman_state(self, tid: int):
+        x = np.zeros(6); P = np.zeros(36)
+        self._chk(self.lib.mot_get_kalman_state(self._h, int(tid), _vp(x), _vp(P)))
+        return x, P
+
+    def get_pos(self, tid: int):
+        b = np.zeros(1, BBOX_DTYPE)
+        self._chk(self.lib.mot_get_pos(self._h, int(tid), _vp(b)))
+        return b[0]
+
+    def fhog_extract(self, patch: np.ndarray, h: int, w: int, windowed=False) -> np.ndarray:
+        p = np.ascontiguousarray(patch, np.float32).ravel()
+        assert p.size == h * w
+        out = np.zeros(32 * (h // 4) * (w // 4), np.float32)
+        self._chk(self.lib.mot_fhog_extract(self._h, _vp(p), h, w, _vp(out), int(windowed)))
+        return out
+
+    def crop_patch(self, box, rows: int, cols: int) -> np.ndarray:
+        b = boxes_array([box])
+        out = np.zeros(rows * cols, np.float32)
+        self._chk(self.lib.mot_crop_patch(self._h, _vp(b), rows, cols, _vp(out)))
+        return out
+
+    # ---- timers ----
+    def timer_create(self, n):
+        self._chk(self.lib.mot_timer_create(self._h, n))
+
+    def timer_record(self, i):
+        self._chk(self.lib.mot_timer_record(self._h, i))
+
+    def timer_elapsed_ms(self, a, b) -> float:
+        ms = C.c_float(0)
+        self._chk(self.lib.mot_timer_elapsed_ms(self._h, a, b, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,751 @@
+// kcf_kernels.hip -- fused per-track KCF predict / update kernels for gfx950.
+//
+// One 512-thread workgroup per track.  All intermediates of the reference's
+// per-track pipeline
+//     rgb2Gray + bilinearInterpolationGray   (top/drawlib.c:192-240, 542-637)
+//     FHoG::extract                          (libhog/fhog.h:16, gradientMex.cpp)
+//     31 x r2c 2-D FFT                       (trackers/kcf.cpp:261-267, FFTW)
+//     linear correlation / alpha / model     (trackers/kcf.cpp:269-395)
+//     c2r + arg-max + box shift              (trackers/kcf.cpp:397-428)
+// live in one scratch slab (LDS when it fits in 160 KB, else an HBM slab per
+// workgroup); only the u8 crop, the model xm/alpha and the boxes touch HBM.
+//
+// Numerics: everything up to and including the 31 FHOG channels is computed
+// with the reference's exact float operation order and separate roundings
+// (-ffp-contract=off) so features are bit-identical to the as-compiled
+// reference, including its rcpps/rsqrtps approximations (table emulation).
+// The DFTs are free to contract (FFTW's own rounding is not reproducible).
+#include "mot_dev.h"
+#include "bin_thresholds.inc"
+
+#define PI_F 3.14159265f /* libhog/gradientMex.cpp:12 */
+
+namespace {
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// x86 rcpps / rsqrtps (libhog/sse.hpp:40-41) -- integer model, see tools/gen_sse_tables.c
+__device__ __forceinline__ float sse_rcp(float x, const uint16_t* tab)
+{
+    uint32_t u = f2u(x), s = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffff;
+    if (e == 0xff) return u2f(m ? (u | 0x400000u) : s);
+    if (e == 0) return u2f(s | 0x7f800000u);
+    int ep = 253 - (int)e;
+    if (ep <= 0) return u2f(s);
+    return u2f(s | ((uint32_t)ep << 23) | ((uint32_t)tab[m >> 12] << 11));
+}
+__device__ __forceinline__ float sse_rsqrt(float x, const uint16_t* tab)
+{
+    uint32_t u = f2u(x), s = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffff;
+    if (e == 0xff && m) return u2f(u | 0x400000u);
+    if (e == 0) return u2f(s | 0x7f800000u);
+    if (s) return u2f(0xffc00000u);
+    if (e == 0xff) return 0.0f;
+    int E = (int)e - 127, odd = E & 1;
+    int ep = odd ? 126 - (E - 1) / 2 : 126 - E / 2;
+    return u2f(((uint32_t)ep << 23) | ((uint32_t)tab[2048 + odd * 1024 + (m >> 13)] << 11));
+}
+
+// drawlib.c:234 -- double arithmetic, one rounding to float at the end.
+__device__ __forceinline__ float gray_of(const uint8_t* __restrict__ frame, int y, int x)
+{
+    y = min(max(y, 0), MOT_FRAME_H - 1);   // the reference reads unchecked; boxes are clamped by the caller
+    x = min(max(x, 0), MOT_FRAME_W - 1);
+    const uint8_t* p = frame + ((size_t)y * MOT_FRAME_W + x) * 3;
+    double B = (double)p[0], G = (double)p[1], R = (double)p[2];
+    return (float)(0.144 * B + 0.587 * G + 0.299 * R);
+}
+
+struct Ctx {
+    int tid, nt;
+};
+
+// ---------------------------------------------------------------------------
+// Phase 0: crop + gray + (bilinear resize) -> P[c*ldp + r]
+// ---------------------------------------------------------------------------
+__device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, const float* __restrict__ patch,
+                           bbox_t box, float* __restrict__ P, int tid, int nt)
+{
+    const int rows = p.rows, cols = p.cols, npx = rows * cols;
+    if (patch) {
+        for (int d = tid; d < npx; d += nt) {
+            uint32_t c, r; p.d_rows.divmod((uint32_t)d, c, r);
+            P[c * p.ldp + r] = patch[d];
+        }
+        return;
+    }
+    int left = box.l, top = box.t, right = box.r, bottom = box.b;
+    if (top > bottom) { int t = top; top = bottom; bottom = t; }      // drawlib.c:203-215
+    if (left > right) { int t = left; left = right; right = t; }
+    const int hs = box.b - box.t + 1, ws = box.r - box.l + 1;          // td.cpp:360-361 (as passed to the resize)
+    const int rows_s = bottom - top + 1;                               // rgb2Gray's column stride
+    if (hs == rows && ws == cols && rows_s == rows) {
+        // identity resize (frac == 0): patch flat index d = c*rows + r <-> pixel (top+r, left+c)
+        for (int i = tid; i < npx; i += nt) {
+            uint32_t r, c; p.d_cols.divmod((uint32_t)i, r, c);         // c fastest: contiguous BGR bytes
+            P[c * p.ldp + r] = gray_of(frame, top + (int)r, left + (int)c);
+        }
+        return;
+    }
+    // general case, drawlib.c:542-637 called as (heightSource=hs, widthSource=ws, height=rows, width=cols);
+    // the source scratch is rgb2Gray's column-major buffer read with flat index y0*ws+x0.
+    const float xs = ((float)ws) / ((float)cols);
+    const float ys = ((float)hs) / ((float)rows);
+    FastDiv drs; // flat source index -> (col, row) of the gray scratch
+    const uint32_t urs = (uint32_t)max(rows_s, 1);
+    for (int d = tid; d < npx; d += nt) {
+        uint32_t y, x; p.d_cols.divmod((uint32_t)d, y, x);             // dst flat = y*width + x
+        float sy = (float)y * ys; int y0 = (int)sy; float fracy = sy - (float)y0, ifracy = 1.0f - fracy;
+        int y1 = y0 + 1; if (y1 >= hs) y1 = y0;
+        float sx = (float)x * xs; int x0 = (int)sx; float fracx = sx - (float)x0, ifracx = 1.0f - fracx;
+        int x1 = x0 + 1; if (x1 >= ws) x1 = x0;
+        int s1 = y0 * ws + x0, s2 = y0 * ws + x1, s3 = y1 * ws + x0, s4 = y1 * ws + x1;
+        float c1 = gray_of(frame, top + (int)((uint32_t)s1 % urs), left + (int)((uint32_t)s1 / urs));
+        float c2 = gray_of(frame, top + (int)((uint32_t)s2 % urs), left + (int)((uint32_t)s2 / urs));
+        float c3 = gray_of(frame, top + (int)((uint32_t)s3 % urs), left + (int)((uint32_t)s3 / urs));
+        float c4 = gray_of(frame, top + (int)((uint32_t)s4 % urs), left + (int)((uint32_t)s4 / urs));
+        float l0 = ifracx * c1 + fracx * c2;                           // drawlib.c:625-627
+        float l1 = ifracx * c3 + fracx * c4;
+        float v = ifracy * l0 + fracy * l1;
+        uint32_t c, r; p.d_rows.divmod((uint32_t)d, c, r);             // KCF reads the flat array column-major
+        P[c * p.ldp + r] = v;
+    }
+    (void)drs;
+}
+
+// ---------------------------------------------------------------------------
+// Phase 1: gradMag (gradientMex.cpp:15-37, 59-100) + orientation quantisation
+// (:119-143) -> Mq = M*(1/16) (float), bin (u8)
+// ---------------------------------------------------------------------------
+__device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, float* __restrict__ Mq,
+                              uint8_t* __restrict__ bins, const uint16_t* __restrict__ tab, int tid, int nt)
+{
+    const int h = p.rows, w = p.cols, npx = h * w, ldp = p.ldp;
+    const int thr0[9] = MOT_BIN_THR0;
+    const int thr1[9] = MOT_BIN_THR1;
+    const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
+    for (int i = tid; i < npx; i += nt) {
+        uint32_t x, y; p.d_rows.divmod((uint32_t)i, x, y);
+        const float* Ic = P + x * ldp;
+        float gx, gy;
+        if (x == 0) gx = (Ic[ldp + y] - Ic[y]) * 1.0f;
+        else if ((int)x == w - 1) gx = (Ic[y] - Ic[(int)y - ldp]) * 1.0f;
+        else gx = (Ic[ldp + y] - Ic[(int)y - ldp]) * 0.5f;
+        if (y == 0) gy = (Ic[1] - Ic[0]) * 1.0f;
+        else if ((int)y == h - 1) gy = (Ic[h - 1] - Ic[h - 2]) * 1.0f;
+        else gy = (Ic[y + 1] - Ic[y - 1]) * 0.5f;
+        float m2 = gx * gx + gy * gy;
+        float m = approx ? sse_rsqrt(m2, tab) : 1.0f / sqrtf(m2);
+        if (!(m < 1e10f)) m = 1e10f;                                   // _mm_min_ps(m, 1e10f)
+        float mag = approx ? sse_rcp(m, tab) : 1.0f / m;
+        float g = (gx * m) * 10000.0f;
+        g = u2f(f2u(g) ^ (f2u(gy) & 0x80000000u));
+        int idx = (int)g;
+        int flag = gy < 0.0f;
+        int b = flag ? MOT_BIN_TOP1 : MOT_BIN_TOP0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) b -= (idx >= (flag ? thr1[j] : thr0[j])) ? 1 : 0;
+        if (b >= 18) b = 0;
+        Mq[i] = mag * 0.0625f;                                         // norm = 1/bin/bin (:152,132)
+        bins[i] = (uint8_t)b;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Phase 2: gradHist, trilinear branch with nearest orientation
+// (gradientMex.cpp:183-221) as a GATHER: one thread owns one cell and adds the
+// contributions of its <= 8x8 pixel footprint in the reference's order
+// (x outer, y inner), so every R1 value is bit-identical.  Then :225-230.
+// ---------------------------------------------------------------------------
+__device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
+                           float* __restrict__ R1, int tid, int nt)
+{
+    const int h = p.rows, hb = p.hb, wb = p.wb, nb = p.nb;
+    const int h0 = hb * 4, w0 = wb * 4;
+    for (int cell = tid; cell < nb; cell += nt) {
+        uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
+#pragma unroll
+        for (int o = 0; o < MOT_NORI; o++) R1[o * nb + cell] = 0.0f;
+        const int x_lo = max(0, 4 * (int)cx - 2), x_hi = min(w0 - 1, 4 * (int)cx + 5);
+        const int y_lo = max(0, 4 * (int)cy - 2), y_hi = min(h0 - 1, 4 * (int)cy + 5);
+        for (int x = x_lo; x <= x_hi; x++) {
+            const float xb = -0.375f + 0.25f * (float)x;               // init + x*sInv, exact
+            const int xb0 = (xb >= 0.0f) ? (int)xb : -1;
+            const float xd = xb - (float)xb0;
+            const bool left = (xb0 == (int)cx);                        // else this cell is the right neighbour (xb0+1)
+            for (int y = y_lo; y <= y_hi; y++) {
+                const float yb = -0.375f + 0.25f * (float)y;
+                const int yb0 = (y < 2) ? -1 : (int)yb;
+                const float yd = yb - (float)yb0;
+                const bool topc = (yb0 == (int)cy);
+                const float xyd = xd * yd;
+                float ms;
+                if (left) ms = topc ? (1.0f - xd - yd + xyd) : (yd - xyd);
+                else ms = topc ? (xd - xyd) : xyd;
+                const int pi = x * h + y;
+                const int o = bins[pi];
+                const float term = ms * Mq[pi];
+                R1[o * nb + cell] += term;
+            }
+        }
+        int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
+        if (nmul) {
+            const float c = 8.f / 7.f;
+            for (int o = 0; o < MOT_NORI; o++) {
+                float v = R1[o * nb + cell];
+                for (int k = 0; k < nmul; k++) v *= c;
+                R1[o * nb + cell] = v;
+            }
+        }
+    }
+}
+
+// Phase 3a: E[cell] = sum_o (R1[o]+R1[o+9])^2  (gradientMex.cpp:308-309, 240-241)
+__device__ void phase_energy(const KcfPool& p, const float* __restrict__ R1, float* __restrict__ E, int tid, int nt)
+{
+    const int nb = p.nb;
+    for (int cell = tid; cell < nb; cell += nt) {
+        float e = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 9; o++) {
+            float r2 = R1[o * nb + cell] + R1[(o + 9) * nb + cell];
+            e += r2 * r2;
+        }
+        E[cell] = e;
+    }
+}
+
+// Phase 3b: N[(x)*(hb+1)+y] (gradientMex.cpp:242-251)
+__device__ void phase_norm(const KcfPool& p, const float* __restrict__ E, float* __restrict__ N, int tid, int nt)
+{
+    const int hb = p.hb, wb = p.wb, hb1 = hb + 1, wb1 = wb + 1;
+    const float eps = 1e-4f / 4 / 4 / 4 / 4 / 4;
+    for (int i = tid; i < hb1 * wb1; i += nt) {
+        int x = i / hb1, y = i - x * hb1;
+        int cx = min(max(x, 1), wb - 1), cy = min(max(y, 1), hb - 1);  // replicated border
+        const float* n = E + (cx - 1) * hb + (cy - 1);
+        N[i] = 1.0f / sqrtf(n[0] + n[1] + n[hb] + n[hb + 1] + eps);
+    }
+}
+
+// Phase 4: hogChannels (gradientMex.cpp:256-280, 313-315) x cos window
+// (kcf.cpp:249-258).  F[(ch*wb + x)*ldf + y], ldf = 2*fh.
+__device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, const float* __restrict__ N,
+                               float* __restrict__ F, float* __restrict__ feat_out, int feat_windowed, int tid, int nt)
+{
+    const int hb = p.hb, wb = p.wb, nb = p.nb, hb1 = hb + 1, ldf = 2 * p.fh;
+    const float clip = 0.2f, r = .2357f;
+    for (int cell = tid; cell < nb; cell += nt) {
+        uint32_t x, y; p.d_hb.divmod((uint32_t)cell, x, y);
+        const float n0 = N[(x + 1) * hb1 + y + 1], n1 = N[(x + 1) * hb1 + y], n2 = N[x * hb1 + y + 1], n3 = N[x * hb1 + y];
+        const float win = p.cos_win[cell];
+        float tex0 = 0.f, tex1 = 0.f, tex2 = 0.f, tex3 = 0.f;
+        float rlo[9];
+#pragma unroll
+        for (int o = 0; o < MOT_NORI; o++) {
+            const float v = R1[o * nb + cell];
+            if (o < 9) rlo[o] = v;
+            float t0 = v * n0; if (t0 > clip) t0 = clip;
+            float t1 = v * n1; if (t1 > clip) t1 = clip;
+            float t2 = v * n2; if (t2 > clip) t2 = clip;
+            float t3 = v * n3; if (t3 > clip) t3 = clip;
+            float hv = 0.0f;
+            hv += t0 * .5f; hv += t1 * .5f; hv += t2 * .5f; hv += t3 * .5f;
+            tex0 += t0 * r; tex1 += t1 * r; tex2 += t2 * r; tex3 += t3 * r;
+            F[(o * wb + x) * ldf + y] = hv * win;
+            if (feat_out) feat_out[o * nb + cell] = feat_windowed ? hv * win : hv;
+            if (o >= 9) {
+                const float v2 = rlo[o - 9] + v;                        // R2 (:309)
+                float u0 = v2 * n0; if (u0 > clip) u0 = clip;
+                float u1 = v2 * n1; if (u1 > clip) u1 = clip;
+                float u2 = v2 * n2; if (u2 > clip) u2 = clip;
+                float u3 = v2 * n3; if (u3 > clip) u3 = clip;
+                float hi = 0.0f;
+                hi += u0 * .5f; hi += u1 * .5f; hi += u2 * .5f; hi += u3 * .5f;
+                const int ch = 18 + (o - 9);
+                F[(ch * wb + x) * ldf + y] = hi * win;
+                if (feat_out) feat_out[ch * nb + cell] = feat_windowed ? hi * win : hi;
+            }
+        }
+        F[((27 + 0) * wb + x) * ldf + y] = tex0 * win;
+        F[((27 + 1) * wb + x) * ldf + y] = tex1 * win;
+        F[((27 + 2) * wb + x) * ldf + y] = tex2 * win;
+        F[((27 + 3) * wb + x) * ldf + y] = tex3 * win;
+        if (feat_out) {
+            feat_out[27 * nb + cell] = feat_windowed ? tex0 * win : tex0;
+            feat_out[28 * nb + cell] = feat_windowed ? tex1 * win : tex1;
+            feat_out[29 * nb + cell] = feat_windowed ? tex2 * win : tex2;
+            feat_out[30 * nb + cell] = feat_windowed ? tex3 * win : tex3;
+            feat_out[31 * nb + cell] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// DFTs (replace FFTW; kcf.cpp:180-195 layout: n0 = f_cols slow, n1 = f_rows
+// fast, half spectrum along n1).  Contraction allowed from here on.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(fast)
+
+// generic forward r2c along y: F[(ch*wb+x)*ldf + y] (real) -> T[((ch*wb+x)*fh + k)] complex
+__device__ void dft_rows_generic(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
+                                 const float2* __restrict__ twr, int tid, int nt)
+{
+    const int hb = p.hb, fh = p.fh, ldf = 2 * fh, total = MOT_NCHAN * p.wb * fh;
+    for (int i = tid; i < total; i += nt) {
+        uint32_t row, k; p.d_fh.divmod((uint32_t)i, row, k);
+        const float* in = F + row * ldf;
+        float re = 0.f, im = 0.f; int j = 0;
+        for (int y = 0; y < hb; y++) {
+            const float2 w = twr[j]; const float v = in[y];
+            re += v * w.x; im -= v * w.y;
+            j += (int)k; if (j >= hb) j -= hb;
+        }
+        T[i] = make_float2(re, im);
+    }
+}
+
+// generic complex DFT along x (length wb): in[(ch*wb + x)*fh + k] -> out[(ch*wb + x')*fh + k]
+template <int SIGN>
+__device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in, float2* __restrict__ out,
+                                 const float2* __restrict__ twc, int nch, int tid, int nt)
+{
+    const int wb = p.wb, fh = p.fh, plane = wb * fh, total = nch * plane;
+    for (int i = tid; i < total; i += nt) {
+        uint32_t ch, b; p.d_nbins.divmod((uint32_t)i, ch, b);
+        uint32_t xp, k; p.d_fh.divmod(b, xp, k);
+        const float2* src = in + ch * plane + k;
+        float re = 0.f, im = 0.f; int j = 0;
+        for (int x = 0; x < wb; x++) {
+            const float2 w = twc[j]; const float2 v = src[x * fh];
+            const float wi = (SIGN < 0) ? -w.y : w.y;
+            re += v.x * w.x - v.y * wi; im += v.x * wi + v.y * w.x;
+            j += (int)xp; if (j >= wb) j -= wb;
+        }
+        out[i] = make_float2(re, im);
+    }
+}
+
+// ---- radix 4x5 prime-factor 20-point transforms, one thread per transform ----
+#define C1_5 0.30901699437494742f   /* cos(2pi/5) */
+#define C2_5 (-0.80901699437494742f) /* cos(4pi/5) */
+#define S1_5 0.95105651629515357f   /* sin(2pi/5) */
+#define S2_5 0.58778525229247313f   /* sin(4pi/5) */
+
+// real input x[20] -> X[0..10]; in place on a 22-float row
+__device__ __forceinline__ void rfft20_inplace(float* __restrict__ row)
+{
+    float x[20];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { float2 v = *reinterpret_cast<const float2*>(row + 2 * i); x[2 * i] = v.x; x[2 * i + 1] = v.y; }
+    // stage 1: four real 5-point DFTs over n2 (input n = (5*n1 + 4*n2) mod 20), outputs k2 = 0,1,2
+    float y0[4], y1r[4], y1i[4], y2r[4], y2i[4];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) {
+        const float a0 = x[(5 * n1) % 20], a1 = x[(5 * n1 + 4) % 20], a2 = x[(5 * n1 + 8) % 20], a3 = x[(5 * n1 + 12) % 20], a4 = x[(5 * n1 + 16) % 20];
+        const float s14 = a1 + a4, d14 = a1 - a4, s23 = a2 + a3, d23 = a2 - a3;
+        y0[n1] = a0 + s14 + s23;
+        y1r[n1] = a0 + C1_5 * s14 + C2_5 * s23; y1i[n1] = -(S1_5 * d14 + S2_5 * d23);
+        y2r[n1] = a0 + C2_5 * s14 + C1_5 * s23; y2i[n1] = -(S2_5 * d14 - S1_5 * d23);
+    }
+    float2 X[11];
+    {   // k2 = 0 (real): k = 0,5,10
+        const float t0 = y0[0] + y0[2], t1 = y0[0] - y0[2], t2 = y0[1] + y0[3], t3 = y0[1] - y0[3];
+        X[0] = make_float2(t0 + t2, 0.f); X[10] = make_float2(t0 - t2, 0.f); X[5] = make_float2(t1, -t3);
+    }
+    {   // k2 = 1: k1=0 -> 16 (=conj 4), k1=1 -> 1, k1=2 -> 6, k1=3 -> 11 (=conj 9)
+        const float t0r = y1r[0] + y1r[2], t0i = y1i[0] + y1i[2], t1r = y1r[0] - y1r[2], t1i = y1i[0] - y1i[2];
+        const float t2r = y1r[1] + y1r[3], t2i = y1i[1] + y1i[3], t3r = y1r[1] - y1r[3], t3i = y1i[1] - y1i[3];
+        X[4] = make_float2(t0r + t2r, -(t0i + t2i));            // conj(Z0)
+        X[6] = make_float2(t0r - t2r, t0i - t2i);                // Z2
+        X[1] = make_float2(t1r + t3i, t1i - t3r);                // Z1 = t1 - i t3
+        X[9] = make_float2(t1r - t3i, -(t1i + t3r));             // conj(Z3), Z3 = t1 + i t3
+    }
+    {   // k2 = 2: k1=0 -> 12 (=conj 8), k1=1 -> 17 (=conj 3), k1=2 -> 2, k1=3 -> 7
+        const float t0r = y2r[0] + y2r[2], t0i = y2i[0] + y2i[2], t1r = y2r[0] - y2r[2], t1i = y2i[0] - y2i[2];
+        const float t2r = y2r[1] + y2r[3], t2i = y2i[1] + y2i[3], t3r = y2r[1] - y2r[3], t3i = y2i[1] - y2i[3];
+        X[8] = make_float2(t0r + t2r, -(t0i + t2i));            // conj(Z0)
+        X[2] = make_float2(t0r - t2r, t0i - t2i);                // Z2
+        X[3] = make_float2(t1r + t3i, -(t1i - t3r));             // conj(Z1)
+        X[7] = make_float2(t1r - t3i, t1i + t3r);                // Z3
+    }
+#pragma unroll
+    for (int k = 0; k < 11; k++) *reinterpret_cast<float2*>(row + 2 * k) = X[k];
+}
+
+// complex 20-point DFT, stride `st` (in float2), in place.  SIGN=-1 forward, +1 inverse (unnormalised)
+template <int SIGN>
+__device__ __forceinline__ void cfft20_inplace(float2* __restrict__ base, int st)
+{
+    float2 x[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) x[i] = base[i * st];
+    float2 Y[4][5];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) {
+        const float2 a0 = x[(5 * n1) % 20], a1 = x[(5 * n1 + 4) % 20], a2 = x[(5 * n1 + 8) % 20], a3 = x[(5 * n1 + 12) % 20], a4 = x[(5 * n1 + 16) % 20];
+        const float2 s14 = make_float2(a1.x + a4.x, a1.y + a4.y), d14 = make_float2(a1.x - a4.x, a1.y - a4.y);
+        const float2 s23 = make_float2(a2.x + a3.x, a2.y + a3.y), d23 = make_float2(a2.x - a3.x, a2.y - a3.y);
+        Y[n1][0] = make_float2(a0.x + s14.x + s23.x, a0.y + s14.y + s23.y);
+        const float2 R1 = make_float2(a0.x + C1_5 * s14.x + C2_5 * s23.x, a0.y + C1_5 * s14.y + C2_5 * s23.y);
+        const float2 R2 = make_float2(a0.x + C2_5 * s14.x + C1_5 * s23.x, a0.y + C2_5 * s14.y + C1_5 * s23.y);
+        const float2 I1 = make_float2(S1_5 * d14.x + S2_5 * d23.x, S1_5 * d14.y + S2_5 * d23.y);
+        const float2 I2 = make_float2(S2_5 * d14.x - S1_5 * d23.x, S2_5 * d14.y - S1_5 * d23.y);
+        // forward: Y1 = R1 - i*I1 = (R1.x + I1.y, R1.y - I1.x); inverse: Y1 = R1 + i*I1
+        if (SIGN < 0) {
+            Y[n1][1] = make_float2(R1.x + I1.y, R1.y - I1.x); Y[n1][4] = make_float2(R1.x - I1.y, R1.y + I1.x);
+            Y[n1][2] = make_float2(R2.x + I2.y, R2.y - I2.x); Y[n1][3] = make_float2(R2.x - I2.y, R2.y + I2.x);
+        } else {
+            Y[n1][1] = make_float2(R1.x - I1.y, R1.y + I1.x); Y[n1][4] = make_float2(R1.x + I1.y, R1.y - I1.x);
+            Y[n1][2] = make_float2(R2.x - I2.y, R2.y + I2.x); Y[n1][3] = make_float2(R2.x + I2.y, R2.y - I2.x);
+        }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 5; k2++) {
+        const float2 t0 = make_float2(Y[0][k2].x + Y[2][k2].x, Y[0][k2].y + Y[2][k2].y);
+        const float2 t1 = make_float2(Y[0][k2].x - Y[2][k2].x, Y[0][k2].y - Y[2][k2].y);
+        const float2 t2 = make_float2(Y[1][k2].x + Y[3][k2].x, Y[1][k2].y + Y[3][k2].y);
+        const float2 t3 = make_float2(Y[1][k2].x - Y[3][k2].x, Y[1][k2].y - Y[3][k2].y);
+        const float2 Z0 = make_float2(t0.x + t2.x, t0.y + t2.y), Z2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+        float2 Z1, Z3;   // forward: Z1 = t1 - i t3, Z3 = t1 + i t3
+        if (SIGN < 0) { Z1 = make_float2(t1.x + t3.y, t1.y - t3.x); Z3 = make_float2(t1.x - t3.y, t1.y + t3.x); }
+        else { Z1 = make_float2(t1.x - t3.y, t1.y + t3.x); Z3 = make_float2(t1.x + t3.y, t1.y - t3.x); }
+        base[((0 * 5 + 16 * k2) % 20) * st] = Z0;
+        base[((1 * 5 + 16 * k2) % 20) * st] = Z1;
+        base[((2 * 5 + 16 * k2) % 20) * st] = Z2;
+        base[((3 * 5 + 16 * k2) % 20) * st] = Z3;
+    }
+}
+
+// forward 2-D r2c of the 31 feature planes; result S[(ch*wb + x')*fh + k] in region B.
+// F lives in region B (row stride ldf = 2*fh floats); A is the ping-pong buffer.
+__device__ void fft_forward(const KcfPool& p, float* __restrict__ regA, float* __restrict__ regB,
+                            const float2* __restrict__ twr, const float2* __restrict__ twc, int tid, int nt)
+{
+    if (p.fft20) {
+        const int nrows = MOT_NCHAN * p.wb;
+        for (int r = tid; r < nrows; r += nt) rfft20_inplace(regB + r * 22);
+        __syncthreads();
+        float2* S = reinterpret_cast<float2*>(regB);
+        const int ncol = MOT_NCHAN * 11;
+        for (int i = tid; i < ncol; i += nt) {
+            const int ch = i / 11, k = i - ch * 11;
+            cfft20_inplace<-1>(S + ch * 220 + k, 11);
+        }
+        __syncthreads();
+    } else {
+        float2* T = reinterpret_cast<float2*>(regA);
+        dft_rows_generic(p, regB, T, twr, tid, nt);
+        __syncthreads();
+        dft_cols_generic<-1>(p, T, reinterpret_cast<float2*>(regB), twc, MOT_NCHAN, tid, nt);
+        __syncthreads();
+    }
+}
+
+// inverse c2r of one plane: Z[(x')*fh + k] -> resp[x*hb + y], unnormalised (kcf.cpp:399)
+__device__ void fft_inverse_plane(const KcfPool& p, const float2* __restrict__ Z, float2* __restrict__ tmp,
+                                  float* __restrict__ resp, const float2* __restrict__ twr,
+                                  const float2* __restrict__ twc, int tid, int nt)
+{
+    const int hb = p.hb, wb = p.wb, fh = p.fh;
+    dft_cols_generic<+1>(p, Z, tmp, twc, 1, tid, nt);
+    __syncthreads();
+    const bool even = (hb % 2 == 0);
+    for (int i = tid; i < p.nb; i += nt) {
+        uint32_t x, y; p.d_hb.divmod((uint32_t)i, x, y);
+        const float2* src = tmp + x * fh;
+        float acc = src[0].x; int j = 0;
+        for (int k = 1; k < fh; k++) {
+            j += (int)y; if (j >= hb) j -= hb;
+            const float2 w = twr[j]; const float2 v = src[k];
+            const float term = v.x * w.x - v.y * w.y;
+            acc += (even && k == fh - 1) ? term : 2.0f * term;
+        }
+        resp[i] = acc;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// block-wide arg-max with the reference's scan semantics (kcf.cpp:402-418):
+// column-major scan, strict '>' against -99999 => first maximum wins.
+// ---------------------------------------------------------------------------
+__device__ int block_argmax_first(const float* __restrict__ resp, int n, float* __restrict__ red_v, int* __restrict__ red_i,
+                                  int tid, int nt)
+{
+    float bv = -99999.0f; int bi = -1;
+    for (int i = tid; i < n; i += nt) { const float v = resp[i]; if (v > bv) { bv = v; bi = i; } }
+    // within a thread indices increase, so '>' keeps the first
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(bv, off); const int oi = __shfl_down(bi, off);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    const int wave = tid >> 6, nw = (nt + 63) >> 6;
+    if ((tid & 63) == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nw; w++) {
+            const float ov = red_v[w]; const int oi = red_i[w];
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        red_i[0] = bi;
+    }
+    __syncthreads();
+    return red_i[0];
+}
+
+struct Regions {
+    float* A; float* B; float* C;
+    float* E; float* N; float2* twr; float2* twc; float2* zf; float2* tmp; float* resp; float* red_v; int* red_i;
+    uint16_t* tab;
+};
+
+__device__ __forceinline__ Regions carve(const KcfPool& p, float* base)
+{
+    Regions r;
+    r.A = base + p.offA; r.B = base + p.offB; r.C = base + p.offC;
+    float* c = r.C;
+    r.tab = reinterpret_cast<uint16_t*>(c); c += 2048;               // 4096 u16
+    r.twr = reinterpret_cast<float2*>(c); c += 2 * p.hb;
+    r.twc = reinterpret_cast<float2*>(c); c += 2 * p.wb;
+    r.zf = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
+    r.tmp = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
+    r.E = c; c += p.nb;
+    r.N = c; c += (p.hb + 1) * (p.wb + 1);
+    r.resp = c; c += p.nb;
+    r.red_v = c; c += 16;
+    r.red_i = reinterpret_cast<int*>(c); c += 16;
+    return r;
+}
+
+// Everything up to the spectrum S (region B): shared by predict / update.
+__device__ void features_to_spectrum(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r,
+                                     int tid, int nt, bool spectrum)
+{
+    // stage constants
+    for (int i = tid; i < 2048; i += nt) reinterpret_cast<uint32_t*>(r.tab)[i] = reinterpret_cast<const uint32_t*>(p.sse_tab)[i];
+    for (int i = tid; i < p.hb; i += nt) r.twr[i] = p.tw_r[i];
+    for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
+    const float* patch = l.patches ? l.patches + (size_t)item * p.rows * p.cols : nullptr;
+    phase_crop(p, l.frame, patch, box, r.A, tid, nt);
+    __syncthreads();
+    float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.rows * p.cols);
+    phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
+    __syncthreads();
+    phase_hist(p, Mq, bins, r.A, tid, nt);                           // R1 overlays the patch
+    __syncthreads();
+    phase_energy(p, r.A, r.E, tid, nt);
+    __syncthreads();
+    phase_norm(p, r.E, r.N, tid, nt);
+    __syncthreads();
+    float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
+    phase_channels(p, r.A, r.N, r.B, fo, l.feat_windowed, tid, nt); // F overlays Mq/bins
+    __syncthreads();
+    if (spectrum) fft_forward(p, r.A, r.B, r.twr, r.twc, tid, nt);
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    const Regions r = carve(p, base);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int slot = l.slots[item];
+    const bbox_t pos = p.pos[slot];                                    // kcf_t::pos == tracker_info.bbox (td.cpp:351-354)
+    features_to_spectrum(p, l, item, pos, r, tid, nt, true);
+    // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm
+    const float2* S = reinterpret_cast<const float2*>(r.B);
+    const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
+    for (int b = tid; b < p.nbins; b += nt) {
+        float zr = 0.f, zi = 0.f;
+#pragma unroll 4
+        for (int ch = 0; ch < MOT_NCHAN; ch++) {
+            const float2 a = S[ch * p.nbins + b]; const float2 m = xm[ch * p.nbins + b];
+            zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y;
+        }
+        const float al = p.alpha[(size_t)slot * p.nbins + b];
+        r.zf[b] = make_float2((zr * al) * p.norm, (zi * al) * p.norm);
+    }
+    __syncthreads();
+    fft_inverse_plane(p, r.zf, r.tmp, r.resp, r.twr, r.twc, tid, nt);
+    for (int i = tid; i < p.nb; i += nt) p.response[(size_t)slot * p.nb + i] = r.resp[i];
+    const int best = block_argmax_first(r.resp, p.nb, r.red_v, r.red_i, tid, nt);
+    if (tid == 0) {
+        int vd = 1, hd = 1;
+        if (best >= 0) { hd = best / p.hb + 1; vd = best - (hd - 1) * p.hb + 1; }
+        if (vd > p.hb / 2) vd -= p.hb;                                 // kcf.cpp:420-421
+        if (hd > p.wb / 2) hd -= p.wb;
+        const float2 sc = p.scale[slot];                               // (horiz, vert)
+        bbox_t np = pos;
+        {
+#pragma clang fp contract(off)
+            np.t = (int)((float)pos.t + (float)(MOT_CELL * (vd - 1)) * sc.y); // kcf.cpp:424-427
+            np.b = (int)((float)pos.b + (float)(MOT_CELL * (vd - 1)) * sc.y);
+            np.l = (int)((float)pos.l + (float)(MOT_CELL * (hd - 1)) * sc.x);
+            np.r = (int)((float)pos.r + (float)(MOT_CELL * (hd - 1)) * sc.x);
+        }
+        p.pos[slot] = np;
+        bbox_t o = np;                                                 // *pbox = pkcf->pos (kcf.cpp:438)
+        if (l.clamp) {                                                 // td.cpp:378-381
+            o.l = min(max(o.l, 0), MOT_FRAME_W - 1); o.r = min(max(o.r, 0), MOT_FRAME_W - 1);
+            o.t = min(max(o.t, 0), MOT_FRAME_H - 1); o.b = min(max(o.b, 0), MOT_FRAME_H - 1);
+        }
+        if (l.boxes_out) l.boxes_out[item] = o;
+    }
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    const Regions r = carve(p, base);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int slot = l.slots[item];
+    const bbox_t box = l.boxes_in[item];
+    const int first = p.first_update[slot];
+    features_to_spectrum(p, l, item, box, r, tid, nt, true);
+    const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
+    const float keep = 1.0f - factor;
+    const float2* S = reinterpret_cast<const float2*>(r.B);
+    float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
+    // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
+    for (int b = tid; b < p.nbins; b += nt) {
+        float kf = 0.f;
+        for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = S[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
+        kf = kf * p.norm;
+        const float a = p.yf_re[b] / (kf + p.lambda);
+        const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
+        p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
+    }
+    // kcf_update_xf (kcf.cpp:380-395)
+    const int tot = MOT_NCHAN * p.nbins;
+    for (int i = tid; i < tot; i += nt) {
+        const float2 a = S[i];
+        float2 m = first ? make_float2(0.f, 0.f) : xm[i];
+        m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
+        xm[i] = m;
+    }
+    if (tid == 0) {                                                    // kcf.cpp:470-472
+        p.pos[slot] = box;
+        p.scale[slot] = make_float2(((float)(box.r - box.l + 1)) / ((float)p.cols), ((float)(box.b - box.t + 1)) / ((float)p.rows));
+        p.first_update[slot] = 0;
+    }
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    const Regions r = carve(p, base);
+    bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
+    features_to_spectrum(p, l, item, box, r, threadIdx.x, blockDim.x, false);
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_crop_kernel(const KcfPool p, const KcfLaunch l, int n, float* patch_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    const Regions r = carve(p, base);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    phase_crop(p, l.frame, nullptr, l.boxes_in[item], r.A, tid, nt);
+    __syncthreads();
+    const int npx = p.rows * p.cols;
+    for (int d = tid; d < npx; d += nt) {
+        uint32_t c, rr; p.d_rows.divmod((uint32_t)d, c, rr);
+        patch_out[(size_t)item * npx + d] = r.A[c * p.ldp + rr];
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+void kcf_pool_layout(KcfPool& p)
+{
+    p.hb = p.rows / MOT_CELL; p.wb = p.cols / MOT_CELL; p.fh = p.hb / 2 + 1;
+    p.nb = p.hb * p.wb; p.nbins = p.wb * p.fh;
+    p.ldp = p.rows | 1;
+    p.d_rows.init(p.rows); p.d_cols.init(p.cols); p.d_hb.init(p.hb); p.d_fh.init(p.fh); p.d_nbins.init(p.nbins); p.d_nb.init(p.nb);
+    p.norm = (float)(1.0 / (double)((float)(p.wb * p.hb * MOT_NCHAN)));
+    p.eta = 0.05f; p.lambda = 0.0001f;
+    const int npx = p.rows * p.cols;
+    const int spec = MOT_NCHAN * p.nbins * 2;                         // floats of a full spectrum / padded feature set
+    auto up4 = [](int v) { return (v + 3) & ~3; };
+    int szA = p.cols * p.ldp; if (MOT_NORI * p.nb > szA) szA = MOT_NORI * p.nb;
+    int szB = npx + (npx + 3) / 4; if (spec > szB) szB = spec;
+    if (!p.fft20 && spec > szA) szA = spec;                           // ping-pong buffer of the generic DFT
+    const int szC = 2048 + 2 * p.hb + 2 * p.wb + 4 * p.nbins + p.nb + (p.hb + 1) * (p.wb + 1) + p.nb + 32;
+    p.offA = 0; p.offB = up4(szA); p.offC = p.offB + up4(szB);
+    p.lds_floats = p.offC + up4(szC);
+    p.use_lds = ((size_t)p.lds_floats * sizeof(float) <= MOT_LDS_LIMIT) ? 1 : 0;
+}
+
+size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats * sizeof(float) : 0; }
+
+template <typename K>
+static hipError_t set_lds_attr(K kern, size_t bytes)
+{
+    if (bytes > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = kcf_lds_bytes(p);
+    if (p.use_lds) {
+        hipError_t e = set_lds_attr(kcf_predict_kernel<true>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+    } else hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), 0, s, p, l, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = kcf_lds_bytes(p);
+    if (p.use_lds) {
+        hipError_t e = set_lds_attr(kcf_update_kernel<true>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+    } else hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), 0, s, p, l, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = kcf_lds_bytes(p);
+    if (p.use_lds) {
+        hipError_t e = set_lds_attr(kcf_fhog_kernel<true>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_fhog_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+    } else hipLaunchKernelGGL(kcf_fhog_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), 0, s, p, l, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = kcf_lds_bytes(p);
+    if (p.use_lds) {
+        hipError_t e = set_lds_attr(kcf_crop_kernel<true>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_crop_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n, patch_out);
+    } else hipLaunchKernelGGL(kcf_crop_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), 0, s, p, l, n, patch_out);
+    return hipGetLastError();
+}

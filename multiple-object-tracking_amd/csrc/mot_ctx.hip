@@ -1,0 +1,740 @@
+// mot_ctx.hip -- host side of libmot_amd.so: context, track pools, batch C ABI
+// (include/mot_abi.h).  There is no CPU compute path in this file: every stage
+// is a HIP kernel launch; when no device is available the calls fail.
+#include "mot_dev.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sse_tables.inc"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MOT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { release(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+};
+template <typename T> struct PinBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { release(); n = count; return count ? hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) : hipSuccess; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    ~PinBuf() { release(); }
+};
+
+struct PoolHost {
+    KcfPool dev{};
+    int cap = 0;
+    std::vector<int> free_slots;
+    DevBuf<float2> xm; DevBuf<float> alpha; DevBuf<bbox_t> pos; DevBuf<float2> scale; DevBuf<int> first; DevBuf<float> response;
+    DevBuf<float> cos_win, yf_re; DevBuf<float2> tw_r, tw_c; DevBuf<float> gscratch;
+};
+
+struct TrackRec { int kind; int pool; int slot; int rows, cols; bool live; };
+
+struct LiveInfo {                    // tracker_info_t (td.cpp:271-290)
+    int id; unsigned tid; int age, visible, invisible; bbox_t bbox;
+};
+
+} // namespace
+
+struct mot_ctx {
+    mot_config cfg{};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    DevBuf<uint8_t> frame_own; const uint8_t* frame = nullptr;
+    DevBuf<uint16_t> sse_tab;
+    std::vector<std::unique_ptr<PoolHost>> pools;
+    KalmanPool kal{}; DevBuf<double> kal_x, kal_P; std::vector<int> kal_free;
+    std::vector<TrackRec> tracks;                     // id -> record
+    // staging (capacity = max_tracks + max_dets)
+    int stage_cap = 0;
+    DevBuf<int> d_slots; DevBuf<bbox_t> d_boxes_a, d_boxes_b, d_dets; DevBuf<float> d_patches; size_t patches_cap = 0;
+    PinBuf<int> h_slots; PinBuf<bbox_t> h_boxes_a, h_boxes_b; PinBuf<int> h_assign; PinBuf<double> h_cost; PinBuf<float> h_patches;
+    // association
+    AssocWs assoc{}; DevBuf<double> a_dist; DevBuf<unsigned long long> a_zr, a_zc, a_linemin; DevBuf<int> a_assign, a_status; DevBuf<double> a_cost;
+    DevBuf<double> a_user;
+    // frame loop (td.cpp:306-748)
+    std::vector<LiveInfo> live; unsigned next_tid = 0;
+    DevBuf<bbox_t> d_gather; int slots_per_rank = 0; std::vector<bbox_t> pending_pred; bool step_open = false;
+    // timers
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int ensure_device(mot_ctx* c) { HIPCHK(hipSetDevice(c->cfg.device)); return MOT_OK; }
+
+// gaussian_shaped_labels (kcf.cpp:96-122) + circshift (:78-94)
+void make_labels(std::vector<float>& out, int rows, int cols)
+{
+    const float sigma = 0.7289f;
+    std::vector<float> xv(rows), yv(cols);
+    const int rx0 = -rows / 2, ry0 = -cols / 2;
+    const float sigma_s_inv = (float)(1.0 / (double)(sigma * sigma));
+    for (int i = 0; i < rows; i++) { int x = rx0 + i; xv[i] = (float)exp(-0.5 * x * x * (double)sigma_s_inv); }
+    for (int j = 0; j < cols; j++) { int y = ry0 + j; yv[j] = (float)exp(-0.5 * y * y * (double)sigma_s_inv); }
+    out.assign((size_t)rows * cols, 0.f);
+    for (int j = 0; j < cols; j++) {
+        int jj = (j + ry0) % cols; if (jj < 0) jj += cols;
+        for (int i = 0; i < rows; i++) { int ii = (i + rx0) % rows; if (ii < 0) ii += rows; out[(size_t)jj * rows + ii] = xv[i] * yv[j]; }
+    }
+}
+
+// sp::hann_f (include/sigpack/window/window.h:34-48,83-89)
+void make_hann(std::vector<float>& h, int N)
+{
+    const double PI_2 = 6.28318530717958647692;
+    h.resize(N);
+    for (int i = 0; i < N; i++) h[i] = (float)(0.5 - 0.5 * cos(1.0 * PI_2 * i / (N - 1)));
+}
+
+void make_twiddles(std::vector<float2>& t, int n)
+{
+    t.resize(n);
+    for (int i = 0; i < n; i++) { double a = 2.0 * 3.14159265358979323846 * (double)i / (double)n; t[i] = make_float2((float)cos(a), (float)sin(a)); }
+    if (n % 4 == 0) { t[n / 4] = make_float2(0.f, 1.f); t[3 * n / 4] = make_float2(0.f, -1.f); }
+    if (n % 2 == 0) t[n / 2] = make_float2(-1.f, 0.f);
+}
+
+int get_pool(mot_ctx* c, int rows, int cols, int* out_idx)
+{
+    for (size_t i = 0; i < c->pools.size(); i++)
+        if (c->pools[i]->dev.rows == rows && c->pools[i]->dev.cols == cols) { *out_idx = (int)i; return MOT_OK; }
+    if (rows < 8 || cols < 8 || rows > MOT_FRAME_H || cols > MOT_FRAME_W) return fail(MOT_ERR_ARG, "template size %dx%d unsupported (need 8..720 x 8..1280)", rows, cols);
+    std::unique_ptr<PoolHost> ph(new PoolHost);
+    KcfPool& p = ph->dev;
+    p.rows = rows; p.cols = cols;
+    p.fhog_mode = c->cfg.fhog_mode;
+    p.fft20 = (c->cfg.fft_mode == MOT_FFT_AUTO && rows / MOT_CELL == 20 && cols / MOT_CELL == 20) ? 1 : 0;
+    kcf_pool_layout(p);
+    const int cap = c->cfg.max_tracks;
+    ph->cap = cap;
+    for (int s = cap - 1; s >= 0; s--) ph->free_slots.push_back(s);
+    HIPCHK(ph->xm.alloc((size_t)cap * MOT_NCHAN * p.nbins));
+    HIPCHK(ph->alpha.alloc((size_t)cap * p.nbins));
+    HIPCHK(ph->pos.alloc(cap)); HIPCHK(ph->scale.alloc(cap)); HIPCHK(ph->first.alloc(cap));
+    HIPCHK(ph->response.alloc((size_t)cap * p.nb));
+    HIPCHK(hipMemsetAsync(ph->xm.p, 0, sizeof(float2) * ph->xm.n, c->stream));
+    HIPCHK(hipMemsetAsync(ph->alpha.p, 0, sizeof(float) * ph->alpha.n, c->stream));
+    HIPCHK(hipMemsetAsync(ph->response.p, 0, sizeof(float) * ph->response.n, c->stream));
+    // constants: window (kcf.cpp:124-130), Re(yf) (kcf.cpp:132-144 -- r2c of the labels)
+    std::vector<float> hy, hx, win((size_t)p.nb), labels;
+    make_hann(hy, p.hb); make_hann(hx, p.wb);
+    for (int j = 0; j < p.wb; j++) for (int i = 0; i < p.hb; i++) win[(size_t)j * p.hb + i] = hy[i] * hx[j];
+    make_labels(labels, p.hb, p.wb);
+    std::vector<float> yfre((size_t)p.nbins);
+    {   // real part of the 2-D DFT of the labels; one-off (init), separable, double precision on the host
+        const double TWO_PI = 6.28318530717958647692;
+        std::vector<double> tr((size_t)p.wb * p.fh), ti((size_t)p.wb * p.fh);
+        for (int cc = 0; cc < p.wb; cc++)
+            for (int k = 0; k < p.fh; k++) {
+                double re = 0, im = 0;
+                for (int r = 0; r < p.hb; r++) {
+                    const double ang = TWO_PI * (double)((long)k * r % p.hb) / p.hb;
+                    re += (double)labels[(size_t)cc * p.hb + r] * cos(ang); im -= (double)labels[(size_t)cc * p.hb + r] * sin(ang);
+                }
+                tr[(size_t)cc * p.fh + k] = re; ti[(size_t)cc * p.fh + k] = im;
+            }
+        for (int cp = 0; cp < p.wb; cp++)
+            for (int k = 0; k < p.fh; k++) {
+                double re = 0;
+                for (int cc = 0; cc < p.wb; cc++) {
+                    const double ang = TWO_PI * (double)((long)cp * cc % p.wb) / p.wb;
+                    re += tr[(size_t)cc * p.fh + k] * cos(ang) + ti[(size_t)cc * p.fh + k] * sin(ang);
+                }
+                yfre[(size_t)cp * p.fh + k] = (float)re;
+            }
+    }
+    std::vector<float2> twr, twc; make_twiddles(twr, p.hb); make_twiddles(twc, p.wb);
+    HIPCHK(ph->cos_win.alloc(win.size())); HIPCHK(ph->yf_re.alloc(yfre.size())); HIPCHK(ph->tw_r.alloc(twr.size())); HIPCHK(ph->tw_c.alloc(twc.size()));
+    HIPCHK(hipMemcpy(ph->cos_win.p, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ph->yf_re.p, yfre.data(), yfre.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ph->tw_r.p, twr.data(), twr.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ph->tw_c.p, twc.data(), twc.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (!p.use_lds) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
+    p.xm = ph->xm.p; p.alpha = ph->alpha.p; p.pos = ph->pos.p; p.scale = ph->scale.p; p.first_update = ph->first.p; p.response = ph->response.p;
+    p.cos_win = ph->cos_win.p; p.yf_re = ph->yf_re.p; p.tw_r = ph->tw_r.p; p.tw_c = ph->tw_c.p; p.sse_tab = c->sse_tab.p; p.gscratch = ph->gscratch.p;
+    c->pools.push_back(std::move(ph));
+    *out_idx = (int)c->pools.size() - 1;
+    return MOT_OK;
+}
+
+TrackRec* rec_of(mot_ctx* c, int id)
+{
+    if (id < 0 || (size_t)id >= c->tracks.size() || !c->tracks[id].live) return nullptr;
+    return &c->tracks[id];
+}
+
+int check_n(mot_ctx* c, int n) { if (n < 0 || n > c->stage_cap) return fail(MOT_ERR_CAPACITY, "batch of %d exceeds capacity %d", n, c->stage_cap); return MOT_OK; }
+
+// groups a batch by pool: order[] lists batch positions pool after pool
+struct Groups { std::vector<int> order; std::vector<int> start; std::vector<int> pool; };
+int group_by_pool(mot_ctx* c, const int* ids, int n, Groups& g, int want_kind)
+{
+    g.order.clear(); g.start.clear(); g.pool.clear();
+    std::vector<std::vector<int>> per(c->pools.size() + 1);
+    for (int i = 0; i < n; i++) {
+        TrackRec* r = rec_of(c, ids[i]);
+        if (!r) return fail(MOT_ERR_ARG, "unknown track id %d", ids[i]);
+        if (r->kind != want_kind) return fail(MOT_ERR_ARG, "track id %d is of the other tracker kind", ids[i]);
+        per[want_kind == MOT_TRACKER_KCF ? r->pool : 0].push_back(i);
+    }
+    for (size_t pi = 0; pi < per.size(); pi++) {
+        if (per[pi].empty()) continue;
+        g.start.push_back((int)g.order.size()); g.pool.push_back((int)pi);
+        for (int i : per[pi]) g.order.push_back(i);
+    }
+    g.start.push_back((int)g.order.size());
+    return MOT_OK;
+}
+
+int new_tracks_common(mot_ctx* c, const bbox_t* boxes, int n, int* ids_out)
+{
+    for (int i = 0; i < n; i++) {
+        TrackRec r{}; r.kind = c->cfg.tracker_kind; r.live = true;
+        r.rows = boxes[i].b - boxes[i].t + 1; r.cols = boxes[i].r - boxes[i].l + 1;      // kcf.cpp:148-149
+        if (r.kind == MOT_TRACKER_KCF) {
+            int pi; int rc = get_pool(c, r.rows, r.cols, &pi); if (rc) return rc;
+            PoolHost& ph = *c->pools[pi];
+            if (ph.free_slots.empty()) return fail(MOT_ERR_CAPACITY, "KCF pool %dx%d full (%d tracks)", r.rows, r.cols, ph.cap);
+            r.pool = pi; r.slot = ph.free_slots.back(); ph.free_slots.pop_back();
+        } else {
+            if (c->kal_free.empty()) return fail(MOT_ERR_CAPACITY, "Kalman pool full");
+            r.pool = 0; r.slot = c->kal_free.back(); c->kal_free.pop_back();
+        }
+        c->tracks.push_back(r);
+        ids_out[i] = (int)c->tracks.size() - 1;
+    }
+    // device-side init: KCF pos / scale / first_update (kcf.cpp:200-212), Kalman x / P
+    if (c->cfg.tracker_kind == MOT_TRACKER_KCF) {
+        for (int i = 0; i < n; i++) {
+            const TrackRec& r = c->tracks[ids_out[i]]; KcfPool& p = c->pools[r.pool]->dev;
+            const float2 one = make_float2(1.f, 1.f); const int first = 1;
+            HIPCHK(hipMemcpyAsync(p.pos + r.slot, &boxes[i], sizeof(bbox_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(p.scale + r.slot, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(p.first_update + r.slot, &first, sizeof first, hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));   // sources are stack / caller memory
+    } else {
+        for (int i = 0; i < n; i++) { c->h_slots.p[i] = c->tracks[ids_out[i]].slot; c->h_boxes_a.p[i] = boxes[i]; }
+        HIPCHK(hipMemcpyAsync(c->d_slots.p, c->h_slots.p, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_boxes_a.p, c->h_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_kalman_init(c->kal, c->d_slots.p, n, c->d_boxes_a.p, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return MOT_OK;
+}
+
+// core of predict / update for a batch; patches == nullptr -> crop from the bound frame
+int run_batch(mot_ctx* c, bool predict, const int* ids, int n, const float* const* patches,
+              const bbox_t* boxes_in, bbox_t* boxes_out, int clamp)
+{
+    int rc = ensure_device(c); if (rc) return rc;
+    rc = check_n(c, n); if (rc) return rc;
+    if (n == 0) return MOT_OK;
+    const int kind = c->cfg.tracker_kind;
+    Groups g; rc = group_by_pool(c, ids, n, g, kind); if (rc) return rc;
+    if (kind == MOT_TRACKER_KCF && !patches && !c->frame) return fail(MOT_ERR_STATE, "no frame bound (mot_frame_upload / mot_frame_bind_device)");
+    // stage slots / boxes in grouped order
+    for (int q = 0; q < n; q++) {
+        const int i = g.order[q];
+        c->h_slots.p[q] = c->tracks[ids[i]].slot;
+        if (boxes_in) c->h_boxes_a.p[q] = boxes_in[i];
+        else if (kind == MOT_TRACKER_KALMAN && boxes_out) c->h_boxes_a.p[q] = boxes_out[i];   // in/out: predict writes l,t,r,b only
+    }
+    HIPCHK(hipMemcpyAsync(c->d_slots.p, c->h_slots.p, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    if (boxes_in || kind == MOT_TRACKER_KALMAN)
+        HIPCHK(hipMemcpyAsync(c->d_boxes_a.p, c->h_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyHostToDevice, c->stream));
+    if (kind == MOT_TRACKER_KALMAN) {
+        if (predict) {
+            HIPCHK(hipMemcpyAsync(c->d_boxes_b.p, c->d_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(launch_kalman_predict(c->kal, c->d_slots.p, nullptr, n, c->d_boxes_b.p, clamp, c->stream));
+        } else HIPCHK(launch_kalman_update(c->kal, c->d_slots.p, nullptr, n, c->d_boxes_a.p, c->stream));
+    } else {
+        for (size_t gi = 0; gi + 1 < g.start.size(); gi++) {
+            const int s = g.start[gi], cnt = g.start[gi + 1] - s;
+            PoolHost& ph = *c->pools[g.pool[gi]];
+            KcfLaunch l{};
+            l.slots = c->d_slots.p + s; l.count = nullptr; l.frame = patches ? nullptr : c->frame;
+            if (patches) {
+                const size_t npx = (size_t)ph.dev.rows * ph.dev.cols;
+                if ((size_t)n * npx > c->patches_cap) {
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    c->patches_cap = (size_t)n * npx * 2;
+                    HIPCHK(c->d_patches.alloc(c->patches_cap)); HIPCHK(c->h_patches.alloc(c->patches_cap));
+                }
+                for (int q = 0; q < cnt; q++) memcpy(c->h_patches.p + (size_t)(s + q) * npx, patches[g.order[s + q]], npx * sizeof(float));
+                HIPCHK(hipMemcpyAsync(c->d_patches.p + (size_t)s * npx, c->h_patches.p + (size_t)s * npx, (size_t)cnt * npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
+                l.patches = c->d_patches.p + (size_t)s * npx;
+            }
+            l.boxes_in = boxes_in ? c->d_boxes_a.p + s : nullptr;
+            l.boxes_out = predict ? c->d_boxes_b.p + s : nullptr;
+            l.clamp = clamp;
+            if (predict) HIPCHK(launch_kcf_predict(ph.dev, l, cnt, c->stream));
+            else HIPCHK(launch_kcf_update(ph.dev, l, cnt, c->stream));
+        }
+    }
+    if (predict && boxes_out) {
+        HIPCHK(hipMemcpyAsync(c->h_boxes_b.p, c->d_boxes_b.p, sizeof(bbox_t) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int q = 0; q < n; q++) boxes_out[g.order[q]] = c->h_boxes_b.p[q];
+    } else HIPCHK(hipStreamSynchronize(c->stream));   // caller buffers (patches / boxes) may be reused after return
+    return MOT_OK;
+}
+
+int do_delete(mot_ctx* c, const int* ids, int n)
+{
+    for (int i = 0; i < n; i++) {
+        TrackRec* r = rec_of(c, ids[i]);
+        if (!r) return fail(MOT_ERR_ARG, "unknown track id %d", ids[i]);
+        if (r->kind == MOT_TRACKER_KCF) c->pools[r->pool]->free_slots.push_back(r->slot); else c->kal_free.push_back(r->slot);
+        r->live = false;
+    }
+    return MOT_OK;
+}
+
+int assign_device(mot_ctx* c, const bbox_t* trk, int nT, const bbox_t* det, int nD, int* assigned_trackers, int* assigned_detected, double* cost_out)
+{
+    if (nT > c->cfg.max_tracks || nD > c->cfg.max_dets || nT > 1024 || nD > 1024) return fail(MOT_ERR_CAPACITY, "assign: %d tracks x %d detections exceeds capacity", nT, nD);
+    for (int i = 0; i < nT; i++) assigned_trackers[i] = -1;            // td.cpp:472-479
+    for (int j = 0; j < nD; j++) assigned_detected[j] = -1;
+    if (cost_out) *cost_out = 0.0;
+    if (!(nT && nD)) return MOT_OK;                                    // td.cpp:460
+    memcpy(c->h_boxes_a.p, trk, sizeof(bbox_t) * nT);
+    memcpy(c->h_boxes_b.p, det, sizeof(bbox_t) * nD);
+    HIPCHK(hipMemcpyAsync(c->d_boxes_a.p, c->h_boxes_a.p, sizeof(bbox_t) * nT, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_dets.p, c->h_boxes_b.p, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_assoc(c->assoc, c->d_boxes_a.p, nullptr, nT, c->d_dets.p, nD, nullptr, 0, 0, cost_out ? 1 : 0, c->stream));
+    const int nR = nT < nD ? nT : nD;
+    HIPCHK(hipMemcpyAsync(c->h_assign.p, c->assoc.assignment, sizeof(int) * nR, hipMemcpyDeviceToHost, c->stream));
+    if (cost_out) HIPCHK(hipMemcpyAsync(c->h_cost.p, c->assoc.cost, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nT < nD) { for (int i = 0; i < nT; i++) { int j = c->h_assign.p[i]; assigned_trackers[i] = j; if (j >= 0) assigned_detected[j] = i; } } // td.cpp:481-491
+    else { for (int j = 0; j < nD; j++) { int i = c->h_assign.p[j]; if (i >= 0) assigned_trackers[i] = j; assigned_detected[j] = i; } }           // td.cpp:492-502
+    if (cost_out) *cost_out = c->h_cost.p[0];
+    return MOT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void mot_config_default(mot_config* cfg)
+{
+    memset(cfg, 0, sizeof *cfg);
+    cfg->device = 0; cfg->tracker_kind = MOT_TRACKER_KCF; cfg->fhog_mode = MOT_FHOG_INTEL_APPROX; cfg->fft_mode = MOT_FFT_AUTO;
+    cfg->max_tracks = 256; cfg->max_dets = 128; cfg->rank = 0; cfg->world = 1; cfg->stream = nullptr;
+}
+
+const char* mot_last_error(void) { return g_err.c_str(); }
+
+int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
+{
+    if (!cfg || !out) return fail(MOT_ERR_ARG, "null argument");
+    if (cfg->max_tracks < 1 || cfg->max_tracks > 1024 || cfg->max_dets < 1 || cfg->max_dets > 1024) return fail(MOT_ERR_ARG, "max_tracks / max_dets must be in 1..1024");
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(MOT_ERR_ARG, "bad rank/world");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MOT_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(MOT_ERR_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+    std::unique_ptr<mot_ctx> c(new mot_ctx);
+    c->cfg = *cfg;
+    HIPCHK(hipSetDevice(cfg->device));
+    if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    // SSE approximation tables: [0..2047] rcp, [2048..4095] rsqrt
+    std::vector<uint16_t> tab(4096);
+    for (int i = 0; i < 2048; i++) { tab[i] = MOT_SSE_RCP_TAB[i]; tab[2048 + i] = MOT_SSE_RSQ_TAB[i]; }
+    HIPCHK(c->sse_tab.alloc(4096));
+    HIPCHK(hipMemcpy(c->sse_tab.p, tab.data(), 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->stage_cap = cfg->max_tracks + cfg->max_dets;
+    const int sc = c->stage_cap;
+    HIPCHK(c->d_slots.alloc(sc)); HIPCHK(c->d_boxes_a.alloc(sc)); HIPCHK(c->d_boxes_b.alloc(sc)); HIPCHK(c->d_dets.alloc(sc));
+    HIPCHK(c->h_slots.alloc(sc)); HIPCHK(c->h_boxes_a.alloc(sc)); HIPCHK(c->h_boxes_b.alloc(sc)); HIPCHK(c->h_assign.alloc(1024)); HIPCHK(c->h_cost.alloc(1));
+    if (cfg->tracker_kind == MOT_TRACKER_KALMAN) {
+        HIPCHK(c->kal_x.alloc((size_t)cfg->max_tracks * 6)); HIPCHK(c->kal_P.alloc((size_t)cfg->max_tracks * 36));
+        c->kal.x = c->kal_x.p; c->kal.P = c->kal_P.p;
+        for (int s = cfg->max_tracks - 1; s >= 0; s--) c->kal_free.push_back(s);
+    }
+    const size_t n2 = (size_t)1024 * 1024;
+    const size_t mr = std::max(cfg->max_tracks, cfg->max_dets);
+    const size_t mat = std::min(n2, mr * mr);
+    HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024));
+    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(8)); HIPCHK(c->a_cost.alloc(1));
+    c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
+    c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
+    c->slots_per_rank = (cfg->max_tracks + cfg->world - 1) / cfg->world;
+    HIPCHK(c->d_gather.alloc((size_t)c->slots_per_rank * cfg->world));
+    HIPCHK(hipMemset(c->d_gather.p, 0, sizeof(bbox_t) * c->d_gather.n));
+    *out = c.release();
+    return MOT_OK;
+}
+
+int mot_ctx_destroy(mot_ctx* c)
+{
+    if (!c) return MOT_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MOT_OK;
+}
+
+void* mot_ctx_stream(mot_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int mot_ctx_sync(mot_ctx* c) { if (!c) return fail(MOT_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return MOT_OK; }
+
+int mot_frame_upload(mot_ctx* c, const uint8_t* host_bgr)
+{
+    if (!c || !host_bgr) return fail(MOT_ERR_ARG, "null argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    const size_t bytes = (size_t)MOT_FRAME_W * MOT_FRAME_H * 3;
+    if (!c->frame_own.p) HIPCHK(c->frame_own.alloc(bytes));
+    HIPCHK(hipMemcpyAsync(c->frame_own.p, host_bgr, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->frame = c->frame_own.p;
+    return MOT_OK;
+}
+
+int mot_frame_bind_device(mot_ctx* c, const void* device_bgr)
+{
+    if (!c || !device_bgr) return fail(MOT_ERR_ARG, "null argument");
+    c->frame = (const uint8_t*)device_bgr;
+    return MOT_OK;
+}
+
+int mot_tracks_new_nofirst(mot_ctx* c, const bbox_t* boxes, int n, int* ids_out)
+{
+    if (!c || !boxes || !ids_out) return fail(MOT_ERR_ARG, "null argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    rc = check_n(c, n); if (rc) return rc;
+    return new_tracks_common(c, boxes, n, ids_out);
+}
+
+int mot_tracks_new(mot_ctx* c, const bbox_t* boxes, int n, int* ids_out)
+{
+    int rc = mot_tracks_new_nofirst(c, boxes, n, ids_out); if (rc) return rc;
+    if (c->cfg.tracker_kind == MOT_TRACKER_KCF) return run_batch(c, false, ids_out, n, nullptr, boxes, nullptr, 0); // td.cpp:631-640
+    return MOT_OK;
+}
+
+int mot_predict_batch(mot_ctx* c, const int* ids, int n, bbox_t* boxes_out, int clamp)
+{
+    if (!c || (n > 0 && (!ids || !boxes_out))) return fail(MOT_ERR_ARG, "null argument");
+    return run_batch(c, true, ids, n, nullptr, nullptr, boxes_out, clamp);
+}
+
+int mot_update_batch(mot_ctx* c, const int* ids, int n, const bbox_t* boxes)
+{
+    if (!c || (n > 0 && (!ids || !boxes))) return fail(MOT_ERR_ARG, "null argument");
+    return run_batch(c, false, ids, n, nullptr, boxes, nullptr, 0);
+}
+
+int mot_predict_batch_patches(mot_ctx* c, const int* ids, int n, const float* const* patches, bbox_t* boxes_out)
+{
+    if (!c || (n > 0 && (!ids || !boxes_out))) return fail(MOT_ERR_ARG, "null argument");
+    if (c->cfg.tracker_kind == MOT_TRACKER_KCF && n > 0 && !patches) return fail(MOT_ERR_ARG, "null patches");
+    return run_batch(c, true, ids, n, c->cfg.tracker_kind == MOT_TRACKER_KCF ? patches : nullptr, nullptr, boxes_out, 0);
+}
+
+int mot_update_batch_patches(mot_ctx* c, const int* ids, int n, const float* const* patches, const bbox_t* boxes)
+{
+    if (!c || (n > 0 && (!ids || !boxes))) return fail(MOT_ERR_ARG, "null argument");
+    if (c->cfg.tracker_kind == MOT_TRACKER_KCF && n > 0 && !patches) return fail(MOT_ERR_ARG, "null patches");
+    return run_batch(c, false, ids, n, c->cfg.tracker_kind == MOT_TRACKER_KCF ? patches : nullptr, boxes, nullptr, 0);
+}
+
+int mot_delete_batch(mot_ctx* c, const int* ids, int n)
+{
+    if (!c || (n > 0 && !ids)) return fail(MOT_ERR_ARG, "null argument");
+    return do_delete(c, ids, n);
+}
+
+int mot_assign(mot_ctx* c, const bbox_t* trk, int nT, const bbox_t* det, int nD, int* assigned_trackers, int* assigned_detected, double* cost_out)
+{
+    if (!c || nT < 0 || nD < 0 || (nT && (!trk || !assigned_trackers)) || (nD && (!det || !assigned_detected))) return fail(MOT_ERR_ARG, "bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    return assign_device(c, trk, nT, det, nD, assigned_trackers, assigned_detected, cost_out);
+}
+
+int mot_cost_matrix(mot_ctx* c, const bbox_t* trk, int nT, const bbox_t* det, int nD, double* dist_out)
+{
+    if (!c || nT < 0 || nD < 0 || !dist_out) return fail(MOT_ERR_ARG, "bad argument");
+    if (nT > c->cfg.max_tracks || nD > c->cfg.max_dets) return fail(MOT_ERR_CAPACITY, "cost matrix exceeds capacity");
+    int rc = ensure_device(c); if (rc) return rc;
+    if (!(nT && nD)) return MOT_OK;
+    memcpy(c->h_boxes_a.p, trk, sizeof(bbox_t) * nT); memcpy(c->h_boxes_b.p, det, sizeof(bbox_t) * nD);
+    HIPCHK(hipMemcpyAsync(c->d_boxes_a.p, c->h_boxes_a.p, sizeof(bbox_t) * nT, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_dets.p, c->h_boxes_b.p, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_cost_matrix(c->d_boxes_a.p, nT, c->d_dets.p, nD, c->assoc.dist, c->stream));
+    HIPCHK(hipMemcpyAsync(dist_out, c->assoc.dist, sizeof(double) * (size_t)nT * nD, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MOT_OK;
+}
+
+int mot_assignment_optimal(mot_ctx* c, int* assignment, double* cost, const double* dist, int nRows, int nCols)
+{
+    if (!c || nRows < 0 || nCols < 0 || (nRows && !assignment) || !cost) return fail(MOT_ERR_ARG, "bad argument");
+    if (nRows > 1024 || nCols > 1024) return fail(MOT_ERR_CAPACITY, "assignment problem %dx%d exceeds 1024x1024", nRows, nCols);
+    int rc = ensure_device(c); if (rc) return rc;
+    *cost = 0.0;
+    for (int r = 0; r < nRows; r++) assignment[r] = -1;                // hungarian.cpp:36-40
+    const size_t ne = (size_t)nRows * nCols;
+    if (!ne) return MOT_OK;
+    if (!dist) return fail(MOT_ERR_ARG, "null cost matrix");
+    if (c->a_user.n < ne) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(c->a_user.alloc(ne)); }
+    if (c->a_dist.n < ne) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const size_t mr = std::max(nRows, nCols);
+        HIPCHK(c->a_dist.alloc(ne)); c->assoc.dist = c->a_dist.p;
+        if (c->a_zr.n < mr * 16) { HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; }
+    }
+    const size_t mr2 = std::max(nRows, nCols);
+    if (c->a_zr.n < mr2 * 16) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(c->a_zr.alloc(mr2 * 16)); HIPCHK(c->a_zc.alloc(mr2 * 16)); c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; }
+    HIPCHK(hipMemcpyAsync(c->a_user.p, dist, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_assoc(c->assoc, nullptr, nullptr, 0, nullptr, 0, c->a_user.p, nRows, nCols, 1, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_assign.p, c->assoc.assignment, sizeof(int) * nRows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_cost.p, c->assoc.cost, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(assignment, c->h_assign.p, sizeof(int) * nRows);
+    *cost = c->h_cost.p[0];
+    return MOT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tracker-thread iteration (td.cpp:344-644), host-orchestrated
+// ---------------------------------------------------------------------------
+static bool owns(const mot_ctx* c, unsigned tid) { return (int)(tid % (unsigned)c->cfg.world) == c->cfg.rank; }
+
+int mot_step_begin(mot_ctx* c, void** local_boxes_dev, int* slots_per_rank)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    int rc = ensure_device(c); if (rc) return rc;
+    if (c->step_open) return fail(MOT_ERR_STATE, "mot_step_begin called twice");
+    // predict the tracks this rank owns (td.cpp:344-384); results land in this rank's all-gather segment
+    std::vector<int> ids; ids.reserve(c->live.size());
+    for (const LiveInfo& t : c->live) if (owns(c, t.tid)) ids.push_back(t.id);
+    const int n = (int)ids.size();
+    if (n > c->slots_per_rank) return fail(MOT_ERR_CAPACITY, "rank owns %d tracks, segment holds %d", n, c->slots_per_rank);
+    std::vector<bbox_t> pred(n);
+    if (c->cfg.tracker_kind == MOT_TRACKER_KALMAN) { int q = 0; for (const LiveInfo& t : c->live) if (owns(c, t.tid)) pred[q++] = t.bbox; }
+    rc = run_batch(c, true, ids.data(), n, nullptr, nullptr, pred.data(), 1); if (rc) return rc;
+    bbox_t* seg = c->d_gather.p + (size_t)c->cfg.rank * c->slots_per_rank;
+    if (n) {
+        memcpy(c->h_boxes_a.p, pred.data(), sizeof(bbox_t) * n);
+        HIPCHK(hipMemcpyAsync(seg, c->h_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    c->step_open = true;
+    if (local_boxes_dev) *local_boxes_dev = seg;
+    if (slots_per_rank) *slots_per_rank = c->slots_per_rank;
+    return MOT_OK;
+}
+
+int mot_step_finish(mot_ctx* c, const void* gathered_boxes_dev, const bbox_t* dets, int nD,
+                    bbox_t* predicted, int* assigned_trackers_out, int* n_before,
+                    bbox_t* live_boxes, unsigned* live_tids, int* n_live)
+{
+    if (!c || nD < 0 || (nD && !dets)) return fail(MOT_ERR_ARG, "bad argument");
+    if (!c->step_open) return fail(MOT_ERR_STATE, "mot_step_finish without mot_step_begin");
+    if (nD > c->cfg.max_dets) return fail(MOT_ERR_CAPACITY, "%d detections exceed max_dets %d", nD, c->cfg.max_dets);
+    c->step_open = false;
+    int rc = ensure_device(c); if (rc) return rc;
+    const int nT = (int)c->live.size(), W = c->cfg.world, spr = c->slots_per_rank;
+    if (n_before) *n_before = nT;
+    // gathered segments -> live order
+    std::vector<bbox_t> all((size_t)W * spr);
+    const void* src = gathered_boxes_dev ? gathered_boxes_dev : (const void*)c->d_gather.p;
+    if (nT) { HIPCHK(hipMemcpyAsync(all.data(), src, sizeof(bbox_t) * all.size(), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+    std::vector<int> cursor(W, 0);
+    std::vector<bbox_t> pred(nT);
+    for (int i = 0; i < nT; i++) { const int rk = (int)(c->live[i].tid % (unsigned)W); pred[i] = all[(size_t)rk * spr + cursor[rk]++]; c->live[i].bbox = pred[i]; }
+    if (predicted) for (int i = 0; i < nT; i++) predicted[i] = pred[i];
+    // association (td.cpp:386-502), replicated on every rank
+    std::vector<int> at(nT + 1), ad(nD + 1);
+    rc = assign_device(c, pred.data(), nT, dets, nD, at.data(), ad.data(), nullptr); if (rc) return rc;
+    if (assigned_trackers_out) for (int i = 0; i < nT; i++) assigned_trackers_out[i] = at[i];
+    // updates (td.cpp:512-582): assigned tracks adopt the detection box, unassigned keep their prediction
+    std::vector<int> ids; std::vector<bbox_t> ub;
+    for (int i = 0; i < nT; i++) {
+        LiveInfo& t = c->live[i];
+        const int j = at[i];
+        if (j >= 0) { t.bbox = dets[j]; t.visible++; t.age++; t.invisible = 0; }
+        else { t.age++; t.invisible++; }
+        if (owns(c, t.tid)) { ids.push_back(t.id); ub.push_back(t.bbox); }
+    }
+    rc = run_batch(c, false, ids.data(), (int)ids.size(), nullptr, ub.data(), nullptr, 0); if (rc) return rc;
+    // delete lost (td.cpp:585-609)
+    int n = 0;
+    for (int i = 0; i < nT; i++) {
+        LiveInfo& t = c->live[i];
+        const bool lost = ((t.age < 10) && (t.visible * 5 < 3 * t.age)) || (t.invisible >= 20);
+        if (!lost) { if (n != i) c->live[n] = t; ++n; }
+        else if (owns(c, t.tid)) { rc = do_delete(c, &t.id, 1); if (rc) return rc; }
+    }
+    c->live.resize(n);
+    // spawn (td.cpp:612-644)
+    std::vector<bbox_t> nb; std::vector<size_t> where;
+    for (int j = 0; j < nD; j++) {
+        if (ad[j] >= 0) continue;
+        if ((int)c->live.size() >= c->cfg.max_tracks) break;          // the reference has no bound check (tracker_info[256])
+        LiveInfo t{}; t.id = -1; t.tid = c->next_tid++; t.bbox = dets[j];
+        c->live.push_back(t);
+        if (owns(c, t.tid)) { nb.push_back(dets[j]); where.push_back(c->live.size() - 1); }
+    }
+    if (!nb.empty()) {
+        std::vector<int> nid(nb.size());
+        rc = mot_tracks_new(c, nb.data(), (int)nb.size(), nid.data()); if (rc) return rc;
+        for (size_t q = 0; q < nb.size(); q++) c->live[where[q]].id = nid[q];
+    }
+    if (n_live) *n_live = (int)c->live.size();
+    for (size_t i = 0; i < c->live.size(); i++) { if (live_boxes) live_boxes[i] = c->live[i].bbox; if (live_tids) live_tids[i] = c->live[i].tid; }
+    return MOT_OK;
+}
+
+int mot_step_frame(mot_ctx* c, const bbox_t* dets, int nD, bbox_t* predicted, int* assigned_trackers, int* n_before,
+                   bbox_t* live_boxes, unsigned* live_tids, int* n_live)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    if (c->cfg.world != 1) return fail(MOT_ERR_STATE, "sharded context: use mot_step_begin / all-gather / mot_step_finish");
+    int rc = mot_step_begin(c, nullptr, nullptr); if (rc) return rc;
+    return mot_step_finish(c, nullptr, dets, nD, predicted, assigned_trackers, n_before, live_boxes, live_tids, n_live);
+}
+
+int mot_live_count(mot_ctx* c, int* n_live) { if (!c || !n_live) return fail(MOT_ERR_ARG, "null argument"); *n_live = (int)c->live.size(); return MOT_OK; }
+
+int mot_live_tracks(mot_ctx* c, bbox_t* boxes, unsigned* tids, int* ages, int* n_live)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    for (size_t i = 0; i < c->live.size(); i++) { if (boxes) boxes[i] = c->live[i].bbox; if (tids) tids[i] = c->live[i].tid; if (ages) ages[i] = c->live[i].age; }
+    if (n_live) *n_live = (int)c->live.size();
+    return MOT_OK;
+}
+
+// ---- introspection ----------------------------------------------------------
+int mot_get_response(mot_ctx* c, int id, float* out, int* f_rows, int* f_cols)
+{
+    TrackRec* r = c ? rec_of(c, id) : nullptr;
+    if (!r || r->kind != MOT_TRACKER_KCF) return fail(MOT_ERR_ARG, "unknown KCF track id %d", id);
+    KcfPool& p = c->pools[r->pool]->dev;
+    if (f_rows) *f_rows = p.hb; if (f_cols) *f_cols = p.wb;
+    if (out) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(out, p.response + (size_t)r->slot * p.nb, sizeof(float) * p.nb, hipMemcpyDeviceToHost)); }
+    return MOT_OK;
+}
+
+int mot_get_model(mot_ctx* c, int id, float* xm_out, float* alpha_out)
+{
+    TrackRec* r = c ? rec_of(c, id) : nullptr;
+    if (!r || r->kind != MOT_TRACKER_KCF) return fail(MOT_ERR_ARG, "unknown KCF track id %d", id);
+    KcfPool& p = c->pools[r->pool]->dev;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (xm_out) HIPCHK(hipMemcpy(xm_out, p.xm + (size_t)r->slot * MOT_NCHAN * p.nbins, sizeof(float2) * MOT_NCHAN * p.nbins, hipMemcpyDeviceToHost));
+    if (alpha_out) HIPCHK(hipMemcpy(alpha_out, p.alpha + (size_t)r->slot * p.nbins, sizeof(float) * p.nbins, hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_get_kalman_state(mot_ctx* c, int id, double* x6, double* P36)
+{
+    TrackRec* r = c ? rec_of(c, id) : nullptr;
+    if (!r || r->kind != MOT_TRACKER_KALMAN) return fail(MOT_ERR_ARG, "unknown Kalman track id %d", id);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (x6) HIPCHK(hipMemcpy(x6, c->kal.x + (size_t)r->slot * 6, sizeof(double) * 6, hipMemcpyDeviceToHost));
+    if (P36) HIPCHK(hipMemcpy(P36, c->kal.P + (size_t)r->slot * 36, sizeof(double) * 36, hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_get_pos(mot_ctx* c, int id, bbox_t* pos)
+{
+    TrackRec* r = c ? rec_of(c, id) : nullptr;
+    if (!r || r->kind != MOT_TRACKER_KCF || !pos) return fail(MOT_ERR_ARG, "unknown KCF track id %d", id);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(pos, c->pools[r->pool]->dev.pos + r->slot, sizeof(bbox_t), hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_fhog_extract(mot_ctx* c, const float* patch, int h, int w, float* H_out, int windowed)
+{
+    if (!c || !patch || !H_out) return fail(MOT_ERR_ARG, "null argument");
+    if (c->cfg.tracker_kind != MOT_TRACKER_KCF) return fail(MOT_ERR_STATE, "FHOG needs a KCF context");
+    int rc = ensure_device(c); if (rc) return rc;
+    int pi; rc = get_pool(c, h, w, &pi); if (rc) return rc;
+    KcfPool& p = c->pools[pi]->dev;
+    const size_t npx = (size_t)h * w, nout = (size_t)32 * p.nb;
+    DevBuf<float> dp, dh; HIPCHK(dp.alloc(npx)); HIPCHK(dh.alloc(nout));
+    HIPCHK(hipMemcpy(dp.p, patch, npx * sizeof(float), hipMemcpyHostToDevice));
+    KcfLaunch l{}; int zero = 0; HIPCHK(hipMemcpy(c->d_slots.p, &zero, sizeof(int), hipMemcpyHostToDevice));
+    l.slots = c->d_slots.p; l.patches = dp.p; l.feat_out = dh.p; l.feat_windowed = windowed;
+    HIPCHK(launch_kcf_fhog_only(p, l, 1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(H_out, dh.p, nout * sizeof(float), hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_crop_patch(mot_ctx* c, const bbox_t* box, int rows, int cols, float* patch_out)
+{
+    if (!c || !box || !patch_out) return fail(MOT_ERR_ARG, "null argument");
+    if (c->cfg.tracker_kind != MOT_TRACKER_KCF) return fail(MOT_ERR_STATE, "crop needs a KCF context");
+    if (!c->frame) return fail(MOT_ERR_STATE, "no frame bound");
+    int rc = ensure_device(c); if (rc) return rc;
+    int pi; rc = get_pool(c, rows, cols, &pi); if (rc) return rc;
+    KcfPool& p = c->pools[pi]->dev;
+    const size_t npx = (size_t)rows * cols;
+    DevBuf<float> dp; HIPCHK(dp.alloc(npx));
+    HIPCHK(hipMemcpy(c->d_boxes_a.p, box, sizeof(bbox_t), hipMemcpyHostToDevice));
+    KcfLaunch l{}; l.frame = c->frame; l.boxes_in = c->d_boxes_a.p;
+    HIPCHK(launch_kcf_crop_only(p, l, 1, dp.p, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(patch_out, dp.p, npx * sizeof(float), hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+// ---- timers -----------------------------------------------------------------
+int mot_timer_create(mot_ctx* c, int n_events)
+{
+    if (!c || n_events < 0) return fail(MOT_ERR_ARG, "bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    c->events.assign(n_events, nullptr);
+    for (int i = 0; i < n_events; i++) HIPCHK(hipEventCreate(&c->events[i]));
+    return MOT_OK;
+}
+int mot_timer_record(mot_ctx* c, int idx)
+{
+    if (!c || idx < 0 || (size_t)idx >= c->events.size()) return fail(MOT_ERR_ARG, "bad event index");
+    HIPCHK(hipEventRecord(c->events[idx], c->stream));
+    return MOT_OK;
+}
+int mot_timer_elapsed_ms(mot_ctx* c, int a, int b, float* ms)
+{
+    if (!c || !ms || a < 0 || b < 0 || (size_t)a >= c->events.size() || (size_t)b >= c->events.size()) return fail(MOT_ERR_ARG, "bad event index");
+    HIPCHK(hipEventSynchronize(c->events[b]));
+    HIPCHK(hipEventElapsedTime(ms, c->events[a], c->events[b]));
+    return MOT_OK;
+}
+
+} // extern "C"
+
+// ---- device-resident steady-state loop: implemented in mot_devloop (round-1 step 2) ----
+extern "C" {
+int mot_step_frame_device(mot_ctx*, const void*, const void*, int) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
+int mot_step_begin_device(mot_ctx*, const void*, void**, int*) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
+int mot_step_finish_device(mot_ctx*, const void*, const void*, int) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
+int mot_profile_frame_device(mot_ctx*, const void*, const void*, int, float*) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
+}

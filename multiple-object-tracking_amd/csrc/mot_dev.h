@@ -1,0 +1,97 @@
+// mot_dev.h -- shared host/device declarations of the MI355X tracker library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mot_abi.h"
+
+#define MOT_NCHAN 31          // FHOG channels used by KCF (trackers/kcf.cpp:157)
+#define MOT_NORI 18           // contrast-sensitive orientations (libhog/gradientMex.cpp:305)
+#define MOT_CELL 4            // trackers/kcf.cpp:488
+#define MOT_KCF_THREADS 512   // one workgroup per track
+#define MOT_LDS_LIMIT (160 * 1024)
+
+struct FastDiv {              // exact n/d for n*d < 2^32
+    uint32_t d, m;
+    __host__ void init(uint32_t dd) { d = dd; m = (dd <= 1) ? 0u : (uint32_t)(0xFFFFFFFFull / dd + 1ull); }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d <= 1 ? n : __umulhi(n, m); }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
+};
+
+// One pool = all KCF tracks that share a template size (rows x cols frozen at
+// tracker_new, trackers/kcf.cpp:148-152).  State is track-major (SoA of
+// per-track contiguous blocks) so a workgroup streams its model with
+// consecutive-lane, 8/16-byte accesses.
+struct KcfPool {
+    // geometry
+    int rows, cols;           // patch h, w (column-major, rows fastest)
+    int hb, wb;               // f_rows, f_cols
+    int fh;                   // hb/2+1
+    int nb;                   // hb*wb cells
+    int nbins;                // wb*fh half-spectrum bins
+    int ldp;                  // LDS patch column stride (odd)
+    FastDiv d_rows, d_cols, d_hb, d_fh, d_nbins, d_nb;
+    float norm;               // 1/(hb*wb*31)  (kcf.cpp:197)
+    float eta, lambda;        // kcf.cpp:211-212
+    int fhog_mode, fft20;
+    // scratch carve (float offsets) and size
+    int offA, offB, offC, lds_floats;
+    int use_lds;              // 1: scratch in LDS, 0: per-workgroup slab in HBM
+    float* gscratch;          // [grid][lds_floats] when !use_lds
+    // state, indexed by slot
+    float2* xm;               // [cap][31][nbins]
+    float* alpha;             // [cap][nbins]
+    bbox_t* pos;              // [cap]   kcf_t::pos  (crop box of the next predict)
+    float2* scale;            // [cap]   (scale_horiz, scale_vert)
+    int* first_update;        // [cap]
+    float* response;          // [cap][nb]
+    // constants
+    const float* cos_win;     // [nb]
+    const float* yf_re;       // [nbins]  only Re(yf) is read by kcf_update_alpha (kcf.cpp:373)
+    const float2* tw_r;       // [hb] (cos,sin)(2*pi*j/hb)
+    const float2* tw_c;       // [wb]
+    const uint16_t* sse_tab;  // [4096] rcp | rsqrt mantissa tables
+};
+
+struct KcfLaunch {
+    const int* slots;         // [n] pool slot per workgroup (device)
+    const int* count;         // optional device count: workgroups >= *count exit
+    const uint8_t* frame;     // 1280x720x3 BGR or null
+    const float* patches;     // [n][rows*cols] gray patches or null
+    const bbox_t* boxes_in;   // update: [n] box to crop at / adopt as pos (null for predict: crop at pos)
+    bbox_t* boxes_out;        // predict: [n] predicted boxes
+    int clamp;                // apply td.cpp:378-381 to boxes_out
+    float* feat_out;          // debug: [n][32][nb] FHOG (optional)
+    int feat_windowed;
+};
+
+struct KalmanPool {
+    double* x;                // [cap][6]
+    double* P;                // [cap][36] column-major
+};
+
+// ---- association workspace -------------------------------------------------
+struct AssocWs {
+    double* dist;             // [1024*1024] working matrix, column-major
+    unsigned long long* zr;   // row-major zero bitmap  [nR][wordsC]
+    unsigned long long* zc;   // col-major zero bitmap  [nC][wordsR]
+    unsigned long long* linemin; // [1024] order-preserving keys of the row / column minima
+    int* assignment;          // [1024]
+    double* cost;             // [1]
+    int* status;              // [8]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow
+};
+
+// host-side launchers implemented in the .hip files
+hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
+hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
+hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
+hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s);
+size_t kcf_lds_bytes(const KcfPool& p);
+void kcf_pool_layout(KcfPool& p);
+
+hipError_t launch_kalman_predict(const KalmanPool& p, const int* slots, const int* count, int n, bbox_t* boxes_out, int clamp, hipStream_t s);
+hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int* count, int n, const bbox_t* boxes, hipStream_t s);
+hipError_t launch_kalman_init(const KalmanPool& p, const int* slots, int n, const bbox_t* boxes, hipStream_t s);
+
+hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
+                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s);
+hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int nD, double* dist_out, hipStream_t s);

@@ -1,0 +1,175 @@
+"""ctypes access to the oracle (oracle/libmot_oracle.so) and, when present, to the
+reference-built libraries in oracle/_ref.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+
+
+class BBox(C.Structure):
+    _fields_ = [("l", C.c_int), ("t", C.c_int), ("b", C.c_int), ("r", C.c_int), ("type", C.c_int), ("score", C.c_float)]
+
+
+BBOX_DTYPE = np.dtype([("l", "<i4"), ("t", "<i4"), ("b", "<i4"), ("r", "<i4"), ("type", "<i4"), ("score", "<f4")])
+FP = C.POINTER(C.c_float)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "libmot_oracle.so")
+    src = os.path.join(ORACLE_DIR, "mot_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_orc = None
+
+
+def load_oracle():
+    global _orc
+    if _orc is not None:
+        return _orc
+    lib = C.CDLL(build_oracle())
+    for f in ["response", "alpha", "xm", "xf", "yf", "labels", "coswin", "features"]:
+        getattr(lib, "orc_kcf_" + f).restype = FP
+        getattr(lib, "orc_kcf_" + f).argtypes = [C.c_void_p]
+    for f in ["rows", "cols", "frows", "fcols"]:
+        getattr(lib, "orc_kcf_" + f).argtypes = [C.c_void_p]
+    lib.orc_kcf_new.restype = C.c_void_p
+    lib.orc_kcf_new.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_kcf_delete.argtypes = [C.c_void_p]
+    lib.orc_kcf_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_kcf_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_kalman_new.restype = C.c_void_p
+    lib.orc_kalman_new.argtypes = [C.c_void_p]
+    lib.orc_kalman_predict.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_kalman_update.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_kalman_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_kalman_delete.argtypes = [C.c_void_p]
+    lib.orc_acos_table.restype = FP
+    lib.orc_sse_rcp.restype = C.c_float
+    lib.orc_sse_rcp.argtypes = [C.c_float]
+    lib.orc_sse_rsqrt.restype = C.c_float
+    lib.orc_sse_rsqrt.argtypes = [C.c_float]
+    lib.orc_mot_new.restype = C.c_void_p
+    lib.orc_mot_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.orc_mot_delete.argtypes = [C.c_void_p]
+    lib.orc_mot_step.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5
+    lib.orc_mot_ntracks.argtypes = [C.c_void_p]
+    lib.orc_mot_kcf.restype = C.c_void_p
+    lib.orc_mot_kcf.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_mot_kalman.restype = C.c_void_p
+    lib.orc_mot_kalman.argtypes = [C.c_void_p, C.c_int]
+    _orc = lib
+    return lib
+
+
+def ref_available():
+    return all(os.path.exists(os.path.join(REF_DIR, f)) for f in
+               ["libref_hog.so", "libref_hungarian.so", "libref_drawlib.so", "libref_kalman.so", "libref_kcf.so"])
+
+
+def load_ref(name):
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    lib = C.CDLL(os.path.join(REF_DIR, f"libref_{name}.so"))
+    if name == "kcf":
+        for f in ["response", "alpha", "xm", "xf", "yf", "features", "labels", "coswin"]:
+            getattr(lib, "refkcf_" + f).restype = FP
+            getattr(lib, "refkcf_" + f).argtypes = [C.c_void_p]
+        lib.refkcf_new.restype = C.c_void_p
+        lib.refkcf_new.argtypes = [C.c_void_p]
+        lib.refkcf_predict.argtypes = [C.c_void_p] * 3
+        lib.refkcf_update.argtypes = [C.c_void_p] * 3
+        lib.refkcf_delete.argtypes = [C.c_void_p]
+        lib.refkcf_frows.argtypes = [C.c_void_p]
+        lib.refkcf_fcols.argtypes = [C.c_void_p]
+    if name == "kalman":
+        lib.refkal_new.restype = C.c_void_p
+        lib.refkal_new.argtypes = [C.c_void_p]
+        lib.refkal_predict.argtypes = [C.c_void_p] * 2
+        lib.refkal_update.argtypes = [C.c_void_p] * 2
+        lib.refkal_state.argtypes = [C.c_void_p] * 3
+        lib.refkal_delete.argtypes = [C.c_void_p]
+    if name == "hog":
+        lib.refhog_acos_table.restype = FP
+    return lib
+
+
+def arr(p, n):
+    return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+
+def boxes_array(boxes):
+    out = np.zeros(len(boxes), BBOX_DTYPE)
+    for i, b in enumerate(boxes):
+        b = tuple(b)
+        out[i] = (b[0], b[1], b[2], b[3], b[4] if len(b) > 4 else 0, b[5] if len(b) > 5 else 0.9)
+    return out
+
+
+# ---- convenience wrappers over the oracle ----
+def fhog(lib, patch, h, w, mode=0):
+    I = np.ascontiguousarray(patch, np.float32).ravel()
+    H = np.zeros(32 * (h // 4) * (w // 4), np.float32)
+    lib.orc_fhog(P(I), h, w, P(H), mode)
+    return H
+
+
+def crop_patch(lib, frame, box, rows, cols):
+    b = boxes_array([box])
+    hs, ws = abs(box[2] - box[1]) + 1, abs(box[3] - box[0]) + 1
+    scratch = np.zeros(max(hs * ws, 1), np.float32)
+    dst = np.zeros(rows * cols, np.float32)
+    lib.orc_crop_patch(P(dst), P(scratch), P(frame), P(b), rows, cols)
+    return dst
+
+
+def cost_matrix(lib, trk, det):
+    t, d = boxes_array(trk) if not isinstance(trk, np.ndarray) else trk, boxes_array(det) if not isinstance(det, np.ndarray) else det
+    out = np.zeros(len(t) * len(d), np.float64)
+    lib.orc_cost_matrix(P(t), len(t), P(d), len(d), P(out))
+    return out
+
+
+def assignment_optimal(lib, dist, nr, nc):
+    d = np.ascontiguousarray(dist, np.float64)
+    a = np.full(max(nr, 1), -1, np.int32)
+    c = C.c_double(0)
+    lib.orc_assignment_optimal(P(a), C.byref(c), P(d), nr, nc)
+    return a[:nr], c.value
+
+
+class OracleMot:
+    """orc_mot_* frame loop (top/td.cpp:306-748 restated)"""
+
+    def __init__(self, lib, kind, mode=0, cap=256):
+        self.lib, self.cap, self.kind = lib, cap, kind
+        self.h = C.c_void_p(lib.orc_mot_new(kind, mode, cap))
+
+    def step(self, frame, dets):
+        d = boxes_array(dets) if not isinstance(dets, np.ndarray) else dets
+        cap = self.cap + 1
+        pred = np.zeros(cap, BBOX_DTYPE); at = np.zeros(cap, np.int32); live = np.zeros(cap, BBOX_DTYPE); tids = np.zeros(cap, np.uint32)
+        nb = C.c_int(0)
+        nl = self.lib.orc_mot_step(self.h, P(frame) if frame is not None else None, P(d), len(d), P(pred), P(at), C.byref(nb), P(live), P(tids))
+        return dict(predicted=pred[:nb.value].copy(), assigned=at[:nb.value].copy(), live=live[:nl].copy(), tids=tids[:nl].copy())
+
+    def kcf(self, i):
+        return C.c_void_p(self.lib.orc_mot_kcf(self.h, i))
+
+    def kalman(self, i):
+        return C.c_void_p(self.lib.orc_mot_kalman(self.h, i))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_mot_delete(self.h)
+            self.h = None
