@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- tracker-updates/sec of the MI355X-native per-frame tracker update.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one camera frame: every live track runs tracker_predict, the
+predicted boxes are (for N > 1) exchanged with ONE RCCL all-gather, the
+detections x tracks cost matrix + Munkres assignment run replicated on every
+rank, then every track runs tracker_update; track lifecycle (delete / spawn)
+included (top/td.cpp:344-644).  One tracker-update = one track x one frame.
+
+Workload (BASELINE.json configs[2] at N=1, configs[3] at N=8): 1024 concurrent
+80x80 KCF tracks on a synthetic 1280x720 BGR stream, sharded tid % N across the
+GPUs of one node => "scaling": "strong".  Frames and detections are resident in
+HBM before the timed region.  `--tracks 64` gives configs[1].
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+`roofline` for the dominant kernel (HIP events on the launch stream) and
+`cpu_baseline` (the reference built in oracle/_ref, or the oracle port, timed on
+one host core on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic HBM bytes per track and launch, 80x80 template (SURVEY 8d / DESIGN.md):
+#   predict: 19,200 (u8 BGR crop) + 54,560 (xm read) + 880 (alpha) + 48 (pos in, box out)
+#   update : 19,200 (crop) + 109,120 (xm read+write) + 1,760 (alpha r+w) + 24 (box in)
+
+
+def alg_bytes(size):
+    nb = (size // 4) * ((size // 4) // 2 + 1)
+    crop = size * size * 3
+    return {"predict": crop + 31 * nb * 8 + nb * 4 + 48, "update": crop + 2 * 31 * nb * 8 + 2 * nb * 4 + 24}
+
+
+def gen_stream(n_tracks, size, n_frames, stream_id=0):
+    import mot_amd
+    from multiple_object_tracking_amd import synth
+    scene = synth.Scene(n_tracks, size, stream_id=stream_id)
+    frames = np.empty((n_frames, 720, 1280, 3), np.uint8)
+    dets = np.zeros((n_frames, n_tracks), mot_amd.BBOX_DTYPE)
+    for f, (frame, d) in enumerate(scene.frames(n_frames)):
+        frames[f] = frame
+        dets[f] = mot_amd.boxes_array(d)
+    return frames, dets
+
+
+def cpu_baseline(n_tracks, size, budget_s=15.0):
+    """the reference's own code (oracle/_ref) -- or the oracle port if that is absent -- on one host core,
+    on the first frames of the same synthetic workload (full track count, all stages incl. Munkres)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    import mot_amd  # noqa: F401
+    from multiple_object_tracking_amd import synth
+    kind = "port"
+    libs = None
+    if orc.ref_available():
+        try:
+            libs = tuple(orc.load_ref(n) for n in ["kcf", "kalman", "hungarian", "drawlib"])
+            kind = "reference"
+        except OSError:
+            libs = None
+    scene = synth.Scene(n_tracks, size, stream_id=0)
+    gen = scene.frames(10 ** 6)
+    updates, t_used, frames_done = 0, 0.0, 0
+    if kind == "reference":
+        class Feed:
+            def __init__(self, items): self.items = items
+            def frames(self, n): return iter(self.items[:n])
+        # frame 0 only spawns the tracks (tracker_new + first update: not steady state) -> timed separately and subtracted
+        est = n_tracks * 0.5e-3 + 0.04 * (n_tracks / 1024.0) ** 2
+        nf = int(max(2, min(40, budget_s / est)))
+        frames = [next(gen) for _ in range(nf + 1)]
+        t0 = time.perf_counter()
+        orc.ref_frame_loop(0, Feed(frames), 1, libs)
+        t_spawn = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.ref_frame_loop(0, Feed(frames), nf + 1, libs)
+        t_used = time.perf_counter() - t0 - t_spawn
+        frames_done = nf
+    else:
+        lib = orc.load_oracle()
+        m = orc.OracleMot(lib, 0, 0, n_tracks)
+        frame, dets = next(gen)
+        m.step(frame, dets)
+        t0 = time.perf_counter()
+        frame, dets = next(gen); m.step(frame, dets)
+        per_frame = time.perf_counter() - t0
+        nf = int(max(1, min(40, budget_s / per_frame)))
+        t0 = time.perf_counter()
+        for _ in range(nf):
+            frame, dets = next(gen); m.step(frame, dets)
+        t_used = time.perf_counter() - t0
+        frames_done = nf
+        m.close()
+    updates = n_tracks * frames_done
+    return {"value": updates / t_used, "unit": "tracker-updates/s", "cores": 1, "kind": kind,
+            "sample": f"{n_tracks} KCF tracks x {frames_done} steady-state frames of the bench stream (crop+resize, predict, cost, Munkres, update), 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tracks", type=int, default=1024, help="total concurrent KCF tracks (all GPUs)")
+    ap.add_argument("--size", type=int, default=80, help="square template / object size in pixels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-frames", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mot_amd
+    from multiple_object_tracking_amd import parallel as par
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_tracks, size = args.tracks, args.size
+    n_prof = args.profile_frames if world == 1 else 0
+    n_frames = 1 + args.warmup + args.steps + n_prof
+    frames_h, dets_h = gen_stream(n_tracks, size, n_frames)
+    frames_d = torch.from_numpy(frames_h).cuda()
+    dets_d = torch.from_numpy(dets_h.view(np.uint8).reshape(n_frames, -1)).cuda()
+    frame_bytes = 720 * 1280 * 3
+    det_bytes = dets_d.shape[1]
+
+    stream = torch.cuda.Stream()
+    ctx = mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(n_tracks, 1), max_dets=max(n_tracks, 1),
+                             rank=rank, world=world, stream=stream.cuda_stream, dev_size=size)
+
+    gathered = None
+
+    def step(f):
+        fp = frames_d.data_ptr() + f * frame_bytes
+        dp = dets_d.data_ptr() + f * det_bytes
+        if world == 1:
+            ctx.step_frame_device(fp, dp, n_tracks)
+        else:
+            seg_ptr, spr = ctx.step_begin_device(fp)
+            nonlocal gathered
+            if gathered is None:
+                gathered = torch.empty(world * spr * 24, dtype=torch.uint8, device="cuda")
+                step.local = torch.as_tensor(par.DevArray(seg_ptr, spr * 24), device="cuda")
+            par.all_gather_boxes(step.local, gathered)             # the single collective of the frame (RCCL over xGMI)
+            ctx.step_finish_device(gathered.data_ptr(), dp, n_tracks)
+
+    with torch.cuda.stream(stream):
+        f = 0
+        step(f); f += 1                                              # frame 0: every detection spawns a track (tracker_new + first update)
+        for _ in range(args.warmup):
+            step(f); f += 1
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(f); f += 1
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        n_live = ctx.live_count()
+
+        # per-kernel device time, HIP events on the launch stream (world == 1 only)
+        stage = None
+        if n_prof:
+            acc = np.zeros(5)
+            for _ in range(n_prof):
+                fp = frames_d.data_ptr() + f * frame_bytes
+                dp = dets_d.data_ptr() + f * det_bytes
+                acc += ctx.profile_frame_device(fp, dp, n_tracks)
+                f += 1
+            stage = acc / n_prof
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_live * args.steps / elapsed
+        out = {
+            "metric": "tracker-updates/sec (KCF, 80x80 patch)", "value": value, "unit": "tracker-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n_tracks} concurrent {size}x{size} KCF tracks (31-ch FHOG, cell 4), 1280x720 BGR synthetic stream, "
+                                   f"{n_tracks} detections/frame, Munkres {n_tracks}x{n_tracks}, tracks sharded tid % {world}; "
+                                   f"BASELINE configs[{2 if n_tracks == 1024 else 1}]" + ("/[3]" if world > 1 else ""),
+                       "tracks_total": n_tracks, "tracks_per_gpu": n_tracks // world, "live_tracks_end": n_live, "patch": size,
+                       "parallelism": f"track-shard x{world}, 1 all-gather/frame" if world > 1 else "single GPU"},
+        }
+        ab = alg_bytes(size)
+        if stage is not None:
+            kern = {"kcf_predict": stage[0], "assoc_min+sub+munkres": stage[1], "lifecycle": stage[3], "kcf_update": stage[4]}
+            dom = "kcf_update" if stage[4] >= stage[0] else "kcf_predict"
+            per_launch = ab["update" if dom == "kcf_update" else "predict"] * n_live
+            dur_s = kern[dom] * 1e-3
+            achieved = per_launch / dur_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(f"{dom}_bytes_per_launch_n{n_tracks}")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "alg_bytes_per_launch": per_launch, "avg_launch_ms": kern[dom]}
+            out["kernel_ms"] = {k: float(v) for k, v in kern.items()}
+            out["hbm_frac_whole_frame"] = (ab["predict"] + ab["update"]) * n_live / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n_tracks, size)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,7 +79,8 @@ typedef struct mot_config {
     int max_dets;      /* capacity of a detection list (reference: 128, cnntype.h:46) */
     int rank, world;   /* track sharding: this context owns KCF/Kalman state of tracks with tid % world == rank */
     void* stream;      /* hipStream_t to launch on, or NULL to create a private stream */
-    int reserved[6];   /* must be zero */
+    int dev_rows, dev_cols; /* template size of the device-resident loop (mot_step_frame_device); 0 = 80 */
+    int reserved[4];   /* must be zero */
 } mot_config;
 
 typedef struct mot_ctx mot_ctx; /* opaque */

@@ -702,8 +702,14 @@ size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats
 template <typename K>
 static hipError_t set_lds_attr(K kern, size_t bytes)
 {
-    if (bytes > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return hipSuccess;
+    // once per kernel symbol: allow the full 160 KB of a gfx950 CU as dynamic LDS
+    static const void* done[16]; static int ndone = 0;
+    if (bytes <= 64 * 1024) return hipSuccess;
+    const void* key = reinterpret_cast<const void*>(kern);
+    for (int i = 0; i < ndone; i++) if (done[i] == key) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, MOT_LDS_LIMIT);
+    if (e == hipSuccess && ndone < 16) done[ndone++] = key;
+    return e;
 }
 
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)

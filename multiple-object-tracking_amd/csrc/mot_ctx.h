@@ -1,0 +1,77 @@
+// mot_ctx.h -- internal host-side types shared by mot_ctx.hip and mot_devloop.hip.
+#pragma once
+#include "mot_dev.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace mot_impl {
+
+int fail(int code, const char* fmt, ...);
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mot_impl::fail(MOT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { release(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+};
+template <typename T> struct PinBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { release(); n = count; return count ? hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) : hipSuccess; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    ~PinBuf() { release(); }
+};
+
+struct PoolHost {
+    KcfPool dev{};
+    int cap = 0;
+    std::vector<int> free_slots;
+    DevBuf<float2> xm; DevBuf<float> alpha; DevBuf<bbox_t> pos; DevBuf<float2> scale; DevBuf<int> first; DevBuf<float> response;
+    DevBuf<float> cos_win, yf_re; DevBuf<float2> tw_r, tw_c; DevBuf<float> gscratch;
+};
+
+struct TrackRec { int kind; int pool; int slot; int rows, cols; bool live; };
+
+struct LiveInfo {                    // tracker_info_t (td.cpp:271-290)
+    int id; unsigned tid; int age, visible, invisible; bbox_t bbox;
+};
+
+struct DevLoop;                      // device-resident frame loop state (mot_devloop.hip)
+void devloop_destroy(DevLoop*);
+
+} // namespace mot_impl
+
+struct mot_ctx {
+    mot_config cfg{};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    mot_impl::DevBuf<uint8_t> frame_own; const uint8_t* frame = nullptr;
+    mot_impl::DevBuf<uint16_t> sse_tab;
+    std::vector<std::unique_ptr<mot_impl::PoolHost>> pools;
+    KalmanPool kal{}; mot_impl::DevBuf<double> kal_x, kal_P; std::vector<int> kal_free;
+    std::vector<mot_impl::TrackRec> tracks;           // id -> record
+    // staging (capacity = max_tracks + max_dets)
+    int stage_cap = 0;
+    mot_impl::DevBuf<int> d_slots; mot_impl::DevBuf<bbox_t> d_boxes_a, d_boxes_b, d_dets; mot_impl::DevBuf<float> d_patches; size_t patches_cap = 0;
+    mot_impl::PinBuf<int> h_slots; mot_impl::PinBuf<bbox_t> h_boxes_a, h_boxes_b; mot_impl::PinBuf<int> h_assign; mot_impl::PinBuf<double> h_cost; mot_impl::PinBuf<float> h_patches;
+    // association
+    AssocWs assoc{}; mot_impl::DevBuf<double> a_dist; mot_impl::DevBuf<unsigned long long> a_zr, a_zc, a_linemin; mot_impl::DevBuf<int> a_assign, a_status; mot_impl::DevBuf<double> a_cost;
+    mot_impl::DevBuf<double> a_user;
+    // frame loop (td.cpp:306-748), host-orchestrated mode
+    std::vector<mot_impl::LiveInfo> live; unsigned next_tid = 0;
+    mot_impl::DevBuf<bbox_t> d_gather; int slots_per_rank = 0; bool step_open = false;
+    // device-resident mode
+    mot_impl::DevLoop* devloop = nullptr;
+    // timers
+    std::vector<hipEvent_t> events;
+};
+
+namespace mot_impl {
+int ensure_device(mot_ctx* c);
+int get_pool(mot_ctx* c, int rows, int cols, int* out_idx);
+}

@@ -1,21 +1,13 @@
 // mot_ctx.hip -- host side of libmot_amd.so: context, track pools, batch C ABI
 // (include/mot_abi.h).  There is no CPU compute path in this file: every stage
 // is a HIP kernel launch; when no device is available the calls fail.
-#include "mot_dev.h"
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-#include <algorithm>
-#include <memory>
-#include <string>
-#include <unordered_map>
-#include <vector>
+#include "mot_ctx.h"
 
 #include "sse_tables.inc"
 
-namespace {
+using namespace mot_impl;
 
+namespace mot_impl {
 thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...)
@@ -25,62 +17,13 @@ int fail(int code, const char* fmt, ...)
     g_err = buf;
     return code;
 }
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(MOT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+} // namespace mot_impl
 
-template <typename T> struct DevBuf {
-    T* p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { release(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-    ~DevBuf() { release(); }
-};
-template <typename T> struct PinBuf {
-    T* p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { release(); n = count; return count ? hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) : hipSuccess; }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
-    ~PinBuf() { release(); }
-};
-
-struct PoolHost {
-    KcfPool dev{};
-    int cap = 0;
-    std::vector<int> free_slots;
-    DevBuf<float2> xm; DevBuf<float> alpha; DevBuf<bbox_t> pos; DevBuf<float2> scale; DevBuf<int> first; DevBuf<float> response;
-    DevBuf<float> cos_win, yf_re; DevBuf<float2> tw_r, tw_c; DevBuf<float> gscratch;
-};
-
-struct TrackRec { int kind; int pool; int slot; int rows, cols; bool live; };
-
-struct LiveInfo {                    // tracker_info_t (td.cpp:271-290)
-    int id; unsigned tid; int age, visible, invisible; bbox_t bbox;
-};
-
-} // namespace
-
-struct mot_ctx {
-    mot_config cfg{};
-    hipStream_t stream = nullptr; bool own_stream = false;
-    DevBuf<uint8_t> frame_own; const uint8_t* frame = nullptr;
-    DevBuf<uint16_t> sse_tab;
-    std::vector<std::unique_ptr<PoolHost>> pools;
-    KalmanPool kal{}; DevBuf<double> kal_x, kal_P; std::vector<int> kal_free;
-    std::vector<TrackRec> tracks;                     // id -> record
-    // staging (capacity = max_tracks + max_dets)
-    int stage_cap = 0;
-    DevBuf<int> d_slots; DevBuf<bbox_t> d_boxes_a, d_boxes_b, d_dets; DevBuf<float> d_patches; size_t patches_cap = 0;
-    PinBuf<int> h_slots; PinBuf<bbox_t> h_boxes_a, h_boxes_b; PinBuf<int> h_assign; PinBuf<double> h_cost; PinBuf<float> h_patches;
-    // association
-    AssocWs assoc{}; DevBuf<double> a_dist; DevBuf<unsigned long long> a_zr, a_zc, a_linemin; DevBuf<int> a_assign, a_status; DevBuf<double> a_cost;
-    DevBuf<double> a_user;
-    // frame loop (td.cpp:306-748)
-    std::vector<LiveInfo> live; unsigned next_tid = 0;
-    DevBuf<bbox_t> d_gather; int slots_per_rank = 0; std::vector<bbox_t> pending_pred; bool step_open = false;
-    // timers
-    std::vector<hipEvent_t> events;
-};
+namespace mot_impl {
+int ensure_device(mot_ctx* c) { HIPCHK(hipSetDevice(c->cfg.device)); return MOT_OK; }
+} // namespace mot_impl
 
 namespace {
-
-int ensure_device(mot_ctx* c) { HIPCHK(hipSetDevice(c->cfg.device)); return MOT_OK; }
 
 // gaussian_shaped_labels (kcf.cpp:96-122) + circshift (:78-94)
 void make_labels(std::vector<float>& out, int rows, int cols)
@@ -114,6 +57,9 @@ void make_twiddles(std::vector<float2>& t, int n)
     if (n % 2 == 0) t[n / 2] = make_float2(-1.f, 0.f);
 }
 
+} // namespace
+
+namespace mot_impl {
 int get_pool(mot_ctx* c, int rows, int cols, int* out_idx)
 {
     for (size_t i = 0; i < c->pools.size(); i++)
@@ -176,6 +122,10 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx)
     *out_idx = (int)c->pools.size() - 1;
     return MOT_OK;
 }
+
+} // namespace mot_impl
+
+namespace {
 
 TrackRec* rec_of(mot_ctx* c, int id)
 {
@@ -394,6 +344,7 @@ int mot_ctx_destroy(mot_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->devloop) devloop_destroy(c->devloop);
     delete c;
     return MOT_OK;
 }
@@ -618,16 +569,6 @@ int mot_step_frame(mot_ctx* c, const bbox_t* dets, int nD, bbox_t* predicted, in
     return mot_step_finish(c, nullptr, dets, nD, predicted, assigned_trackers, n_before, live_boxes, live_tids, n_live);
 }
 
-int mot_live_count(mot_ctx* c, int* n_live) { if (!c || !n_live) return fail(MOT_ERR_ARG, "null argument"); *n_live = (int)c->live.size(); return MOT_OK; }
-
-int mot_live_tracks(mot_ctx* c, bbox_t* boxes, unsigned* tids, int* ages, int* n_live)
-{
-    if (!c) return fail(MOT_ERR_ARG, "null ctx");
-    for (size_t i = 0; i < c->live.size(); i++) { if (boxes) boxes[i] = c->live[i].bbox; if (tids) tids[i] = c->live[i].tid; if (ages) ages[i] = c->live[i].age; }
-    if (n_live) *n_live = (int)c->live.size();
-    return MOT_OK;
-}
-
 // ---- introspection ----------------------------------------------------------
 int mot_get_response(mot_ctx* c, int id, float* out, int* f_rows, int* f_cols)
 {
@@ -731,10 +672,3 @@ int mot_timer_elapsed_ms(mot_ctx* c, int a, int b, float* ms)
 
 } // extern "C"
 
-// ---- device-resident steady-state loop: implemented in mot_devloop (round-1 step 2) ----
-extern "C" {
-int mot_step_frame_device(mot_ctx*, const void*, const void*, int) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
-int mot_step_begin_device(mot_ctx*, const void*, void**, int*) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
-int mot_step_finish_device(mot_ctx*, const void*, const void*, int) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
-int mot_profile_frame_device(mot_ctx*, const void*, const void*, int, float*) { return fail(MOT_ERR_STATE, "device-resident loop not built in this snapshot"); }
-}

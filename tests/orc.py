@@ -173,3 +173,98 @@ class OracleMot:
         if self.h:
             self.lib.orc_mot_delete(self.h)
             self.h = None
+
+
+def ref_frame_loop(kind, scene, n_frames, libs, timing=None):
+    """The tracker thread body of top/td.cpp:344-644, transcribed, driving the REFERENCE's
+    own per-object functions (tracker_*, assignmentoptimal, rgb2Gray, bilinearInterpolationGray)."""
+    kcf, kal, hung, draw = libs
+    tracks = []   # dict(h, bbox(list l,t,b,r,type,score), age, vis, inv, rows, cols, tid)
+    next_tid = 0
+    trace = []
+    gray = np.zeros(1280 * 720, np.float32); scratch = np.zeros(1280 * 720, np.float32)
+
+    def crop(frame, bb, rows, cols):
+        l, t, b, r = bb[0], bb[1], bb[2], bb[3]
+        draw.rgb2Gray(P(scratch), P(frame), l, t, r, b)
+        draw.bilinearInterpolationGray(P(gray), P(scratch), b - t + 1, r - l + 1, rows, cols)
+
+    def mk(bb):
+        return BBox(int(bb[0]), int(bb[1]), int(bb[2]), int(bb[3]), int(bb[4]), float(bb[5]))
+
+    for frame, dets in scene.frames(n_frames):
+        nT, nD = len(tracks), len(dets)
+        pred = []
+        for t in tracks:
+            pb = mk(t["bbox"])
+            if kind == 0:
+                crop(frame, t["bbox"], t["rows"], t["cols"])
+                kcf.refkcf_predict(t["h"], P(gray), C.byref(pb))
+            else:
+                kal.refkal_predict(t["h"], C.byref(pb))
+            bb = [min(max(pb.l, 0), 1279), min(max(pb.t, 0), 719), min(max(pb.b, 0), 719), min(max(pb.r, 0), 1279), pb.type, pb.score]
+            t["bbox"] = bb
+            pred.append(tuple(bb[:5]))
+        at = [-1] * nT; ad = [-1] * nD
+        if nT and nD:
+            tb = boxes_array([tuple(t["bbox"]) for t in tracks]); db = boxes_array(dets)
+            dist = cost_matrix(load_oracle(), tb, db)   # td.cpp:386-457 (restated; pinned separately by cost golden)
+            if nT < nD:
+                a = np.zeros(nT, np.int32); c = C.c_double(0)
+                hung.refhung_assign(P(a), C.byref(c), P(dist), nT, nD)
+                for i in range(nT):
+                    at[i] = int(a[i]); ad[int(a[i])] = i
+            else:
+                a = np.zeros(nD, np.int32); c = C.c_double(0)
+                hung.refhung_assign(P(a), C.byref(c), P(dist), nD, nT)
+                for j in range(nD):
+                    at[int(a[j])] = j; ad[j] = int(a[j])
+        for i, t in enumerate(tracks):
+            j = at[i]
+            if j < 0:
+                continue
+            db = mk(dets[j])
+            if kind == 0:
+                crop(frame, dets[j], t["rows"], t["cols"])
+                kcf.refkcf_update(t["h"], P(gray), C.byref(db))
+            else:
+                kal.refkal_update(t["h"], C.byref(db))
+            t["bbox"] = list(dets[j]); t["vis"] += 1; t["age"] += 1; t["inv"] = 0
+        for i, t in enumerate(tracks):
+            if at[i] >= 0:
+                continue
+            t["age"] += 1; t["inv"] += 1
+            ob = mk(t["bbox"])
+            if kind == 0:
+                crop(frame, t["bbox"], t["rows"], t["cols"])
+                kcf.refkcf_update(t["h"], P(gray), C.byref(ob))
+            else:
+                kal.refkal_update(t["h"], C.byref(ob))
+        keep = []
+        for t in tracks:
+            lost = (t["age"] < 10 and t["vis"] * 5 < 3 * t["age"]) or t["inv"] >= 20
+            if not lost:
+                keep.append(t)
+            else:
+                (kcf.refkcf_delete if kind == 0 else kal.refkal_delete)(t["h"])
+        tracks = keep
+        for j in range(nD):
+            if ad[j] >= 0:
+                continue
+            d = dets[j]
+            t = dict(bbox=list(d), age=0, vis=0, inv=0, rows=d[2] - d[1] + 1, cols=d[3] - d[0] + 1, tid=next_tid)
+            next_tid += 1
+            db = mk(d)
+            if kind == 0:
+                t["h"] = C.c_void_p(kcf.refkcf_new(C.byref(db)))
+                draw.rgb2Gray(P(gray), P(frame), d[0], d[1], d[3], d[2])
+                kcf.refkcf_update(t["h"], P(gray), C.byref(db))
+            else:
+                t["h"] = C.c_void_p(kal.refkal_new(C.byref(db)))
+            tracks.append(t)
+        trace.append(dict(pred=pred, assigned=list(at), live=[tuple(t["bbox"][:5]) for t in tracks], tids=[t["tid"] for t in tracks]))
+    for t in tracks:
+        (kcf.refkcf_delete if kind == 0 else kal.refkal_delete)(t["h"])
+    return trace
+
+
