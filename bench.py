@@ -76,16 +76,14 @@ def cpu_baseline(n_tracks, size, budget_s=15.0):
         class Feed:
             def __init__(self, items): self.items = items
             def frames(self, n): return iter(self.items[:n])
-        # frame 0 only spawns the tracks (tracker_new + first update: not steady state) -> timed separately and subtracted
+        # frame 0 only spawns the tracks (tracker_new + first update: not steady state); frames 1.. are timed individually
         est = n_tracks * 0.5e-3 + 0.04 * (n_tracks / 1024.0) ** 2
         nf = int(max(2, min(40, budget_s / est)))
         frames = [next(gen) for _ in range(nf + 1)]
-        t0 = time.perf_counter()
-        orc.ref_frame_loop(0, Feed(frames), 1, libs)
-        t_spawn = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        orc.ref_frame_loop(0, Feed(frames), nf + 1, libs)
-        t_used = time.perf_counter() - t0 - t_spawn
+        timing = []
+        orc.ref_frame_loop(0, Feed(frames), nf + 1, libs, timing)
+        t_used = sum(t for t, _ in timing[1:])
+        updates = sum(n for _, n in timing[1:])
         frames_done = nf
     else:
         lib = orc.load_oracle()
@@ -101,8 +99,8 @@ def cpu_baseline(n_tracks, size, budget_s=15.0):
             frame, dets = next(gen); m.step(frame, dets)
         t_used = time.perf_counter() - t0
         frames_done = nf
+        updates = n_tracks * frames_done
         m.close()
-    updates = n_tracks * frames_done
     return {"value": updates / t_used, "unit": "tracker-updates/s", "cores": 1, "kind": kind,
             "sample": f"{n_tracks} KCF tracks x {frames_done} steady-state frames of the bench stream (crop+resize, predict, cost, Munkres, update), 1 thread"}
 
@@ -116,6 +114,7 @@ def main():
     ap.add_argument("--size", type=int, default=80, help="square template / object size in pixels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=20)
+    ap.add_argument("--debug-assoc", action="store_true", help="print Munkres step counters / phase times per profiled frame to stderr")
     args = ap.parse_args()
 
     import torch
@@ -197,6 +196,8 @@ def main():
                 fp = frames_d.data_ptr() + f * frame_bytes
                 dp = dets_d.data_ptr() + f * det_bytes
                 acc += ctx.profile_frame_device(fp, dp, n_tracks)
+                if args.debug_assoc:
+                    print("assoc", ctx.assoc_stats().tolist(), file=sys.stderr)
                 f += 1
             stage = acc / n_prof
 

@@ -279,6 +279,11 @@ class MotContext:
         self._chk(self.lib.mot_get_pos(self._h, int(tid), _vp(b)))
         return b[0]
 
+    def assoc_stats(self) -> np.ndarray:
+        out = np.zeros(16, np.int32)
+        self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
+        return out
+
     def fhog_extract(self, patch: np.ndarray, h: int, w: int, windowed=False) -> np.ndarray:
         p = np.ascontiguousarray(patch, np.float32).ravel()
         assert p.size == h * w

@@ -123,42 +123,49 @@ __global__ void __launch_bounds__(256) assoc_sub_kernel(AssocArgs a)
 // the sequential state machine, one workgroup
 // ---------------------------------------------------------------------------
 struct MkShared {
-    u64 bm[MK_MAXN * MK_MAXW];      // zero bitmap, [line][W]
+    u64 bm[MK_MAXN * MK_MAXW];      // zero bitmap, [line][16 words]; row-major during init, column-major afterwards
     short starColOfRow[MK_MAXN];
     short starRowOfCol[MK_MAXN];
     short primeColOfRow[MK_MAXN];
-    unsigned short list[MK_MAXN];
-    u64 covR[MK_MAXW], covC[MK_MAXW], validR[MK_MAXW], validC[MK_MAXW];
+    unsigned short list[MK_MAXN];   // uncovered columns, ascending
+    unsigned short clist[MK_MAXN];  // init: contested lines, ascending
+    unsigned short crosscnt[MK_MAXN];
+    u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW];
+    unsigned int taken32[2 * MK_MAXW], cont32[2 * MK_MAXW];
     double red[MK_THREADS / 64];
     int flag[8];
 };
 
+__device__ __forceinline__ u64 readlane64(u64 v, int src)          // src must be wave-uniform
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ int wave_first_bit(u64 m, int lane, int nwords)
-{   // lanes < nwords hold words of a line; returns index of the first set bit, or -1
+{   // lanes < nwords hold words of a line; returns index of the first set bit, or -1 (wave-uniform)
     const u64 bal = __ballot(lane < nwords && m != 0);
     if (!bal) return -1;
     const int w = __ffsll((long long)bal) - 1;
-    const u64 word = __shfl(m, w);
+    const u64 word = readlane64(m, w);
     return w * 64 + (__ffsll((long long)word) - 1);
 }
 
-// list of uncovered columns >= from, ascending; executed by wave 0.  returns count
-__device__ int build_uncovered_cols(MkShared& S, int from, int wordsC, int lane)
+// ascending list of the set bits of a <=1024-bit mask held one word per lane, restricted to bits >= from;
+// wave 0 only, returns the count (wave-uniform)
+__device__ __forceinline__ int wave_list_bits(u64 w, int from, unsigned short* out, int lane)
 {
-    u64 w = 0;
-    if (lane < wordsC) {
-        w = ~S.covC[lane] & S.validC[lane];
-        const int fw = from >> 6;
-        if (lane < fw) w = 0;
-        else if (lane == fw) w &= ~0ull << (from & 63);
-    }
-    int cnt = __popcll(w), pre = cnt;
+    const int fw = from >> 6;
+    if (lane < fw) w = 0;
+    else if (lane == fw) w &= ~0ull << (from & 63);
+    const int cnt = __popcll(w);
+    int pre = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
-    const int total = __shfl(pre, 63);
+    const int total = __builtin_amdgcn_readlane(pre, 63);
     int pos = pre - cnt;
-    while (w) { const int b = __ffsll((long long)w) - 1; S.list[pos++] = (unsigned short)(lane * 64 + b); w &= w - 1; }
-    __threadfence_block();                                            // list is read by other lanes of this wave
+    while (w) { const int b = __ffsll((long long)w) - 1; out[pos++] = (unsigned short)(lane * 64 + b); w &= w - 1; }
     return total;
 }
 
@@ -170,40 +177,62 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     double* __restrict__ d = a.ws.dist;
     int* stat = a.ws.status;
-    if (tid < 4) stat[tid] = 0;
+    const long long t_begin = wall_clock64();
+    const long long c_begin = clock64();
     if (nR <= 0 || nC <= 0) { if (tid == 0) *a.ws.cost = 0.0; for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
     const int minDim = perRow ? nR : nC;
+    int n_s4 = 0, n_s5 = 0, n_sw = 0, n_cov5 = 0, ncu0 = 0; long long t_s3 = 0, t_s5 = 0;     // wave-0 / thread-0 statistics
 
     for (int i = tid; i < MK_MAXN; i += MK_THREADS) { S.starColOfRow[i] = -1; S.starRowOfCol[i] = -1; S.primeColOfRow[i] = -1; }
-    if (tid < MK_MAXW) {
-        S.covR[tid] = 0; S.covC[tid] = 0;
-        S.validR[tid] = (tid < wordsR) ? ((tid == wordsR - 1 && (nR & 63)) ? ((1ull << (nR & 63)) - 1) : ~0ull) : 0;
-        S.validC[tid] = (tid < wordsC) ? ((tid == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
-    }
+    if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
+    if (tid < 2 * MK_MAXW) { S.taken32[tid] = 0; S.cont32[tid] = 0; }
     // ---- steps 1 + 2a: initial stars (hungarian.cpp:93-101 / :128-139) ----
-    // lines = rows (perRow) scanned in order, each takes its first zero whose cross line is still free
+    // lines (rows if perRow, else columns) are scanned in order; each takes its first zero whose cross line
+    // is still free.  A line whose first zero sits in a cross line with exactly ONE zero ("clean") can be
+    // starred out of order: no other line can ever claim that cross line.  Only the contested lines go
+    // through the ordered scan (wave 0).
     {
-        const int nL = perRow ? nR : nC, W = perRow ? wordsC : wordsR;
-        const u64* src = perRow ? a.ws.zr : a.ws.zc;
-        for (int i = tid; i < nL * W; i += MK_THREADS) S.bm[(i / W) * MK_MAXW + (i % W)] = src[i];
+        const int nL = perRow ? nR : nC, nX = perRow ? nC : nR;
+        const int W = perRow ? wordsC : wordsR, WX = perRow ? wordsR : wordsC;
+        const u64* lineBm = perRow ? a.ws.zr : a.ws.zc;
+        const u64* crossBm = perRow ? a.ws.zc : a.ws.zr;
+        for (int i = tid; i < nL * W; i += MK_THREADS) S.bm[(i / W) * MK_MAXW + (i % W)] = lineBm[i];
+        for (int x = tid; x < nX; x += MK_THREADS) {
+            int cnt = 0;
+            for (int w = 0; w < WX; w++) cnt += __popcll(crossBm[(size_t)x * WX + w]);
+            S.crosscnt[x] = (unsigned short)min(cnt, 65535);
+        }
+        __syncthreads();
+        for (int l = tid; l < nL; l += MK_THREADS) {
+            int fz = -1;
+            for (int w = 0; w < W; w++) { const u64 m = S.bm[l * MK_MAXW + w]; if (m) { fz = w * 64 + __ffsll((long long)m) - 1; break; } }
+            if (fz >= 0) {
+                if (S.crosscnt[fz] == 1) {
+                    const int row = perRow ? l : fz, col = perRow ? fz : l;
+                    S.starColOfRow[row] = (short)col; S.starRowOfCol[col] = (short)row;
+                    atomicOr(&S.taken32[fz >> 5], 1u << (fz & 31));
+                } else atomicOr(&S.cont32[l >> 5], 1u << (l & 31));
+            }
+        }
         __syncthreads();
         if (wave == 0) {
-            u64 taken = 0;                                            // lane w holds word w of the taken-cross-line mask
-            for (int l0 = 0; l0 < nL; l0 += 8) {
-                u64 m[8];
+            const u64 cont = (lane < MK_MAXW) ? ((u64)S.cont32[2 * lane] | ((u64)S.cont32[2 * lane + 1] << 32)) : 0;
+            const int ncont = wave_list_bits(cont, 0, S.clist, lane);
+            u64 taken = (lane < W) ? ((u64)S.taken32[2 * lane] | ((u64)S.taken32[2 * lane + 1] << 32)) : 0;
+            for (int q0 = 0; q0 < ncont; q0 += 8) {
+                u64 m[8]; int ln[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) m[k] = (lane < W && l0 + k < nL) ? S.bm[(l0 + k) * MK_MAXW + lane] : 0;
+                for (int k = 0; k < 8; k++) { ln[k] = (q0 + k < ncont) ? S.clist[q0 + k] : -1; m[k] = (lane < W && ln[k] >= 0) ? S.bm[ln[k] * MK_MAXW + lane] : 0; }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    if (l0 + k >= nL) break;
-                    const u64 mm = m[k] & ~taken;
-                    const int x = wave_first_bit(mm, lane, W);
+                    if (ln[k] < 0) break;
+                    const int x = wave_first_bit(m[k] & ~taken, lane, W);
                     if (x >= 0) {
                         if (lane == (x >> 6)) taken |= 1ull << (x & 63);
                         if (lane == 0) {
-                            const int row = perRow ? (l0 + k) : x, col = perRow ? x : (l0 + k);
+                            const int row = perRow ? ln[k] : x, col = perRow ? x : ln[k];
                             S.starColOfRow[row] = (short)col; S.starRowOfCol[col] = (short)row;
                         }
                     }
@@ -211,150 +240,223 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             }
         }
         __syncthreads();
-        // covered columns = starred columns (both branches end with exactly that; rows uncovered :138-139)
-        if (tid < wordsC) {
-            u64 w = 0;
-            for (int b = 0; b < 64; b++) { const int c = tid * 64 + b; if (c < nC && S.starRowOfCol[c] >= 0) w |= 1ull << b; }
-            S.covC[tid] = w;
+        {   // covered columns = starred columns (both branches end with exactly that; rows uncovered :138-139)
+            const bool has = tid < nC && S.starRowOfCol[tid] >= 0;
+            const u64 bal = __ballot(has);
+            if (lane == 0) S.covC[wave] = bal;
         }
         __syncthreads();
     }
-    // load the column-major bitmap for the main loop
-    auto count_cov = [&]() { int n = 0; for (int w = 0; w < wordsC; w++) n += __popcll(S.covC[w]); return n; };
-    bool done = (count_cov() == minDim);                               // step 2b (:216-237)
+    int ncov = 0;
+    for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
+    bool done = (ncov == minDim);                                      // step 2b (:216-237)
     if (!done) {
         __syncthreads();
         for (int i = tid; i < nC * wordsR; i += MK_THREADS) S.bm[(i / wordsR) * MK_MAXW + (i % wordsR)] = a.ws.zc[i];
         __syncthreads();
     }
+    // hz[c]: column c holds at least one zero (any row).  Exact for every column that is uncovered while no
+    // row is covered: those are never-starred columns, whose entries change in step 5 only, where hz is rebuilt.
+    if (!done) {
+        const bool has = [&] { bool h2 = false; if (tid < nC) for (int w = 0; w < wordsR; w++) h2 |= S.bm[tid * MK_MAXW + w] != 0; return h2; }();
+        const u64 bal = __ballot(has);
+        if (lane == 0) S.hz[wave] = bal;
+        __syncthreads();
+    }
+    const long long t_init = wall_clock64();
+    // cover masks live in wave 0's registers: lane w (<16) holds word w of covC / hz / phaseUnc, lane l holds
+    // word (l & 15) of covR (replicated over the four 16-lane quarters); LDS mirrors serve the other waves
+    u64 cC = (lane < MK_MAXW) ? S.covC[lane] : 0, cR16 = 0, phaseUnc = 0, hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
+    const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
+    bool covRany = false;
     int guard = 0;
     while (!done) {
-        // ================= step 3 (:240-280), wave 0 =================
+        const long long t_a = wall_clock64();
+        // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wave 0 until a step 5 is needed ==========
         if (wave == 0) {
-            int action = 0;                                           // 1: augmented (go to 2a), 2: no zeros (go to 5)
-            bool zerosFound = true;
+            int action = 0;                                           // 2: sweep found nothing -> step 5, 3: finished
+            int from = 0; bool found_in_sweep = false;                // state of the current column sweep (:249)
             while (action == 0) {
-                if (!zerosFound) { action = 2; break; }
-                zerosFound = false;
-                if (lane == 0) atomicAdd(&stat[2], 1);
-                int from = 0;
-                int cnt = build_uncovered_cols(S, from, wordsC, lane);
-                int pos = 0;
-                while (pos < cnt) {
-                    const int c = (pos + lane < cnt) ? S.list[pos + lane] : -1;
-                    bool hit = false;
-                    if (c >= 0) for (int w = 0; w < wordsR; w++) hit |= (S.bm[c * MK_MAXW + w] & ~S.covR[w]) != 0;
-                    const u64 bal = __ballot(hit);
-                    if (!bal) { pos += 64; continue; }
-                    const int fl = __ffsll((long long)bal) - 1;
-                    const int col = __shfl(c, fl);
-                    const u64 mw = (lane < wordsR) ? (S.bm[col * MK_MAXW + lane] & ~S.covR[lane]) : 0;
-                    const int row = wave_first_bit(mw, lane, wordsR);
-                    const int sc = S.starColOfRow[row];
-                    if (lane == 0) S.primeColOfRow[row] = (short)col;  // prime zero (:255)
-                    if (sc < 0) {
-                        // ---------- step 4 (:283-334): augment along the star/prime path ----------
-                        if (lane == 0) {
-                            atomicAdd(&stat[0], 1);
-                            int cr = row, cc = col;
-                            for (;;) {
-                                const int old_r = S.starRowOfCol[cc];
-                                S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr;
-                                if (old_r < 0) break;
-                                const int pc = S.primeColOfRow[old_r];
-                                cr = old_r; cc = pc;
-                            }
+                if (++n_sw > 8 * MK_MAXN * MK_MAXN) { action = 3; break; }   // safety bound, never reached
+                int col = -1, row = -1;
+                if (!covRany && from == 0) {
+                    // fast sweep: no row is covered, so the first uncovered column holding a zero is the hit
+                    const u64 hm = (lane < MK_MAXW) ? (hz & ~cC & vC) : 0;
+                    col = wave_first_bit(hm, lane, wordsC);
+                    if (col < 0) { action = 2; break; }
+                    const u64 mw = (lane < wordsR) ? S.bm[col * MK_MAXW + lane] : 0;
+                    row = wave_first_bit(mw, lane, wordsR);
+                    if (row < 0) { if (lane == (col >> 6)) hz &= ~(1ull << (col & 63)); continue; }   // stale hint
+                } else {
+                    // general sweep: candidate columns (uncovered, >= from, may hold a zero) in ascending order, four per
+                    // LDS read: quarter q of the wave tests column c_q against the uncovered rows
+                    const int q = lane >> 4, wd = lane & 15;
+                    const int fw = from >> 6;
+                    u64 cand = (lane < MK_MAXW) ? (~cC & vC & (hz | phaseUnc)) : 0;   // hz is a superset of "has a zero"
+                    if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
+                    for (;;) {
+                        int cs[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            cs[j] = wave_first_bit(cand, lane, MK_MAXW);
+                            if (cs[j] >= 0 && lane == (cs[j] >> 6)) cand &= ~(1ull << (cs[j] & 63));
                         }
-                        action = 1;
-                        break;
+                        if (cs[0] < 0) break;
+                        const int myc = q == 0 ? cs[0] : q == 1 ? cs[1] : q == 2 ? cs[2] : cs[3];
+                        u64 m = 0;
+                        if (myc >= 0 && wd < wordsR) m = S.bm[myc * MK_MAXW + wd] & ~cR16;
+                        const u64 bal = __ballot(m != 0);
+                        if (bal) {
+                            const int fl = __ffsll((long long)bal) - 1;   // lowest quarter = lowest column, lowest word = lowest row
+                            const int qq = fl >> 4;
+                            col = qq == 0 ? cs[0] : qq == 1 ? cs[1] : qq == 2 ? cs[2] : cs[3];
+                            const u64 word = readlane64(m, fl);
+                            row = (fl & 15) * 64 + __ffsll((long long)word) - 1;
+                            break;
+                        }
+                        if (cs[3] < 0) break;
                     }
-                    if (lane == 0) { S.covR[row >> 6] |= 1ull << (row & 63); S.covC[sc >> 6] &= ~(1ull << (sc & 63)); } // :270-271
-                    __threadfence_block();
-                    zerosFound = true;
-                    cnt = build_uncovered_cols(S, col + 1, wordsC, lane);  // the sweep continues with the next column (:273)
-                    pos = 0;
+                    if (col < 0) {                                    // end of this sweep (:246-248)
+                        if (found_in_sweep) { found_in_sweep = false; from = 0; continue; }
+                        action = 2; break;
+                    }
                 }
+                const int sc = S.starColOfRow[row];
+                if (lane == 0) S.primeColOfRow[row] = (short)col;      // prime zero (:255)
+                if (sc < 0) {
+                    // ---------- step 4 (:283-334): augment along the star/prime path ----------
+                    n_s4++;
+                    int last = col;                                   // the path ends in the one column that gains a star
+                    if (lane == 0) {
+                        int cr = row, cc = col;
+                        for (int it = 0; it <= nR + nC; it++) {
+                            const int old_r = S.starRowOfCol[cc];
+                            S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr;
+                            if (old_r < 0) break;
+                            cc = S.primeColOfRow[old_r]; cr = old_r;
+                            if (cc < 0) break;                        // broken invariant: never for consistent state
+                        }
+                        last = cc;
+                    }
+                    last = __builtin_amdgcn_readfirstlane(last);
+                    // delete primes (only covered rows and `row` carry one), uncover rows (:324-330)
+                    if (lane < MK_MAXW) { u64 t = cR16; while (t) { const int r2 = lane * 64 + __ffsll((long long)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
+                    if (lane == 0) S.primeColOfRow[row] = -1;
+                    cR16 = 0; covRany = false;
+                    // step 2a (:198-209): every starred column is covered again; the columns uncovered in this
+                    // phase kept a star, and the last column of the path just received its first one
+                    cC |= phaseUnc; if (last >= 0 && lane == (last >> 6)) cC |= 1ull << (last & 63);
+                    phaseUnc = 0;
+                    if (lane < MK_MAXW) { S.covR[lane] = 0; S.covC[lane] = cC; }
+                    int total = 0;
+                    for (int w = 0; w < wordsC; w++) total += __popcll(readlane64(cC, w));
+                    if (total == minDim) { action = 3; break; }      // step 2b
+                    from = 0; found_in_sweep = false;                 // step 3 starts over
+                    continue;
+                }
+                if ((lane & 15) == (row >> 6)) cR16 |= 1ull << (row & 63);                       // :270
+                covRany = true;
+                if (lane < MK_MAXW) {
+                    if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); }   // :271
+                    S.covR[lane] = cR16; S.covC[lane] = cC;
+                }
+                found_in_sweep = true;
+                from = col + 1;                                        // the sweep continues with the next column (:273)
             }
+            if (action == 2) { const int ncu = wave_list_bits(~cC & vC, 0, S.list, lane); if (lane == 0) S.flag[1] = ncu; }
             if (lane == 0) S.flag[0] = action;
         }
         __syncthreads();
         const int action = S.flag[0];
-        if (action == 1) {
-            // delete primes, uncover rows (:324-330); step 2a (:198-209): cover starred columns
-            for (int i = tid; i < nR; i += MK_THREADS) S.primeColOfRow[i] = -1;
-            if (tid < MK_MAXW) S.covR[tid] = 0;
-            __syncthreads();
-            if (tid < wordsC) {
-                u64 w = S.covC[tid];
-                for (int b = 0; b < 64; b++) { const int c = tid * 64 + b; if (c < nC && S.starRowOfCol[c] >= 0) w |= 1ull << b; }
-                S.covC[tid] = w;
-            }
-            __syncthreads();
-            done = (count_cov() == minDim);
-        } else {
-            // ================= step 5 (:337-368) =================
-            if (tid == 0) atomicAdd(&stat[1], 1);
-            // h = min over uncovered rows x uncovered columns
-            int ncu = 0;
-            if (wave == 0) { ncu = build_uncovered_cols(S, 0, wordsC, lane); if (lane == 0) S.flag[1] = ncu; }
-            __syncthreads();
-            ncu = S.flag[1];
+        const long long t_b = wall_clock64();
+        t_s3 += t_b - t_a;
+        if (action == 3) { done = true; break; }
+        // ================= step 5 (:337-368): one row per thread =================
+        n_s5++;
+        {
+            const int ncu = S.flag[1];
+            if (n_s5 == 1) ncu0 = ncu;
+            const int r = tid;
+            const u64 cw = S.covR[wave];                               // wave == 64-row word of this thread's row
+            const bool mine = r < nR && !((cw >> lane) & 1);
             double h = DBL_MAX;
-            for (int r = tid; r < nR; r += MK_THREADS) {
-                if ((S.covR[r >> 6] >> (r & 63)) & 1) continue;
-                for (int k = 0; k < ncu; k++) { const double v = d[(size_t)r + (size_t)nR * S.list[k]]; if (v < h) h = v; }
+            double v[16];
+            const size_t rclamp = (size_t)min(r, nR - 1);
+            // pass 1: h = min over uncovered rows x uncovered columns; 16 columns per round, all loads in flight at once
+            // (unconditional loads with clamped indices: a per-element guard would serialise them)
+            for (int k0 = 0; k0 < ncu; k0 += 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = d[rclamp + (size_t)nR * S.list[min(k0 + k, ncu - 1)]];
+#pragma unroll
+                for (int k = 0; k < 16; k++) if (mine && k0 + k < ncu && v[k] < h) h = v[k];
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(h, off); if (o < h) h = o; }
             if (lane == 0) S.red[wave] = h;
             __syncthreads();
             h = S.red[0];
-            for (int w = 1; w < MK_THREADS / 64; w++) if (S.red[w] < h) h = S.red[w];
-            // (a) uncovered rows in uncovered columns: d -= h ; bitmap bits of uncovered rows rebuilt per word.
-            //     wave-task = (64-row word, 4 columns) so four independent loads are in flight per lane
-            {
-                const int ntask = wordsR * ((ncu + 3) >> 2);
-                for (int t = wave; t < ntask; t += MK_THREADS / 64) {
-                    const int w = t % wordsR, k0 = (t / wordsR) << 2;
-                    const int r = w * 64 + lane;
-                    const u64 cw = S.covR[w];
-                    const bool mine = r < nR && !((cw >> lane) & 1);
-                    double v[4]; int cs[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { cs[u] = (k0 + u < ncu) ? S.list[k0 + u] : -1; v[u] = (mine && cs[u] >= 0) ? d[(size_t)r + (size_t)nR * cs[u]] : 1.0; }
+            for (int w = 1; w < MK_THREADS / 64; w++) { const double o = S.red[w]; if (o < h) h = o; }
+            // (a) uncovered rows x uncovered columns: d -= h; rebuild the uncovered-row bits of the bitmap word
+            for (int k0 = 0; k0 < ncu; k0 += 16) {
+                if (ncu > 16) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (cs[u] < 0) continue;
+                    for (int k = 0; k < 16; k++) v[k] = d[rclamp + (size_t)nR * S.list[min(k0 + k, ncu - 1)]];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k0 + k < ncu) {
+                        const int c = S.list[k0 + k];
                         bool z = false;
-                        if (mine) { const double nv = v[u] - h; d[(size_t)r + (size_t)nR * cs[u]] = nv; z = fabs(nv) < DBL_EPSILON; }
+                        if (mine) { const double nv = v[k] - h; d[(size_t)r + (size_t)nR * c] = nv; z = fabs(nv) < DBL_EPSILON; }
                         const u64 bal = __ballot(z);
-                        if (lane == 0) S.bm[cs[u] * MK_MAXW + w] = (S.bm[cs[u] * MK_MAXW + w] & cw) | (bal & ~cw);
+                        if (lane == 0 && wave < wordsR) S.bm[c * MK_MAXW + wave] = (S.bm[c * MK_MAXW + wave] & cw) | (bal & ~cw);
+                    }
+                }
+            }
+            // (b) covered rows, every column: d += h, then -= h where the column is uncovered (order of :355-364)
+            bool anyCov = false;
+            for (int w = 0; w < wordsR; w++) anyCov |= S.covR[w] != 0;
+            if (anyCov) {
+                if (tid == 0) n_cov5++;
+                __syncthreads();
+                for (int w = 0; w < wordsR; w++) {
+                    u64 rows = S.covR[w];
+                    while (rows) {
+                        const int rr = w * 64 + (__ffsll((long long)rows) - 1); rows &= rows - 1;
+                        for (int c = tid; c < nC; c += MK_THREADS) {
+                            double x = d[(size_t)rr + (size_t)nR * c] + h;
+                            if (!((S.covC[c >> 6] >> (c & 63)) & 1)) x -= h;
+                            d[(size_t)rr + (size_t)nR * c] = x;
+                            const bool z = fabs(x) < DBL_EPSILON;
+                            unsigned int* wp = reinterpret_cast<unsigned int*>(&S.bm[c * MK_MAXW + (rr >> 6)]) + ((rr & 63) >> 5);
+                            const unsigned int bit = 1u << (rr & 31);
+                            const bool cur = (*wp & bit) != 0;
+                            if (z != cur) { if (z) atomicOr(wp, bit); else atomicAnd(wp, ~bit); }
+                        }
                     }
                 }
             }
             __syncthreads();
-            // (b) covered rows, every column: d += h, and -h again where the column is uncovered (same order as :355-364)
-            for (int w = 0; w < wordsR; w++) {
-                u64 rows = S.covR[w];
-                while (rows) {
-                    const int r = w * 64 + (__ffsll((long long)rows) - 1); rows &= rows - 1;
-                    for (int c = tid; c < nC; c += MK_THREADS) {
-                        double v = d[(size_t)r + (size_t)nR * c] + h;
-                        if (!((S.covC[c >> 6] >> (c & 63)) & 1)) v -= h;
-                        d[(size_t)r + (size_t)nR * c] = v;
-                        const bool z = fabs(v) < DBL_EPSILON;
-                        unsigned int* wp = reinterpret_cast<unsigned int*>(&S.bm[c * MK_MAXW + (r >> 6)]) + ((r & 63) >> 5);
-                        const unsigned int bit = 1u << (r & 31);
-                        const bool cur = (*wp & bit) != 0;
-                        if (z != cur) { if (z) atomicOr(wp, bit); else atomicAnd(wp, ~bit); }
-                    }
-                }
+            {   // rebuild hz for the uncovered columns (their entries just changed)
+                const bool unc = tid < nC && !((S.covC[wave] >> lane) & 1);
+                bool has = false;
+                if (unc) for (int w = 0; w < wordsR; w++) has |= S.bm[tid * MK_MAXW + w] != 0;
+                const u64 bal = __ballot(has);
+                if (lane == 0) S.hz[wave] = (S.hz[wave] & S.covC[wave]) | bal;
             }
             __syncthreads();
+            if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
         }
+        t_s5 += wall_clock64() - t_b;
         if (++guard > 4 * MK_MAXN * MK_MAXN) break;                    // cannot happen for finite costs
     }
     __syncthreads();
+    if (tid == 0) {
+        stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0;
+        stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[10] = 0; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
+        stat[13] = (int)((clock64() - c_begin) * 100 / max((long long)1, wall_clock64() - t_begin));   // shader MHz during this launch
+    }
     // buildassignmentvector (:161-176) + computeassignmentcost (:179-189)
     for (int r = tid; r < nR; r += MK_THREADS) a.ws.assignment[r] = S.starColOfRow[r];
     if (want_cost) {

@@ -327,7 +327,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     const size_t mr = std::max(cfg->max_tracks, cfg->max_dets);
     const size_t mat = std::min(n2, mr * mr);
     HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024));
-    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(8)); HIPCHK(c->a_cost.alloc(1));
+    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
     c->slots_per_rank = (cfg->max_tracks + cfg->world - 1) / cfg->world;
@@ -643,6 +643,14 @@ int mot_crop_patch(mot_ctx* c, const bbox_t* box, int rows, int cols, float* pat
     HIPCHK(launch_kcf_crop_only(p, l, 1, dp.p, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(patch_out, dp.p, npx * sizeof(float), hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_get_assoc_stats(mot_ctx* c, int* out16)
+{
+    if (!c || !out16) return fail(MOT_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out16, c->assoc.status, sizeof(int) * 16, hipMemcpyDeviceToHost));
     return MOT_OK;
 }
 

@@ -192,7 +192,9 @@ def ref_frame_loop(kind, scene, n_frames, libs, timing=None):
     def mk(bb):
         return BBox(int(bb[0]), int(bb[1]), int(bb[2]), int(bb[3]), int(bb[4]), float(bb[5]))
 
+    import time as _time
     for frame, dets in scene.frames(n_frames):
+        _t0 = _time.perf_counter()
         nT, nD = len(tracks), len(dets)
         pred = []
         for t in tracks:
@@ -262,6 +264,8 @@ def ref_frame_loop(kind, scene, n_frames, libs, timing=None):
             else:
                 t["h"] = C.c_void_p(kal.refkal_new(C.byref(db)))
             tracks.append(t)
+        if timing is not None:
+            timing.append((_time.perf_counter() - _t0, nT))
         trace.append(dict(pred=pred, assigned=list(at), live=[tuple(t["bbox"][:5]) for t in tracks], tids=[t["tid"] for t in tracks]))
     for t in tracks:
         (kcf.refkcf_delete if kind == 0 else kal.refkal_delete)(t["h"])
