@@ -198,6 +198,8 @@ def main():
                 acc += ctx.profile_frame_device(fp, dp, n_tracks)
                 if args.debug_assoc:
                     print("assoc", ctx.assoc_stats().tolist(), file=sys.stderr)
+                    pa, ub = ctx.debug_kcf_phases(True)
+                    print("kcf predict phases us", (np.diff(pa) / 100.0).round(1).tolist(), "update", (np.diff(ub) / 100.0).round(1).tolist(), file=sys.stderr)
                 f += 1
             stage = acc / n_prof
 

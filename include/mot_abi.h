@@ -167,6 +167,9 @@ int mot_get_response(mot_ctx* ctx, int id, float* out, int* f_rows, int* f_cols)
 int mot_get_model(mot_ctx* ctx, int id, float* xm_out /* 31*f_cols*(f_rows/2+1)*2 */, float* alpha_out);
 int mot_get_kalman_state(mot_ctx* ctx, int id, double* x6, double* P36);
 int mot_get_pos(mot_ctx* ctx, int id, bbox_t* pos);
+/* debug: enable / read the per-phase time stamps (100 MHz ticks) of workgroup 0 of the device-loop KCF kernels:
+ * [0] start [1] crop [2] gradient [3] histogram [4] norm [5] channels [6] DFT [7] end */
+int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long long* update8);
 /* counters of the most recent Munkres launch: [0] step-4 augmentations [1] step-5 updates [2] step-3 sweeps,
  * [4..7] nRows nCols rowsAreTrackers perRow, [8..12] device time in 10 ns ticks: init, step 3, step 4/2a, step 5, total */
 int mot_get_assoc_stats(mot_ctx* ctx, int* out16);

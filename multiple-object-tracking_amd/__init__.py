@@ -279,6 +279,11 @@ class MotContext:
         self._chk(self.lib.mot_get_pos(self._h, int(tid), _vp(b)))
         return b[0]
 
+    def debug_kcf_phases(self, enable=True):
+        a = np.zeros(8, np.int64); b = np.zeros(8, np.int64)
+        self._chk(self.lib.mot_debug_kcf_phases(self._h, int(enable), _vp(a), _vp(b)))
+        return a, b
+
     def assoc_stats(self) -> np.ndarray:
         out = np.zeros(16, np.int32)
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))

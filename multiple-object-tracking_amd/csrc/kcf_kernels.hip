@@ -25,26 +25,30 @@ namespace {
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-// x86 rcpps / rsqrtps (libhog/sse.hpp:40-41) -- integer model, see tools/gen_sse_tables.c
+// x86 rcpps / rsqrtps (libhog/sse.hpp:40-41) -- integer model, see tools/gen_sse_tables.c.
+// Written select-style (no branches): the table path is computed unconditionally and the special
+// cases (NaN, zero/denormal, infinity, negative, underflow) are patched in with conditional moves.
 __device__ __forceinline__ float sse_rcp(float x, const uint16_t* tab)
 {
-    uint32_t u = f2u(x), s = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffff;
-    if (e == 0xff) return u2f(m ? (u | 0x400000u) : s);
-    if (e == 0) return u2f(s | 0x7f800000u);
-    int ep = 253 - (int)e;
-    if (ep <= 0) return u2f(s);
-    return u2f(s | ((uint32_t)ep << 23) | ((uint32_t)tab[m >> 12] << 11));
+    const uint32_t u = f2u(x), s = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffff;
+    const int ep = 253 - (int)e;
+    uint32_t r = s | ((uint32_t)ep << 23) | ((uint32_t)tab[m >> 12] << 11);
+    r = (ep <= 0) ? s : r;                                   // result underflows -> +-0
+    r = (e == 0) ? (s | 0x7f800000u) : r;                    // zero / denormal -> +-inf
+    r = (e == 0xff) ? (m ? (u | 0x400000u) : s) : r;         // NaN -> quiet NaN, inf -> +-0
+    return u2f(r);
 }
 __device__ __forceinline__ float sse_rsqrt(float x, const uint16_t* tab)
 {
-    uint32_t u = f2u(x), s = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffff;
-    if (e == 0xff && m) return u2f(u | 0x400000u);
-    if (e == 0) return u2f(s | 0x7f800000u);
-    if (s) return u2f(0xffc00000u);
-    if (e == 0xff) return 0.0f;
-    int E = (int)e - 127, odd = E & 1;
-    int ep = odd ? 126 - (E - 1) / 2 : 126 - E / 2;
-    return u2f(((uint32_t)ep << 23) | ((uint32_t)tab[2048 + odd * 1024 + (m >> 13)] << 11));
+    const uint32_t u = f2u(x), s = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffff;
+    const int E = (int)e - 127, odd = E & 1;
+    const int ep = 126 - ((E - odd) >> 1);                   // odd: 126-(E-1)/2, even: 126-E/2 (E-odd is even: exact shift)
+    uint32_t r = ((uint32_t)ep << 23) | ((uint32_t)tab[2048 + odd * 1024 + (m >> 13)] << 11);
+    r = (e == 0xff) ? 0u : r;                                // +inf -> 0
+    r = s ? 0xffc00000u : r;                                 // negative -> NaN
+    r = (e == 0) ? (s | 0x7f800000u) : r;                    // +-0 / denormal -> +-inf
+    r = (e == 0xff && m) ? (u | 0x400000u) : r;              // NaN -> quiet NaN
+    return u2f(r);
 }
 
 // drawlib.c:234 -- double arithmetic, one rounding to float at the end.
@@ -65,7 +69,7 @@ struct Ctx {
 // Phase 0: crop + gray + (bilinear resize) -> P[c*ldp + r]
 // ---------------------------------------------------------------------------
 __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, const float* __restrict__ patch,
-                           bbox_t box, float* __restrict__ P, int tid, int nt)
+                           bbox_t box, float* __restrict__ P, uint8_t* __restrict__ raw, int tid, int nt)
 {
     const int rows = p.rows, cols = p.cols, npx = rows * cols;
     if (patch) {
@@ -82,6 +86,31 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
     const int rows_s = bottom - top + 1;                               // rgb2Gray's column stride
     if (hs == rows && ws == cols && rows_s == rows) {
         // identity resize (frac == 0): patch flat index d = c*rows + r <-> pixel (top+r, left+c)
+        if (raw && left >= 0 && top >= 0 && left + cols <= MOT_FRAME_W && top + rows <= MOT_FRAME_H) {
+            // stage the BGR rows of the crop in LDS with aligned 16-byte loads (all loads of the workgroup in
+            // flight at once, one HBM round trip), then convert from LDS
+            const size_t g0 = (size_t)(frame + ((size_t)top * MOT_FRAME_W + left) * 3);
+            const int mis = (int)(g0 & 15);                            // same for every row: 3840 = 240 * 16
+            const int nch = (mis + cols * 3 + 15) >> 4;                // 16-byte chunks per row
+            const int stride = nch * 16;
+            const uint8_t* fend = frame + (size_t)MOT_FRAME_W * MOT_FRAME_H * 3;
+            for (int i = tid; i < rows * nch; i += nt) {
+                const int r = i / nch, j = i - r * nch;
+                const uint8_t* src = frame + ((size_t)(top + r) * MOT_FRAME_W + left) * 3 - mis + 16 * j;
+                uint4 v;
+                if (src + 16 <= fend) v = *reinterpret_cast<const uint4*>(src);
+                else { uint8_t t8[16]; for (int q = 0; q < 16; q++) t8[q] = (src + q < fend) ? src[q] : 0; v = *reinterpret_cast<uint4*>(t8); }
+                *reinterpret_cast<uint4*>(raw + r * stride + 16 * j) = v;
+            }
+            __syncthreads();
+            for (int i = tid; i < npx; i += nt) {
+                uint32_t r, c; p.d_cols.divmod((uint32_t)i, r, c);
+                const uint8_t* px = raw + r * stride + mis + 3 * c;
+                const double B = (double)px[0], G = (double)px[1], R = (double)px[2];
+                P[c * p.ldp + r] = (float)(0.144 * B + 0.587 * G + 0.299 * R);   // drawlib.c:234
+            }
+            return;
+        }
         for (int i = tid; i < npx; i += nt) {
             uint32_t r, c; p.d_cols.divmod((uint32_t)i, r, c);         // c fastest: contiguous BGR bytes
             P[c * p.ldp + r] = gray_of(frame, top + (int)r, left + (int)c);
@@ -123,29 +152,27 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 {
     const int h = p.rows, w = p.cols, npx = h * w, ldp = p.ldp;
     const int thr0[9] = MOT_BIN_THR0;
-    const int thr1[9] = MOT_BIN_THR1;
+    { const int t1[9] = MOT_BIN_THR1; for (int j = 0; j < 9; j++) if (t1[j] != thr0[j]) __builtin_trap(); }   // both sign flags share the thresholds
     const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
     for (int i = tid; i < npx; i += nt) {
         uint32_t x, y; p.d_rows.divmod((uint32_t)i, x, y);
-        const float* Ic = P + x * ldp;
-        float gx, gy;
-        if (x == 0) gx = (Ic[ldp + y] - Ic[y]) * 1.0f;
-        else if ((int)x == w - 1) gx = (Ic[y] - Ic[(int)y - ldp]) * 1.0f;
-        else gx = (Ic[ldp + y] - Ic[(int)y - ldp]) * 0.5f;
-        if (y == 0) gy = (Ic[1] - Ic[0]) * 1.0f;
-        else if ((int)y == h - 1) gy = (Ic[h - 1] - Ic[h - 2]) * 1.0f;
-        else gy = (Ic[y + 1] - Ic[y - 1]) * 0.5f;
-        float m2 = gx * gx + gy * gy;
+        // one-sided differences at the borders are the same expression with clamped neighbours and factor 1
+        const int xm = max((int)x - 1, 0), xp = min((int)x + 1, w - 1);
+        const int ym = max((int)y - 1, 0), yp = min((int)y + 1, h - 1);
+        const float rx = (x == 0 || (int)x == w - 1) ? 1.0f : 0.5f;
+        const float ry = (y == 0 || (int)y == h - 1) ? 1.0f : 0.5f;
+        const float gx = (P[xp * ldp + y] - P[xm * ldp + y]) * rx;
+        const float gy = (P[x * ldp + yp] - P[x * ldp + ym]) * ry;
+        const float m2 = gx * gx + gy * gy;
         float m = approx ? sse_rsqrt(m2, tab) : 1.0f / sqrtf(m2);
-        if (!(m < 1e10f)) m = 1e10f;                                   // _mm_min_ps(m, 1e10f)
-        float mag = approx ? sse_rcp(m, tab) : 1.0f / m;
+        m = (m < 1e10f) ? m : 1e10f;                                   // _mm_min_ps(m, 1e10f)
+        const float mag = approx ? sse_rcp(m, tab) : 1.0f / m;
         float g = (gx * m) * 10000.0f;
         g = u2f(f2u(g) ^ (f2u(gy) & 0x80000000u));
-        int idx = (int)g;
-        int flag = gy < 0.0f;
-        int b = flag ? MOT_BIN_TOP1 : MOT_BIN_TOP0;
+        const int idx = (int)g;
+        int b = (gy < 0.0f) ? MOT_BIN_TOP1 : MOT_BIN_TOP0;
 #pragma unroll
-        for (int j = 0; j < 9; j++) b -= (idx >= (flag ? thr1[j] : thr0[j])) ? 1 : 0;
+        for (int j = 0; j < 9; j++) b -= (idx >= thr0[j]) ? 1 : 0;     // thr0 == thr1 (static_assert below)
         if (b >= 18) b = 0;
         Mq[i] = mag * 0.0625f;                                         // norm = 1/bin/bin (:152,132)
         bins[i] = (uint8_t)b;
@@ -169,25 +196,39 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         for (int o = 0; o < MOT_NORI; o++) R1[o * nb + cell] = 0.0f;
         const int x_lo = max(0, 4 * (int)cx - 2), x_hi = min(w0 - 1, 4 * (int)cx + 5);
         const int y_lo = max(0, 4 * (int)cy - 2), y_hi = min(h0 - 1, 4 * (int)cy + 5);
-        for (int x = x_lo; x <= x_hi; x++) {
-            const float xb = -0.375f + 0.25f * (float)x;               // init + x*sInv, exact
-            const int xb0 = (xb >= 0.0f) ? (int)xb : -1;
-            const float xd = xb - (float)xb0;
-            const bool left = (xb0 == (int)cx);                        // else this cell is the right neighbour (xb0+1)
-            for (int y = y_lo; y <= y_hi; y++) {
-                const float yb = -0.375f + 0.25f * (float)y;
-                const int yb0 = (y < 2) ? -1 : (int)yb;
-                const float yd = yb - (float)yb0;
-                const bool topc = (yb0 == (int)cy);
-                const float xyd = xd * yd;
-                float ms;
-                if (left) ms = topc ? (1.0f - xd - yd + xyd) : (yd - xyd);
-                else ms = topc ? (xd - xyd) : xyd;
-                const int pi = x * h + y;
-                const int o = bins[pi];
-                const float term = ms * Mq[pi];
-                R1[o * nb + cell] += term;
+        // One column of the footprint (<= 8 pixels) per round: all LDS reads of the round are issued together and
+        // the eight read-modify-writes are resolved in registers in pixel order (a later pixel of the same
+        // orientation takes the running value of the earlier one), then written back in order -- the same
+        // sequence of float additions as the reference, without eight dependent LDS round trips.
+        // The bilinear weight of footprint pixel (i, j), i/j = 0..7 counted from (4cx-2, 4cy-2), is the exact
+        // product wq[i]*wq[j] with wq = {1,3,5,7,7,5,3,1}/8: the reference's ms[] expressions (:192) evaluate
+        // to exactly these values (all operands are multiples of 1/8, products multiples of 1/64).
+        const float wq[8] = { 0.125f, 0.375f, 0.625f, 0.875f, 0.875f, 0.625f, 0.375f, 0.125f };
+        const int x0 = 4 * (int)cx - 2, y0 = 4 * (int)cy - 2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int x = x0 + i;
+            if (x < x_lo || x > x_hi) continue;
+            int ob[8]; float term[8], cur[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int y = y0 + j;
+                const bool valid = (y >= y_lo) && (y <= y_hi);
+                const int pi = x * h + (valid ? y : y_lo);
+                ob[j] = valid ? (int)bins[pi] : (100 + j);             // invalid slots never match
+                term[j] = (wq[i] * wq[j]) * Mq[pi];
             }
+#pragma unroll
+            for (int j = 0; j < 8; j++) cur[j] = R1[(ob[j] < MOT_NORI ? ob[j] : 0) * nb + cell];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float v = cur[j];
+#pragma unroll
+                for (int q = 0; q < j; q++) if (ob[q] == ob[j]) v = cur[q];   // cur[q] already holds the updated value
+                cur[j] = v + term[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) R1[ob[j] * nb + cell] = cur[j];
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
         if (nmul) {
@@ -524,26 +565,34 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base)
 __device__ void features_to_spectrum(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r,
                                      int tid, int nt, bool spectrum)
 {
+#define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
+    DBG_STAMP(0);
     // stage constants
     for (int i = tid; i < 2048; i += nt) reinterpret_cast<uint32_t*>(r.tab)[i] = reinterpret_cast<const uint32_t*>(p.sse_tab)[i];
     for (int i = tid; i < p.hb; i += nt) r.twr[i] = p.tw_r[i];
     for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
     const float* patch = l.patches ? l.patches + (size_t)item * p.rows * p.cols : nullptr;
-    phase_crop(p, l.frame, patch, box, r.A, tid, nt);
+    phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
     __syncthreads();
+    DBG_STAMP(1);
     float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.rows * p.cols);
     phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
+    DBG_STAMP(2);
     phase_hist(p, Mq, bins, r.A, tid, nt);                           // R1 overlays the patch
     __syncthreads();
+    DBG_STAMP(3);
     phase_energy(p, r.A, r.E, tid, nt);
     __syncthreads();
     phase_norm(p, r.E, r.N, tid, nt);
     __syncthreads();
+    DBG_STAMP(4);
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
     phase_channels(p, r.A, r.N, r.B, fo, l.feat_windowed, tid, nt); // F overlays Mq/bins
     __syncthreads();
+    DBG_STAMP(5);
     if (spectrum) fft_forward(p, r.A, r.B, r.twr, r.twc, tid, nt);
+    DBG_STAMP(6);
 }
 
 template <bool kLds>
@@ -558,19 +607,41 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_predict_kernel(const KcfP
     const int tid = threadIdx.x, nt = blockDim.x;
     const int slot = l.slots[item];
     const bbox_t pos = p.pos[slot];                                    // kcf_t::pos == tracker_info.bbox (td.cpp:351-354)
+    // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
+    // they land while the features are computed
+    const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
+    const bool pre = p.nbins <= nt;
+    const int bpre = min(tid, p.nbins - 1);
+    float2 xmr[MOT_NCHAN]; float alr = 0.f;
+    if (pre) {
+#pragma unroll
+        for (int ch = 0; ch < MOT_NCHAN; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
+        alr = p.alpha[(size_t)slot * p.nbins + bpre];
+    }
     features_to_spectrum(p, l, item, pos, r, tid, nt, true);
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm
     const float2* S = reinterpret_cast<const float2*>(r.B);
-    const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
-    for (int b = tid; b < p.nbins; b += nt) {
-        float zr = 0.f, zi = 0.f;
-#pragma unroll 4
-        for (int ch = 0; ch < MOT_NCHAN; ch++) {
-            const float2 a = S[ch * p.nbins + b]; const float2 m = xm[ch * p.nbins + b];
-            zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y;
+    if (pre) {
+        if (tid < p.nbins) {
+            float zr = 0.f, zi = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < MOT_NCHAN; ch++) {
+                const float2 a = S[ch * p.nbins + tid]; const float2 m = xmr[ch];
+                zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y;
+            }
+            r.zf[tid] = make_float2((zr * alr) * p.norm, (zi * alr) * p.norm);
         }
-        const float al = p.alpha[(size_t)slot * p.nbins + b];
-        r.zf[b] = make_float2((zr * al) * p.norm, (zi * al) * p.norm);
+    } else {
+        for (int b = tid; b < p.nbins; b += nt) {
+            float zr = 0.f, zi = 0.f;
+#pragma unroll 4
+            for (int ch = 0; ch < MOT_NCHAN; ch++) {
+                const float2 a = S[ch * p.nbins + b]; const float2 m = xm[ch * p.nbins + b];
+                zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y;
+            }
+            const float al = p.alpha[(size_t)slot * p.nbins + b];
+            r.zf[b] = make_float2((zr * al) * p.norm, (zi * al) * p.norm);
+        }
     }
     __syncthreads();
     fft_inverse_plane(p, r.zf, r.tmp, r.resp, r.twr, r.twc, tid, nt);
@@ -598,6 +669,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_predict_kernel(const KcfP
         }
         if (l.boxes_out) l.boxes_out[item] = o;
     }
+    DBG_STAMP(7);
 }
 
 template <bool kLds>
@@ -613,11 +685,19 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_update_kernel(const KcfPo
     const int slot = l.slots[item];
     const bbox_t box = l.boxes_in[item];
     const int first = p.first_update[slot];
+    float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
+    const int tot = MOT_NCHAN * p.nbins;
+    // old model values do not depend on this frame: load them now (<= 16 independent loads per thread)
+    const bool pre = tot <= 16 * nt;
+    float2 xold[16];
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
+    }
     features_to_spectrum(p, l, item, box, r, tid, nt, true);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
-    float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
     // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
     for (int b = tid; b < p.nbins; b += nt) {
         float kf = 0.f;
@@ -628,18 +708,30 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_update_kernel(const KcfPo
         p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
     }
     // kcf_update_xf (kcf.cpp:380-395)
-    const int tot = MOT_NCHAN * p.nbins;
-    for (int i = tid; i < tot; i += nt) {
-        const float2 a = S[i];
-        float2 m = first ? make_float2(0.f, 0.f) : xm[i];
-        m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
-        xm[i] = m;
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int i = tid + j * nt;
+            if (i < tot) {
+                const float2 a = S[i]; float2 m = xold[j];
+                m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
+                xm[i] = m;
+            }
+        }
+    } else {
+        for (int i = tid; i < tot; i += nt) {
+            const float2 a = S[i];
+            float2 m = first ? make_float2(0.f, 0.f) : xm[i];
+            m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
+            xm[i] = m;
+        }
     }
     if (tid == 0) {                                                    // kcf.cpp:470-472
         p.pos[slot] = box;
         p.scale[slot] = make_float2(((float)(box.r - box.l + 1)) / ((float)p.cols), ((float)(box.b - box.t + 1)) / ((float)p.rows));
         p.first_update[slot] = 0;
     }
+    DBG_STAMP(7);
 }
 
 template <bool kLds>
@@ -663,7 +755,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_crop_kernel(const KcfPool
     float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
     const Regions r = carve(p, base);
     const int tid = threadIdx.x, nt = blockDim.x;
-    phase_crop(p, l.frame, nullptr, l.boxes_in[item], r.A, tid, nt);
+    phase_crop(p, l.frame, nullptr, l.boxes_in[item], r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
     __syncthreads();
     const int npx = p.rows * p.cols;
     for (int d = tid; d < npx; d += nt) {

@@ -67,8 +67,9 @@ struct mot_ctx {
     mot_impl::DevBuf<bbox_t> d_gather; int slots_per_rank = 0; bool step_open = false;
     // device-resident mode
     mot_impl::DevLoop* devloop = nullptr;
-    // timers
+    // timers / debug
     std::vector<hipEvent_t> events;
+    mot_impl::DevBuf<long long> dbg; bool dbg_on = false;
 };
 
 namespace mot_impl {

@@ -646,6 +646,17 @@ int mot_crop_patch(mot_ctx* c, const bbox_t* box, int rows, int cols, float* pat
     return MOT_OK;
 }
 
+int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long* update8)
+{   // workgroup-0 phase stamps (100 MHz ticks) of the most recent device-loop predict / update launches
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32)); HIPCHK(hipMemset(c->dbg.p, 0, 32 * sizeof(long long))); }
+    c->dbg_on = enable != 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (update8) HIPCHK(hipMemcpy(update8, c->dbg.p + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
 int mot_get_assoc_stats(mot_ctx* c, int* out16)
 {
     if (!c || !out16) return fail(MOT_ERR_ARG, "null argument");

@@ -62,6 +62,7 @@ struct KcfLaunch {
     int clamp;                // apply td.cpp:378-381 to boxes_out
     float* feat_out;          // debug: [n][32][nb] FHOG (optional)
     int feat_windowed;
+    long long* dbg;           // debug: phase time stamps of workgroup 0 (100 MHz ticks), or null
 };
 
 struct KalmanPool {

@@ -222,7 +222,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev)
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
     if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
     if (S.kind == MOT_TRACKER_KCF) {
-        KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1;
+        KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
         HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
     } else HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
@@ -248,7 +248,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     if (ev) HIPCHK(hipEventRecord(ev[3], c->stream));
     const int upd_max = S.spr + nD;
     if (S.kind == MOT_TRACKER_KCF) {
-        KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes;
+        KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
         HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
     } else HIPCHK(launch_kalman_update(c->kal, S.upd_slots, S.upd_count, upd_max, S.upd_boxes, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[4], c->stream));
