@@ -13,53 +13,12 @@
 //     zero structure as bitmaps (n <= 1024 -> 128 KB), so "first uncovered
 //     zero in column-major order" is a ballot + ctz instead of a scan;
 //   * step 5 touches only covered rows and uncovered columns.
-#include "mot_dev.h"
-#include <float.h>
+#include "assoc_common.h"
+#include <stdlib.h>
+
+using namespace assoc;
 
 namespace {
-
-#define MK_MAXN 1024
-#define MK_MAXW 16                  // 64-bit words per bitmap line
-#define MK_THREADS 1024
-
-typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 dkey(double v) { u64 b = (u64)__double_as_longlong(v); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
-__device__ __forceinline__ double dunkey(u64 k) { u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; return __longlong_as_double((long long)b); }
-
-// td.cpp:407-419
-__device__ __forceinline__ double pair_cost(const bbox_t a, const bbox_t d)
-{
-    const int cxi = (a.l + a.r) >> 1, cyi = (a.t + a.b) >> 1;
-    const int cxj = (d.l + d.r) >> 1, cyj = (d.t + d.b) >> 1;
-    double dist = 0.0;
-    dist += sqrt((double)((cxi - cxj) * (cxi - cxj) + (cyi - cyj) * (cyi - cyj))) * (1.0 / ((double)MOT_FRAME_W));
-    if (a.type != d.type) dist += 1.0;
-    return dist;
-}
-
-struct AssocArgs {
-    const bbox_t* trk; const bbox_t* det; const int* nT_dev; int nT; int nD;
-    const double* user; int userR, userC;
-    AssocWs ws;
-    u64* linemin;        // [MK_MAXN] keys
-    int* dims;           // [4]: nR, nC, rowsAreTrackers, minIsPerRow
-    double* cost_only;   // assoc_cost_kernel output
-};
-
-__device__ __forceinline__ void resolve_dims(const AssocArgs& a, int& nR, int& nC, bool& rowsTrk)
-{
-    if (a.user) { nR = a.userR; nC = a.userC; rowsTrk = true; return; }
-    const int nT = a.nT_dev ? *a.nT_dev : a.nT;
-    if (nT < a.nD) { nR = nT; nC = a.nD; rowsTrk = true; }            // td.cpp:388,462-465
-    else { nR = a.nD; nC = nT; rowsTrk = false; }
-}
-
-__device__ __forceinline__ double elem_cost(const AssocArgs& a, int r, int c, int nR, bool rowsTrk)
-{
-    if (a.user) return a.user[(size_t)r + (size_t)nR * c];
-    return rowsTrk ? pair_cost(a.trk[r], a.det[c]) : pair_cost(a.trk[c], a.det[r]);
-}
 
 // pass 1: per-line minimum (rows if nR <= nC, hungarian.cpp:69-81; else columns, :107-119)
 __global__ void __launch_bounds__(256) assoc_min_kernel(AssocArgs a)
@@ -135,39 +94,6 @@ struct MkShared {
     double red[MK_THREADS / 64];
     int flag[8];
 };
-
-__device__ __forceinline__ u64 readlane64(u64 v, int src)          // src must be wave-uniform
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
-    return ((u64)hi << 32) | lo;
-}
-
-__device__ __forceinline__ int wave_first_bit(u64 m, int lane, int nwords)
-{   // lanes < nwords hold words of a line; returns index of the first set bit, or -1 (wave-uniform)
-    const u64 bal = __ballot(lane < nwords && m != 0);
-    if (!bal) return -1;
-    const int w = __ffsll((long long)bal) - 1;
-    const u64 word = readlane64(m, w);
-    return w * 64 + (__ffsll((long long)word) - 1);
-}
-
-// ascending list of the set bits of a <=1024-bit mask held one word per lane, restricted to bits >= from;
-// wave 0 only, returns the count (wave-uniform)
-__device__ __forceinline__ int wave_list_bits(u64 w, int from, unsigned short* out, int lane)
-{
-    const int fw = from >> 6;
-    if (lane < fw) w = 0;
-    else if (lane == fw) w &= ~0ull << (from & 63);
-    const int cnt = __popcll(w);
-    int pre = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
-    const int total = __builtin_amdgcn_readlane(pre, 63);
-    int pos = pre - cnt;
-    while (w) { const int b = __ffsll((long long)w) - 1; out[pos++] = (unsigned short)(lane * 64 + b); w &= w - 1; }
-    return total;
-}
 
 __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost)
 {
@@ -509,6 +435,11 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
         hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     }
+    // default: the eager emulation below; MOT_MUNKRES_LAZY=1 selects the lazy-column variant (munkres_lazy.hip:
+    // same results, touches far fewer bytes per step 5, but its per-event bookkeeping is not yet faster end to end)
+    static int use_lazy = -1;
+    if (use_lazy < 0) { const char* ev = getenv("MOT_MUNKRES_LAZY"); use_lazy = (ev && ev[0] == '1') ? 1 : 0; }
+    if (use_lazy) return launch_munkres_lazy(a, want_cost, s);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));

@@ -396,3 +396,32 @@ def test_dropin_per_object_interface(mot):
         a = np.zeros(nr, np.int32); cost = C.c_double(0); d = np.ascontiguousarray(gm[f"m{i}_d"])
         asg(P(a), C.byref(cost), P(d), nr, nc)
         assert np.array_equal(a, gm[f"m{i}_a"]) and cost.value == float(gm[f"m{i}_c"])
+
+
+def test_munkres_lazy_variant_subprocess():
+    """the lazy-column Munkres kernel (MOT_MUNKRES_LAZY=1, csrc/munkres_lazy.hip) must give the same bit-exact
+    assignments; the switch is read once per process, so it runs in a child process."""
+    import subprocess, sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import mot_amd, orc
+g = np.load(os.path.join("tests", "golden", "munkres_cases.npz"))
+c = mot_amd.MotContext(max_tracks=1024, max_dets=1024)
+for i in range(int(g["n"])):
+    nr, nc, _ = map(int, g[f"m{i}_shape"])
+    a, cost = c.assignment_optimal(g[f"m{i}_d"], nr, nc)
+    assert np.array_equal(a, g[f"m{i}_a"]) and cost == float(g[f"m{i}_c"]), i
+lib = orc.load_oracle(); rng = np.random.default_rng(5)
+for n in (64, 300, 1024):
+    cx = rng.integers(0, 1200, n); cy = rng.integers(0, 640, n)
+    trk = [(int(cx[i] + rng.integers(-3, 4)), int(cy[i] + rng.integers(-3, 4)), int(cy[i]) + 79, int(cx[i]) + 79, i % 3, 0.9) for i in range(n)]
+    det = [(int(cx[i] + rng.integers(-2, 3)), int(cy[i] + rng.integers(-2, 3)), int(cy[i]) + 79, int(cx[i]) + 79, int(i % 3), 0.9) for i in rng.permutation(n)]
+    at, ad, cost = c.assign(trk, det)
+    ra, rc = orc.assignment_optimal(lib, orc.cost_matrix(lib, trk, det), n, n)
+    assert np.array_equal(ad, ra) and cost == rc, n
+print("LAZY_OK", c.assoc_stats()[:3].tolist())
+'''
+    env = dict(os.environ, MOT_MUNKRES_LAZY="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert "LAZY_OK" in out.stdout, out.stdout + out.stderr
