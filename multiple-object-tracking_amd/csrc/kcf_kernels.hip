@@ -19,6 +19,7 @@
 #include "bin_thresholds.inc"
 
 #define PI_F 3.14159265f /* libhog/gradientMex.cpp:12 */
+#define R1S 19   /* LDS stride of one cell's 18 orientation bins (odd: conflict-free across lanes, no multiply per access) */
 
 namespace {
 
@@ -150,32 +151,53 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
 __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, float* __restrict__ Mq,
                               uint8_t* __restrict__ bins, const uint16_t* __restrict__ tab, int tid, int nt)
 {
-    const int h = p.rows, w = p.cols, npx = h * w, ldp = p.ldp;
+    // one thread = 4 vertically adjacent pixels (y0..y0+3) of column x: three aligned 16-byte LDS reads + two scalars.
+    // Mq / bins are stored as [x][2 + y] with column stride ldp so the 8-pixel footprint of a cell starts 16-byte aligned.
+    const int h = p.rows, w = p.cols, LP = p.ldp, ng = p.ng;
     const int thr0[9] = MOT_BIN_THR0;
     { const int t1[9] = MOT_BIN_THR1; for (int j = 0; j < 9; j++) if (t1[j] != thr0[j]) __builtin_trap(); }   // both sign flags share the thresholds
     const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
-    for (int i = tid; i < npx; i += nt) {
-        uint32_t x, y; p.d_rows.divmod((uint32_t)i, x, y);
-        // one-sided differences at the borders are the same expression with clamped neighbours and factor 1
-        const int xm = max((int)x - 1, 0), xp = min((int)x + 1, w - 1);
-        const int ym = max((int)y - 1, 0), yp = min((int)y + 1, h - 1);
+    for (int it = tid; it < w * ng; it += nt) {
+        uint32_t x, kq; p.d_ng.divmod((uint32_t)it, x, kq);
+        const int y0 = 4 * (int)kq;
+        const float* Pc = P + x * LP;
+        const float4 c4 = *reinterpret_cast<const float4*>(Pc + y0);
+        const float4 l4 = *reinterpret_cast<const float4*>(P + max((int)x - 1, 0) * LP + y0);
+        const float4 r4 = *reinterpret_cast<const float4*>(P + min((int)x + 1, w - 1) * LP + y0);
+        const float up = Pc[max(y0 - 1, 0)], dn = Pc[min(y0 + 4, h - 1)];
+        const float cc[6] = { up, c4.x, c4.y, c4.z, c4.w, dn };
+        const float ll[4] = { l4.x, l4.y, l4.z, l4.w }, rr[4] = { r4.x, r4.y, r4.z, r4.w };
         const float rx = (x == 0 || (int)x == w - 1) ? 1.0f : 0.5f;
-        const float ry = (y == 0 || (int)y == h - 1) ? 1.0f : 0.5f;
-        const float gx = (P[xp * ldp + y] - P[xm * ldp + y]) * rx;
-        const float gy = (P[x * ldp + yp] - P[x * ldp + ym]) * ry;
-        const float m2 = gx * gx + gy * gy;
-        float m = approx ? sse_rsqrt(m2, tab) : 1.0f / sqrtf(m2);
-        m = (m < 1e10f) ? m : 1e10f;                                   // _mm_min_ps(m, 1e10f)
-        const float mag = approx ? sse_rcp(m, tab) : 1.0f / m;
-        float g = (gx * m) * 10000.0f;
-        g = u2f(f2u(g) ^ (f2u(gy) & 0x80000000u));
-        const int idx = (int)g;
-        int b = (gy < 0.0f) ? MOT_BIN_TOP1 : MOT_BIN_TOP0;
+        float mq[4]; uint32_t bq[4];
 #pragma unroll
-        for (int j = 0; j < 9; j++) b -= (idx >= thr0[j]) ? 1 : 0;     // thr0 == thr1 (static_assert below)
-        if (b >= 18) b = 0;
-        Mq[i] = mag * 0.0625f;                                         // norm = 1/bin/bin (:152,132)
-        bins[i] = (uint8_t)b;
+        for (int j = 0; j < 4; j++) {
+            const int y = y0 + j;
+            // one-sided differences at the borders = the same expression with clamped neighbours and factor 1
+            const float ym = (y == 0) ? cc[j + 1] : cc[j];
+            const float yp = (y >= h - 1) ? cc[j + 1] : cc[j + 2];
+            const float ry = (y == 0 || y >= h - 1) ? 1.0f : 0.5f;
+            const float gx = (rr[j] - ll[j]) * rx;
+            const float gy = (yp - ym) * ry;
+            const float m2 = gx * gx + gy * gy;
+            float m = approx ? sse_rsqrt(m2, tab) : 1.0f / sqrtf(m2);
+            m = (m < 1e10f) ? m : 1e10f;                               // _mm_min_ps(m, 1e10f)
+            const float mag = approx ? sse_rcp(m, tab) : 1.0f / m;
+            float g = (gx * m) * 10000.0f;
+            g = u2f(f2u(g) ^ (f2u(gy) & 0x80000000u));
+            const int idx = (int)g;
+            int b = (gy < 0.0f) ? MOT_BIN_TOP1 : MOT_BIN_TOP0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) b -= (idx >= thr0[q]) ? 1 : 0;
+            if (b >= 18) b = 0;
+            mq[j] = mag * 0.0625f;                                     // norm = 1/bin/bin (:152,132)
+            bq[j] = (uint32_t)b;
+        }
+        float* mo = Mq + x * LP + 2 + y0;                              // 8-byte aligned
+        *reinterpret_cast<float2*>(mo) = make_float2(mq[0], mq[1]);
+        *reinterpret_cast<float2*>(mo + 2) = make_float2(mq[2], mq[3]);
+        uint8_t* bo = bins + x * LP + 2 + y0;                          // 2-byte aligned
+        *reinterpret_cast<uint16_t*>(bo) = (uint16_t)(bq[0] | (bq[1] << 8));
+        *reinterpret_cast<uint16_t*>(bo + 2) = (uint16_t)(bq[2] | (bq[3] << 8));
     }
 }
 
@@ -188,12 +210,13 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
                            float* __restrict__ R1, int tid, int nt)
 {
-    const int h = p.rows, hb = p.hb, wb = p.wb, nb = p.nb;
+    const int hb = p.hb, wb = p.wb, nb = p.nb, LP = p.ldp;
     const int h0 = hb * 4, w0 = wb * 4;
     for (int cell = tid; cell < nb; cell += nt) {
         uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
+        float* __restrict__ Rc = R1 + cell * R1S;
 #pragma unroll
-        for (int o = 0; o < MOT_NORI; o++) R1[o * nb + cell] = 0.0f;
+        for (int o = 0; o < MOT_NORI; o++) Rc[o] = 0.0f;
         const int x_lo = max(0, 4 * (int)cx - 2), x_hi = min(w0 - 1, 4 * (int)cx + 5);
         const int y_lo = max(0, 4 * (int)cy - 2), y_hi = min(h0 - 1, 4 * (int)cy + 5);
         // One column of the footprint (<= 8 pixels) per round: all LDS reads of the round are issued together and
@@ -209,34 +232,32 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         for (int i = 0; i < 8; i++) {
             const int x = x0 + i;
             if (x < x_lo || x > x_hi) continue;
-            int ob[8]; float term[8], cur[8];
+            int ob[8]; float term[8];
+            const float* mp = Mq + x * LP + 4 * (int)cy;               // = [x][2 + (4cy-2)], 16-byte aligned
+            const float4 ma = *reinterpret_cast<const float4*>(mp), mb = *reinterpret_cast<const float4*>(mp + 4);
+            const uint32_t ba = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
+            const uint32_t bb = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
+            const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int y = y0 + j;
                 const bool valid = (y >= y_lo) && (y <= y_hi);
-                const int pi = x * h + (valid ? y : y_lo);
-                ob[j] = valid ? (int)bins[pi] : (100 + j);             // invalid slots never match
-                term[j] = (wq[i] * wq[j]) * Mq[pi];
+                const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
+                ob[j] = valid ? bj : (100 + j);                        // invalid slots never match
+                term[j] = (wq[i] * wq[j]) * mv[j];
             }
+            // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
+            // same orientation sees the earlier sum; few instructions, the latency is covered by the other waves
 #pragma unroll
-            for (int j = 0; j < 8; j++) cur[j] = R1[(ob[j] < MOT_NORI ? ob[j] : 0) * nb + cell];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                float v = cur[j];
-#pragma unroll
-                for (int q = 0; q < j; q++) if (ob[q] == ob[j]) v = cur[q];   // cur[q] already holds the updated value
-                cur[j] = v + term[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) R1[ob[j] * nb + cell] = cur[j];
+            for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) Rc[ob[j]] += term[j];
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
         if (nmul) {
             const float c = 8.f / 7.f;
             for (int o = 0; o < MOT_NORI; o++) {
-                float v = R1[o * nb + cell];
+                float v = Rc[o];
                 for (int k = 0; k < nmul; k++) v *= c;
-                R1[o * nb + cell] = v;
+                Rc[o] = v;
             }
         }
     }
@@ -250,7 +271,7 @@ __device__ void phase_energy(const KcfPool& p, const float* __restrict__ R1, flo
         float e = 0.0f;
 #pragma unroll
         for (int o = 0; o < 9; o++) {
-            float r2 = R1[o * nb + cell] + R1[(o + 9) * nb + cell];
+            float r2 = R1[cell * R1S + o] + R1[cell * R1S + o + 9];
             e += r2 * r2;
         }
         E[cell] = e;
@@ -272,20 +293,28 @@ __device__ void phase_norm(const KcfPool& p, const float* __restrict__ E, float*
 
 // Phase 4: hogChannels (gradientMex.cpp:256-280, 313-315) x cos window
 // (kcf.cpp:249-258).  F[(ch*wb + x)*ldf + y], ldf = 2*fh.
+// Channels are produced in two halves (0: channels 0..15, 1: channels 16..30) so the feature / spectrum buffer
+// holds 16 planes instead of 31 and two workgroups fit in one CU's LDS.
+#define MOT_HALF0 16
+template <int HALF>
 __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, const float* __restrict__ N,
                                float* __restrict__ F, float* __restrict__ feat_out, int feat_windowed, int tid, int nt)
 {
     const int hb = p.hb, wb = p.wb, nb = p.nb, hb1 = hb + 1, ldf = 2 * p.fh;
     const float clip = 0.2f, r = .2357f;
+    constexpr int C0 = HALF ? MOT_HALF0 : 0, C1 = HALF ? MOT_NCHAN : MOT_HALF0;
     for (int cell = tid; cell < nb; cell += nt) {
         uint32_t x, y; p.d_hb.divmod((uint32_t)cell, x, y);
         const float n0 = N[(x + 1) * hb1 + y + 1], n1 = N[(x + 1) * hb1 + y], n2 = N[x * hb1 + y + 1], n3 = N[x * hb1 + y];
         const float win = p.cos_win[cell];
         float tex0 = 0.f, tex1 = 0.f, tex2 = 0.f, tex3 = 0.f;
         float rlo[9];
+#define PUT(ch, val) do { if ((ch) >= C0 && (ch) < C1) { F[(((ch) - C0) * wb + x) * ldf + y] = (val) * win; \
+                          if (feat_out) feat_out[(ch) * nb + cell] = feat_windowed ? (val) * win : (val); } } while (0)
 #pragma unroll
         for (int o = 0; o < MOT_NORI; o++) {
-            const float v = R1[o * nb + cell];
+            if (HALF == 0 && o >= MOT_HALF0) continue;                  // half 0 needs the first 16 sensitive channels only
+            const float v = R1[cell * R1S + o];
             if (o < 9) rlo[o] = v;
             float t0 = v * n0; if (t0 > clip) t0 = clip;
             float t1 = v * n1; if (t1 > clip) t1 = clip;
@@ -293,33 +322,26 @@ __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, c
             float t3 = v * n3; if (t3 > clip) t3 = clip;
             float hv = 0.0f;
             hv += t0 * .5f; hv += t1 * .5f; hv += t2 * .5f; hv += t3 * .5f;
-            tex0 += t0 * r; tex1 += t1 * r; tex2 += t2 * r; tex3 += t3 * r;
-            F[(o * wb + x) * ldf + y] = hv * win;
-            if (feat_out) feat_out[o * nb + cell] = feat_windowed ? hv * win : hv;
-            if (o >= 9) {
-                const float v2 = rlo[o - 9] + v;                        // R2 (:309)
-                float u0 = v2 * n0; if (u0 > clip) u0 = clip;
-                float u1 = v2 * n1; if (u1 > clip) u1 = clip;
-                float u2 = v2 * n2; if (u2 > clip) u2 = clip;
-                float u3 = v2 * n3; if (u3 > clip) u3 = clip;
-                float hi = 0.0f;
-                hi += u0 * .5f; hi += u1 * .5f; hi += u2 * .5f; hi += u3 * .5f;
-                const int ch = 18 + (o - 9);
-                F[(ch * wb + x) * ldf + y] = hi * win;
-                if (feat_out) feat_out[ch * nb + cell] = feat_windowed ? hi * win : hi;
+            PUT(o, hv);
+            if (HALF == 1) {
+                tex0 += t0 * r; tex1 += t1 * r; tex2 += t2 * r; tex3 += t3 * r;
+                if (o >= 9) {
+                    const float v2 = rlo[o - 9] + v;                    // R2 (:309)
+                    float u0 = v2 * n0; if (u0 > clip) u0 = clip;
+                    float u1 = v2 * n1; if (u1 > clip) u1 = clip;
+                    float u2 = v2 * n2; if (u2 > clip) u2 = clip;
+                    float u3 = v2 * n3; if (u3 > clip) u3 = clip;
+                    float hi = 0.0f;
+                    hi += u0 * .5f; hi += u1 * .5f; hi += u2 * .5f; hi += u3 * .5f;
+                    PUT(18 + (o - 9), hi);
+                }
             }
         }
-        F[((27 + 0) * wb + x) * ldf + y] = tex0 * win;
-        F[((27 + 1) * wb + x) * ldf + y] = tex1 * win;
-        F[((27 + 2) * wb + x) * ldf + y] = tex2 * win;
-        F[((27 + 3) * wb + x) * ldf + y] = tex3 * win;
-        if (feat_out) {
-            feat_out[27 * nb + cell] = feat_windowed ? tex0 * win : tex0;
-            feat_out[28 * nb + cell] = feat_windowed ? tex1 * win : tex1;
-            feat_out[29 * nb + cell] = feat_windowed ? tex2 * win : tex2;
-            feat_out[30 * nb + cell] = feat_windowed ? tex3 * win : tex3;
-            feat_out[31 * nb + cell] = 0.0f;
+        if (HALF == 1) {
+            PUT(27, tex0); PUT(28, tex1); PUT(29, tex2); PUT(30, tex3);
+            if (feat_out) feat_out[31 * nb + cell] = 0.0f;
         }
+#undef PUT
     }
 }
 
@@ -331,9 +353,9 @@ __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, c
 
 // generic forward r2c along y: F[(ch*wb+x)*ldf + y] (real) -> T[((ch*wb+x)*fh + k)] complex
 __device__ void dft_rows_generic(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
-                                 const float2* __restrict__ twr, int tid, int nt)
+                                 const float2* __restrict__ twr, int nch, int tid, int nt)
 {
-    const int hb = p.hb, fh = p.fh, ldf = 2 * fh, total = MOT_NCHAN * p.wb * fh;
+    const int hb = p.hb, fh = p.fh, ldf = 2 * fh, total = nch * p.wb * fh;
     for (int i = tid; i < total; i += nt) {
         uint32_t row, k; p.d_fh.divmod((uint32_t)i, row, k);
         const float* in = F + row * ldf;
@@ -459,27 +481,27 @@ __device__ __forceinline__ void cfft20_inplace(float2* __restrict__ base, int st
     }
 }
 
-// forward 2-D r2c of the 31 feature planes; result S[(ch*wb + x')*fh + k] in region B.
-// F lives in region B (row stride ldf = 2*fh floats); A is the ping-pong buffer.
-__device__ void fft_forward(const KcfPool& p, float* __restrict__ regA, float* __restrict__ regB,
-                            const float2* __restrict__ twr, const float2* __restrict__ twc, int tid, int nt)
+// forward 2-D r2c of `nch` feature planes; result S[(ch*wb + x')*fh + k] in region B.
+// F lives in region B (row stride ldf = 2*fh floats); T is the ping-pong buffer of the generic path.
+__device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* __restrict__ regB,
+                            const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt)
 {
     if (p.fft20) {
-        const int nrows = MOT_NCHAN * p.wb;
+        const int nrows = nch * p.wb;
         for (int r = tid; r < nrows; r += nt) rfft20_inplace(regB + r * 22);
         __syncthreads();
         float2* S = reinterpret_cast<float2*>(regB);
-        const int ncol = MOT_NCHAN * 11;
+        const int ncol = nch * 11;
         for (int i = tid; i < ncol; i += nt) {
             const int ch = i / 11, k = i - ch * 11;
             cfft20_inplace<-1>(S + ch * 220 + k, 11);
         }
         __syncthreads();
     } else {
-        float2* T = reinterpret_cast<float2*>(regA);
-        dft_rows_generic(p, regB, T, twr, tid, nt);
+        float2* T = reinterpret_cast<float2*>(regT);
+        dft_rows_generic(p, regB, T, twr, nch, tid, nt);
         __syncthreads();
-        dft_cols_generic<-1>(p, T, reinterpret_cast<float2*>(regB), twc, MOT_NCHAN, tid, nt);
+        dft_cols_generic<-1>(p, T, reinterpret_cast<float2*>(regB), twc, nch, tid, nt);
         __syncthreads();
     }
 }
@@ -538,7 +560,7 @@ __device__ int block_argmax_first(const float* __restrict__ resp, int n, float* 
 }
 
 struct Regions {
-    float* A; float* B; float* C;
+    float* A; float* B; float* C; float* T;
     float* E; float* N; float2* twr; float2* twc; float2* zf; float2* tmp; float* resp; float* red_v; int* red_i;
     uint16_t* tab;
 };
@@ -546,7 +568,7 @@ struct Regions {
 __device__ __forceinline__ Regions carve(const KcfPool& p, float* base)
 {
     Regions r;
-    r.A = base + p.offA; r.B = base + p.offB; r.C = base + p.offC;
+    r.A = base + p.offA; r.B = base + p.offB; r.C = base + p.offC; r.T = base + p.offT;
     float* c = r.C;
     r.tab = reinterpret_cast<uint16_t*>(c); c += 2048;               // 4096 u16
     r.twr = reinterpret_cast<float2*>(c); c += 2 * p.hb;
@@ -561,9 +583,8 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base)
     return r;
 }
 
-// Everything up to the spectrum S (region B): shared by predict / update.
-__device__ void features_to_spectrum(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r,
-                                     int tid, int nt, bool spectrum)
+// Everything up to R1 (region A) and the norm matrix: shared by predict / update.
+__device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt)
 {
 #define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
     DBG_STAMP(0);
@@ -575,7 +596,7 @@ __device__ void features_to_spectrum(const KcfPool& p, const KcfLaunch& l, int i
     phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
     __syncthreads();
     DBG_STAMP(1);
-    float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.rows * p.cols);
+    float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.cols * p.ldp);
     phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
@@ -587,16 +608,20 @@ __device__ void features_to_spectrum(const KcfPool& p, const KcfLaunch& l, int i
     phase_norm(p, r.E, r.N, tid, nt);
     __syncthreads();
     DBG_STAMP(4);
+}
+
+// one half of the channels -> windowed features -> spectrum in region B (overlays Mq / bins, then itself)
+template <int HALF>
+__device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum)
+{
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
-    phase_channels(p, r.A, r.N, r.B, fo, l.feat_windowed, tid, nt); // F overlays Mq/bins
+    phase_channels<HALF>(p, r.A, r.N, r.B, fo, l.feat_windowed, tid, nt);
     __syncthreads();
-    DBG_STAMP(5);
-    if (spectrum) fft_forward(p, r.A, r.B, r.twr, r.twc, tid, nt);
-    DBG_STAMP(6);
+    if (spectrum) fft_forward(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt);
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -612,35 +637,48 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_predict_kernel(const KcfP
     const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
     const bool pre = p.nbins <= nt;
     const int bpre = min(tid, p.nbins - 1);
-    float2 xmr[MOT_NCHAN]; float alr = 0.f;
+    float2 xmr[MOT_HALF0]; float alr = 0.f;                            // 16 planes at a time (register budget for 2 workgroups / CU)
     if (pre) {
 #pragma unroll
-        for (int ch = 0; ch < MOT_NCHAN; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
+        for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
-    features_to_spectrum(p, l, item, pos, r, tid, nt, true);
-    // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm
+    features_prepare(p, l, item, pos, r, tid, nt);
+    // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
+    // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
+    float zr = 0.f, zi = 0.f;
+    half_spectrum<0>(p, l, item, r, tid, nt, true);
+    DBG_STAMP(5);
     if (pre) {
         if (tid < p.nbins) {
-            float zr = 0.f, zi = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < MOT_NCHAN; ch++) {
-                const float2 a = S[ch * p.nbins + tid]; const float2 m = xmr[ch];
-                zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y;
-            }
+            for (int ch = 0; ch < MOT_HALF0; ch++) { const float2 a = S[ch * p.nbins + tid]; const float2 m = xmr[ch]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
+        }
+#pragma unroll
+        for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) xmr[ch - MOT_HALF0] = xm[ch * p.nbins + bpre];   // second half: lands during its features
+    } else {
+        for (int b = tid; b < p.nbins; b += nt) {      // generic sizes: partial sums parked in zf
+            float pr = 0.f, pi = 0.f;
+            for (int ch = 0; ch < MOT_HALF0; ch++) { const float2 a = S[ch * p.nbins + b]; const float2 m = xm[ch * p.nbins + b]; pr += a.x * m.x + a.y * m.y; pi += a.y * m.x - a.x * m.y; }
+            r.zf[b] = make_float2(pr, pi);
+        }
+    }
+    __syncthreads();
+    half_spectrum<1>(p, l, item, r, tid, nt, true);
+    DBG_STAMP(6);
+    if (pre) {
+        if (tid < p.nbins) {
+#pragma unroll
+            for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = S[(ch - MOT_HALF0) * p.nbins + tid]; const float2 m = xmr[ch - MOT_HALF0]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
             r.zf[tid] = make_float2((zr * alr) * p.norm, (zi * alr) * p.norm);
         }
     } else {
         for (int b = tid; b < p.nbins; b += nt) {
-            float zr = 0.f, zi = 0.f;
-#pragma unroll 4
-            for (int ch = 0; ch < MOT_NCHAN; ch++) {
-                const float2 a = S[ch * p.nbins + b]; const float2 m = xm[ch * p.nbins + b];
-                zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y;
-            }
+            float pr = r.zf[b].x, pi = r.zf[b].y;
+            for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = S[(ch - MOT_HALF0) * p.nbins + b]; const float2 m = xm[ch * p.nbins + b]; pr += a.x * m.x + a.y * m.y; pi += a.y * m.x - a.x * m.y; }
             const float al = p.alpha[(size_t)slot * p.nbins + b];
-            r.zf[b] = make_float2((zr * al) * p.norm, (zi * al) * p.norm);
+            r.zf[b] = make_float2((pr * al) * p.norm, (pi * al) * p.norm);
         }
     }
     __syncthreads();
@@ -673,7 +711,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_predict_kernel(const KcfP
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -694,37 +732,51 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_update_kernel(const KcfPo
 #pragma unroll
         for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
     }
-    features_to_spectrum(p, l, item, box, r, tid, nt, true);
+    features_prepare(p, l, item, box, r, tid, nt);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
-    // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
+    const int tot0 = MOT_HALF0 * p.nbins;
+    float kf = 0.f;                                                    // kcf_linear_correlation_kf (kcf.cpp:269-304), one bin per thread
+    // per half: kf partial sums, then kcf_update_xf (kcf.cpp:380-395) for the channels of this half
+#define UPDATE_HALF(C0, C1)                                                                                      \
+    do {                                                                                                          \
+        if (p.nbins <= nt) {                                                                                      \
+            if (tid < p.nbins) for (int ch = (C0); ch < (C1); ch++) { const float2 a = S[(ch - (C0)) * p.nbins + tid]; kf = (a.x * a.x + a.y * a.y) + kf; } \
+        } else {                                                                                                  \
+            for (int b = tid; b < p.nbins; b += nt) { float q = ((C0) == 0) ? 0.f : r.tmp[b].x;                   \
+                for (int ch = (C0); ch < (C1); ch++) { const float2 a = S[(ch - (C0)) * p.nbins + b]; q = (a.x * a.x + a.y * a.y) + q; } \
+                r.tmp[b].x = q; }                                                                                 \
+        }                                                                                                         \
+        if (pre) {                                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 16; j++) {                                                      \
+                const int i = tid + j * nt;                                                                       \
+                if (i >= (C0) * p.nbins && i < (C1) * p.nbins) {                                                  \
+                    const float2 a = S[i - (C0) * p.nbins]; float2 m = xold[j];                                   \
+                    m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y; xm[i] = m; }                \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            for (int i = (C0) * p.nbins + tid; i < (C1) * p.nbins; i += nt) {                                     \
+                const float2 a = S[i - (C0) * p.nbins]; float2 m = first ? make_float2(0.f, 0.f) : xm[i];         \
+                m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y; xm[i] = m; }                    \
+        }                                                                                                         \
+    } while (0)
+    half_spectrum<0>(p, l, item, r, tid, nt, true);
+    DBG_STAMP(5);
+    UPDATE_HALF(0, MOT_HALF0);
+    __syncthreads();
+    half_spectrum<1>(p, l, item, r, tid, nt, true);
+    DBG_STAMP(6);
+    UPDATE_HALF(MOT_HALF0, MOT_NCHAN);
+#undef UPDATE_HALF
+    (void)tot0;
+    // kcf_update_alpha (kcf.cpp:364-378)
     for (int b = tid; b < p.nbins; b += nt) {
-        float kf = 0.f;
-        for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = S[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
-        kf = kf * p.norm;
-        const float a = p.yf_re[b] / (kf + p.lambda);
+        float kq = (p.nbins <= nt) ? kf : r.tmp[b].x;
+        kq = kq * p.norm;
+        const float a = p.yf_re[b] / (kq + p.lambda);
         const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
         p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
-    }
-    // kcf_update_xf (kcf.cpp:380-395)
-    if (pre) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int i = tid + j * nt;
-            if (i < tot) {
-                const float2 a = S[i]; float2 m = xold[j];
-                m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
-                xm[i] = m;
-            }
-        }
-    } else {
-        for (int i = tid; i < tot; i += nt) {
-            const float2 a = S[i];
-            float2 m = first ? make_float2(0.f, 0.f) : xm[i];
-            m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
-            xm[i] = m;
-        }
     }
     if (tid == 0) {                                                    // kcf.cpp:470-472
         p.pos[slot] = box;
@@ -743,7 +795,10 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool
     float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
     const Regions r = carve(p, base);
     bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
-    features_to_spectrum(p, l, item, box, r, threadIdx.x, blockDim.x, false);
+    features_prepare(p, l, item, box, r, threadIdx.x, blockDim.x);
+    half_spectrum<0>(p, l, item, r, threadIdx.x, blockDim.x, false);
+    __syncthreads();
+    half_spectrum<1>(p, l, item, r, threadIdx.x, blockDim.x, false);
 }
 
 template <bool kLds>
@@ -773,19 +828,20 @@ void kcf_pool_layout(KcfPool& p)
 {
     p.hb = p.rows / MOT_CELL; p.wb = p.cols / MOT_CELL; p.fh = p.hb / 2 + 1;
     p.nb = p.hb * p.wb; p.nbins = p.wb * p.fh;
-    p.ldp = p.rows | 1;
+    p.ldp = ((p.rows + 3) & ~3) + 4;
+    p.ng = (p.rows + 3) / 4;
+    p.d_ng.init(p.ng);
     p.d_rows.init(p.rows); p.d_cols.init(p.cols); p.d_hb.init(p.hb); p.d_fh.init(p.fh); p.d_nbins.init(p.nbins); p.d_nb.init(p.nb);
     p.norm = (float)(1.0 / (double)((float)(p.wb * p.hb * MOT_NCHAN)));
     p.eta = 0.05f; p.lambda = 0.0001f;
-    const int npx = p.rows * p.cols;
-    const int spec = MOT_NCHAN * p.nbins * 2;                         // floats of a full spectrum / padded feature set
+    const int spec = MOT_HALF0 * p.nbins * 2;                         // floats of 16 spectrum planes / padded feature planes
     auto up4 = [](int v) { return (v + 3) & ~3; };
-    int szA = p.cols * p.ldp; if (MOT_NORI * p.nb > szA) szA = MOT_NORI * p.nb;
-    int szB = npx + (npx + 3) / 4; if (spec > szB) szB = spec;
-    if (!p.fft20 && spec > szA) szA = spec;                           // ping-pong buffer of the generic DFT
+    int szA = p.cols * p.ldp; if (19 * p.nb > szA) szA = 19 * p.nb;   // patch, then R1[cell][19]
+    int szB = p.cols * p.ldp + (p.cols * p.ldp + 3) / 4 + 8; if (spec > szB) szB = spec;   // Mq + bins in the padded column layout
     const int szC = 2048 + 2 * p.hb + 2 * p.wb + 4 * p.nbins + p.nb + (p.hb + 1) * (p.wb + 1) + p.nb + 32;
-    p.offA = 0; p.offB = up4(szA); p.offC = p.offB + up4(szB);
-    p.lds_floats = p.offC + up4(szC);
+    const int szT = p.fft20 ? 0 : spec;                               // ping-pong buffer of the generic DFT
+    p.offA = 0; p.offB = up4(szA); p.offC = p.offB + up4(szB); p.offT = p.offC + up4(szC);
+    p.lds_floats = p.offT + up4(szT);
     p.use_lds = ((size_t)p.lds_floats * sizeof(float) <= MOT_LDS_LIMIT) ? 1 : 0;
 }
 

@@ -28,13 +28,14 @@ struct KcfPool {
     int fh;                   // hb/2+1
     int nb;                   // hb*wb cells
     int nbins;                // wb*fh half-spectrum bins
-    int ldp;                  // LDS patch column stride (odd)
-    FastDiv d_rows, d_cols, d_hb, d_fh, d_nbins, d_nb;
+    int ldp;                  // LDS patch column stride: roundup4(rows) + 4 (16-byte aligned 4-pixel groups)
+    int ng;                   // 4-pixel groups per column
+    FastDiv d_rows, d_cols, d_hb, d_fh, d_nbins, d_nb, d_ng;
     float norm;               // 1/(hb*wb*31)  (kcf.cpp:197)
     float eta, lambda;        // kcf.cpp:211-212
     int fhog_mode, fft20;
     // scratch carve (float offsets) and size
-    int offA, offB, offC, lds_floats;
+    int offA, offB, offC, offT, lds_floats;   // offT: ping-pong buffer of the generic DFT (unused by the 20x20 register FFT)
     int use_lds;              // 1: scratch in LDS, 0: per-workgroup slab in HBM
     float* gscratch;          // [grid][lds_floats] when !use_lds
     // state, indexed by slot
