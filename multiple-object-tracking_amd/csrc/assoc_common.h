@@ -11,6 +11,26 @@ namespace assoc {
 
 typedef unsigned long long u64;
 
+// ---- step-5 helper protocol (munkres_kernel launched with 1 + MK_HELPERS workgroups) -------------------------
+// control block, u64 words; every access is a relaxed agent-scope atomic (sc1), flags follow G16 of the HIP guide
+#define MK_HELPERS 16
+#define CTL_SEQ 0
+#define CTL_CMD 1
+#define CTL_ARRIVE 2
+#define CTL_NCU 3
+#define CTL_H 4
+#define CTL_NCR 5
+#define CTL_COVR 8
+#define CTL_COVC 24
+#define CTL_PARTIAL 40
+#define CTL_LIST 64      /* 1024 entries, one u64 each */
+#define CTL_CROWS 1088   /* 1024 entries */
+#define CTL_COVBITS 2112 /* [1024 rows][16 words] */
+#define CTL_BMOUT (2112 + 16384) /* [1024 cols][16 words] */
+#define MK_CTL_WORDS (2112 + 2 * 16384)
+__device__ __forceinline__ u64 ctl_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctl_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ u64 dkey(double v) { u64 b = (u64)__double_as_longlong(v); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
 __device__ __forceinline__ double dunkey(u64 k) { u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; return __longlong_as_double((long long)b); }
 

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) assoc_min_kernel(AssocArgs a)
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const int r = blockIdx.x * 64 + (threadIdx.x & 63);
     const int c0 = blockIdx.y * 64, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.ws.ctl) { a.ws.ctl[CTL_SEQ] = 0; a.ws.ctl[CTL_ARRIVE] = 0; a.ws.ctl[CTL_CMD] = 0; }
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
     const bool perRow = nR <= nC;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.dims[0] = nR; a.dims[1] = nC; a.dims[2] = rowsTrk; a.dims[3] = perRow; }
@@ -81,6 +82,8 @@ __global__ void __launch_bounds__(256) assoc_sub_kernel(AssocArgs a)
 // ---------------------------------------------------------------------------
 // the sequential state machine, one workgroup
 // ---------------------------------------------------------------------------
+#define MK_HELP_MIN 512
+#define MK_SPIN_LIMIT 4000000   /* bounded spins: a lost partner ends the wait after seconds instead of hanging the GPU */
 struct MkShared {
     u64 bm[MK_MAXN * MK_MAXW];      // zero bitmap, [line][16 words]; row-major during init, column-major afterwards
     short starColOfRow[MK_MAXN];
@@ -95,6 +98,92 @@ struct MkShared {
     int flag[8];
 };
 
+
+// ---- helper workgroups: own 64 consecutive columns each; execute the bulk of step 5 on them -----------------
+// Column ownership is fixed, so a column's elements are only ever touched by one CU (no cross-CU visibility issue for
+// the matrix itself); only the small control block crosses CUs.
+__device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
+{
+    u64* ctl = a.ws.ctl;
+    double* __restrict__ d = a.ws.dist;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x - 1;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int wordsR = (nR + 63) >> 6;
+    const int r = tid;
+    const size_t rclamp = (size_t)min(r, nR - 1);
+    unsigned seen = 0;
+    if (tid == 0) S.flag[3] = 0;
+    __syncthreads();
+    for (;;) {
+        // Wave 0 polls as a whole, on a wave-uniform (scalar) condition: a spin loop confined to one LANE is a divergent
+        // loop, and the structuriser may run the other lanes of that wave (and with them the workgroup barrier below)
+        // ahead of it -- seen on gfx950: the barrier then releases before lane 0 has polled.
+        if (uwave == 0) {
+            int spins = 0; unsigned now;
+            for (;;) {
+                now = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_SEQ));
+                if (now != seen || ++spins > MK_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const int cmdv = __builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_CMD));
+            const int ncuv = __builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_NCU));
+            const int ncrv = __builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_NCR));
+            if (lane == 0) { S.flag[3] = (now == seen); S.flag[4] = (int)now; S.flag[5] = cmdv; S.flag[6] = ncuv; S.flag[7] = ncrv; S.flag[2] = 0; }
+        }
+        __syncthreads();
+        if (S.flag[3]) return;
+        seen = (unsigned)S.flag[4];
+        const int cmd = S.flag[5];
+        if (cmd == 3) return;
+        const int ncu = S.flag[6], ncr = S.flag[7];
+        const u64 cw = ctl_ld(ctl + CTL_COVR + wave);
+        const bool rowcov = (cw >> lane) & 1;
+        // my uncovered columns
+        for (int k = tid; k < ncu; k += MK_THREADS) { const int c = (int)ctl_ld(ctl + CTL_LIST + k); if ((c >> 6) == g) { const int q = atomicAdd(&S.flag[2], 1); S.list[q] = (unsigned short)c; } }
+        __syncthreads();
+        const int nmine = S.flag[2];
+        if (cmd == 1) {
+            u64 best = ~0ull;
+            for (int q = 0; q < nmine; q++) { const double v = d[rclamp + (size_t)nR * S.list[q]]; if (r < nR && !rowcov) { const u64 kk = dkey(v); if (kk < best) best = kk; } }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(best, off); if (o < best) best = o; }
+            if (lane == 0) S.red[wave] = __longlong_as_double((long long)best);
+            __syncthreads();
+            if (tid == 0) { u64 b = ~0ull; for (int w = 0; w < 16; w++) { const u64 o = (u64)__double_as_longlong(S.red[w]); if (o < b) b = o; } ctl_st(ctl + CTL_PARTIAL + g, b); }
+        } else {
+            const double h = __longlong_as_double((long long)ctl_ld(ctl + CTL_H));
+            for (int q = 0; q < nmine; q++) {
+                const int c = S.list[q];
+                const double v = d[rclamp + (size_t)nR * c];
+                bool z = false;
+                if (r < nR) { const double x = rowcov ? (v + h) - h : v - h; d[(size_t)r + (size_t)nR * c] = x; z = fabs(x) < DBL_EPSILON; }   // :355-364
+                const u64 bal = __ballot(z);
+                if (lane == 0) ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + wave, bal);
+            }
+            // covered rows in my COVERED columns: += h (:355-358)
+            if (wave == 0) {
+                const int c = g * 64 + lane;
+                const u64 ccw = ctl_ld(ctl + CTL_COVC + g);
+                const bool act = c < nC && ((ccw >> lane) & 1);
+                for (int i = 0; i < ncr; i++) {
+                    const int rr = (int)ctl_ld(ctl + CTL_CROWS + i);
+                    bool z = false;
+                    if (act) { const double x = d[(size_t)rr + (size_t)nR * c] + h; d[(size_t)rr + (size_t)nR * c] = x; z = fabs(x) < DBL_EPSILON; }
+                    const u64 bal = __ballot(z);
+                    if (lane == 0) ctl_st(ctl + CTL_COVBITS + (size_t)i * MK_MAXW + g, bal);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctl + CTL_ARRIVE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)wordsR;
+    }
+}
+
+// HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
+// HELP = true : launched with 1 + MK_HELPERS workgroups; workgroups 1.. run mk_helper_loop.
+template <bool HELP>
 __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char mk_raw[];
@@ -105,14 +194,19 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     int* stat = a.ws.status;
     const long long t_begin = wall_clock64();
     const long long c_begin = clock64();
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int nhelp = HELP ? (int)gridDim.x - 1 : 0;                   // 0: everything in this workgroup
+    if (HELP && blockIdx.x > 0) { if (nR > 0 && nC > 0) mk_helper_loop(a, S, nR, nC); return; }
     if (nR <= 0 || nC <= 0) { if (tid == 0) *a.ws.cost = 0.0; for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
+    u64* ctl = a.ws.ctl; unsigned myseq = 0; u64 arrived = 0;
     const int minDim = perRow ? nR : nC;
     int n_s4 = 0, n_s5 = 0, n_sw = 0, n_cov5 = 0, ncu0 = 0; long long t_s3 = 0, t_s5 = 0;     // wave-0 / thread-0 statistics
 
     for (int i = tid; i < MK_MAXN; i += MK_THREADS) { S.starColOfRow[i] = -1; S.starRowOfCol[i] = -1; S.primeColOfRow[i] = -1; }
     if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
+    if (tid == 0) S.flag[7] = 0;
     if (tid < 2 * MK_MAXW) { S.taken32[tid] = 0; S.cont32[tid] = 0; }
     // ---- steps 1 + 2a: initial stars (hungarian.cpp:93-101 / :128-139) ----
     // lines (rows if perRow, else columns) are scanned in order; each takes its first zero whose cross line
@@ -299,7 +393,74 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         if (action == 3) { done = true; break; }
         // ================= step 5 (:337-368): one row per thread =================
         n_s5++;
-        {
+        if (HELP && nhelp > 0) {
+            // ---- step 5 on the helper workgroups: publish covers + column list, collect the minimum, publish h, merge bitmaps ----
+            const int ncu = S.flag[1];
+            if (n_s5 == 1) ncu0 = ncu;
+            int ncr = 0;
+            for (int w = 0; w < wordsR; w++) ncr += __popcll(S.covR[w]);
+            for (int k = tid; k < ncu; k += MK_THREADS) ctl_st(ctl + CTL_LIST + k, (u64)S.list[k]);
+            if (tid < MK_MAXW) { ctl_st(ctl + CTL_COVR + tid, S.covR[tid]); ctl_st(ctl + CTL_COVC + tid, S.covC[tid]); }
+            if (wave == 0) {   // covered rows, ascending
+                const int n = wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);
+                for (int i = lane; i < n; i += 64) ctl_st(ctl + CTL_CROWS + i, (u64)S.clist[i]);
+            }
+            if (tid == 0) { ctl_st(ctl + CTL_NCU, (u64)ncu); ctl_st(ctl + CTL_NCR, (u64)ncr); ctl_st(ctl + CTL_CMD, 1ull); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++myseq; arrived += nhelp;
+            if (uwave == 0) {                                          // wave-uniform spin (see mk_helper_loop)
+                if (lane == 0) ctl_st(ctl + CTL_SEQ, (u64)myseq);
+                int spins = 0;
+                for (;;) {
+                    const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_ARRIVE));
+                    if (got >= (unsigned)arrived) break;
+                    if (++spins > MK_SPIN_LIMIT) { if (lane == 0) { stat[15] = 1; S.flag[7] = 1; } break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (S.flag[7]) break;                                      // helpers lost: give up (status[15] says where)
+            u64 hk = (tid < nhelp) ? ctl_ld(ctl + CTL_PARTIAL + tid) : ~0ull;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(hk, off); if (o < hk) hk = o; }
+            if (tid == 0) { ctl_st(ctl + CTL_H, (u64)__double_as_longlong(dunkey(hk))); ctl_st(ctl + CTL_CMD, 2ull); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++myseq; arrived += nhelp;
+            if (uwave == 0) {                                          // wave-uniform spin (see mk_helper_loop)
+                if (lane == 0) ctl_st(ctl + CTL_SEQ, (u64)myseq);
+                int spins = 0;
+                for (;;) {
+                    const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_ARRIVE));
+                    if (got >= (unsigned)arrived) break;
+                    if (++spins > MK_SPIN_LIMIT) { if (lane == 0) { stat[15] = 2; S.flag[7] = 1; } break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (S.flag[7]) break;
+            // merge: uncovered columns get their complete new words; covered columns only the covered rows' bits
+            for (int i = tid; i < ncu * wordsR; i += MK_THREADS) { const int k = i / wordsR, w = i - k * wordsR; const int c = S.list[k]; S.bm[c * MK_MAXW + w] = ctl_ld(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + w); }
+            if (ncr > 0 && tid < nC && ((S.covC[wave] >> lane) & 1)) {
+                for (int i = 0; i < ncr; i++) {
+                    const int rr = S.clist[i];
+                    const bool z = (ctl_ld(ctl + CTL_COVBITS + (size_t)i * MK_MAXW + wave) >> lane) & 1;
+                    u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
+                    wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                }
+            }
+            __syncthreads();
+            {   // rebuild hz for the uncovered columns (their entries just changed)
+                const bool unc = tid < nC && !((S.covC[wave] >> lane) & 1);
+                bool has = false;
+                if (unc) for (int w = 0; w < wordsR; w++) has |= S.bm[tid * MK_MAXW + w] != 0;
+                const u64 bal = __ballot(has);
+                if (lane == 0) S.hz[wave] = (S.hz[wave] & S.covC[wave]) | bal;
+            }
+            __syncthreads();
+            if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
+        } else {
             const int ncu = S.flag[1];
             if (n_s5 == 1) ncu0 = ncu;
             const int r = tid;
@@ -378,6 +539,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         if (++guard > 4 * MK_MAXN * MK_MAXN) break;                    // cannot happen for finite costs
     }
     __syncthreads();
+    if (HELP && nhelp > 0 && tid == 0) { ctl_st(ctl + CTL_CMD, 3ull); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ctl_st(ctl + CTL_SEQ, (u64)(++myseq)); }
     if (tid == 0) {
         stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0;
         stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[10] = 0; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
@@ -442,10 +604,20 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     if (use_lazy) return launch_munkres_lazy(a, want_cost, s);
     static bool attr_set = false;
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(munkres_kernel, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost);
+    // Step-5 helper workgroups (16 more CUs stream the matrix; two cross-CU hand-offs per step 5) pay off only when
+    // step 5 moves a lot of data: dense hard problems beyond ~512 lines.  MOT_MUNKRES_HELPERS=1 forces them on for
+    // every problem above 256 lines, =0 off; default: above MK_HELP_MIN lines.
+    static int helpers = -1;
+    if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
+    const int lines = maxR > maxC ? maxR : maxC;
+    const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN));
+    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost);
+    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost);
     return hipGetLastError();
 }

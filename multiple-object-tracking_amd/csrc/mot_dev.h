@@ -79,7 +79,8 @@ struct AssocWs {
     unsigned long long* linemin; // [1024] order-preserving keys of the row / column minima
     int* assignment;          // [1024]
     double* cost;             // [1]
-    int* status;              // [8]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow
+    int* status;              // [16]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow, timers
+    unsigned long long* ctl;  // control block + result buffers of the step-5 helper workgroups (MK_CTL_WORDS u64)
 };
 
 // host-side launchers implemented in the .hip files

@@ -398,11 +398,7 @@ def test_dropin_per_object_interface(mot):
         assert np.array_equal(a, gm[f"m{i}_a"]) and cost.value == float(gm[f"m{i}_c"])
 
 
-def test_munkres_lazy_variant_subprocess():
-    """the lazy-column Munkres kernel (MOT_MUNKRES_LAZY=1, csrc/munkres_lazy.hip) must give the same bit-exact
-    assignments; the switch is read once per process, so it runs in a child process."""
-    import subprocess, sys
-    code = r'''
+_VARIANT_CODE = r'''
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import mot_amd, orc
@@ -420,8 +416,37 @@ for n in (64, 300, 1024):
     at, ad, cost = c.assign(trk, det)
     ra, rc = orc.assignment_optimal(lib, orc.cost_matrix(lib, trk, det), n, n)
     assert np.array_equal(ad, ra) and cost == rc, n
-print("LAZY_OK", c.assoc_stats()[:3].tolist())
+lazy = os.environ.get("MOT_MUNKRES_LAZY") == "1"
+for n in ((257,) if lazy else (257, 520, 1024)):            # dense uniform costs: hundreds of step-5 passes with hundreds of uncovered columns
+    d = rng.uniform(0, 1, size=n * n)
+    a, cost = c.assignment_optimal(d, n, n)
+    ra, rc = orc.assignment_optimal(lib, d, n, n)
+    assert np.array_equal(a, ra) and cost == rc, ("uniform", n)
+    assert lazy or c.assoc_stats()[15] == 0, ("helper protocol timed out", n)
+d = rng.uniform(0, 1, size=700 * 400)  # rectangular, both orientations
+for nr, nc in ((700, 400), (400, 700)):
+    a, cost = c.assignment_optimal(d, nr, nc)
+    ra, rc = orc.assignment_optimal(lib, d, nr, nc)
+    assert np.array_equal(a, ra) and cost == rc, ("rect", nr, nc)
+print("VARIANT_OK", c.assoc_stats()[:3].tolist())
 '''
-    env = dict(os.environ, MOT_MUNKRES_LAZY="1")
-    out = subprocess.run([sys.executable, "-c", code], cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert "LAZY_OK" in out.stdout, out.stdout + out.stderr
+
+
+def _run_variant(env_extra):
+    import subprocess, sys
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", _VARIANT_CODE], cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert "VARIANT_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_munkres_lazy_variant_subprocess():
+    """the lazy-column Munkres kernel (MOT_MUNKRES_LAZY=1, csrc/munkres_lazy.hip) must give the same bit-exact
+    assignments; the switch is read once per process, so it runs in a child process."""
+    _run_variant({"MOT_MUNKRES_LAZY": "1"})
+
+
+@pytest.mark.parametrize("helpers", ["0", "1"])
+def test_munkres_helper_workgroups_subprocess(helpers):
+    """step-5 helper workgroups (munkres_kernel<true>, 1 + 16 workgroups, cross-CU control block) forced on for every
+    problem above 256 lines ("1") and forced off ("0"): identical assignments and cost either way."""
+    _run_variant({"MOT_MUNKRES_HELPERS": helpers})
