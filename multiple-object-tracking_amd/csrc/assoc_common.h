@@ -11,23 +11,30 @@ namespace assoc {
 
 typedef unsigned long long u64;
 
-// ---- step-5 helper protocol (munkres_kernel launched with 1 + MK_HELPERS workgroups) -------------------------
-// control block, u64 words; every access is a relaxed agent-scope atomic (sc1), flags follow G16 of the HIP guide
+// ---- step-5 helper protocol (munkres_kernel<true> launched with 1 + MK_HELPERS workgroups) --------------------
+// Control block of u64 words; every access is a relaxed agent-scope atomic (sc1 load / store) and flags follow G16 of
+// the HIP guide (payload stores drained with s_waitcnt vmcnt(0) before the flag store of the same wave).  Words that
+// are polled sit on 128-byte lines of their own.
+//   SEQ       number of the step 5 whose cover masks are published (0xFFFFFFFF: the controller is done)
+//   H0, H0+1  step k's h lands in slot k & 1 (MK_HSENT = not yet); the controller re-arms the other slot beforehand
+//   ARRIVE    one add per helper per phase (monotonic across the launch)
+//   COVR/COVC row / column cover masks of the current step 5
+//   PARTIAL   [step & 1][g]: helper g's minimum key over (uncovered rows) x (its uncovered columns); MK_HSENT = not
+//             yet, MK_KEY_NONE = no such element; the controller re-arms the other parity's 16 words beforehand
+//   BMOUT     [column][row word]: new zero bits of the uncovered columns;  COVBITS [i-th covered row][column word]
 #define MK_HELPERS 16
 #define CTL_SEQ 0
-#define CTL_CMD 1
-#define CTL_ARRIVE 2
-#define CTL_NCU 3
-#define CTL_H 4
-#define CTL_NCR 5
-#define CTL_COVR 8
-#define CTL_COVC 24
-#define CTL_PARTIAL 40
-#define CTL_LIST 64      /* 1024 entries, one u64 each */
-#define CTL_CROWS 1088   /* 1024 entries */
-#define CTL_COVBITS 2112 /* [1024 rows][16 words] */
-#define CTL_BMOUT (2112 + 16384) /* [1024 cols][16 words] */
-#define MK_CTL_WORDS (2112 + 2 * 16384)
+#define CTL_H0 16
+#define CTL_ARRIVE 32
+#define CTL_COVR 48
+#define CTL_COVC 64
+#define CTL_PARTIAL 80                 /* 2 x 16 words */
+#define CTL_COVBITS 128                /* [1024 rows][16 words] */
+#define CTL_BMOUT (128 + 16384)        /* [1024 cols][16 words] */
+#define MK_CTL_WORDS (128 + 2 * 16384)
+#define MK_SEQ_EXIT 0xFFFFFFFFu
+#define MK_HSENT 0xFFFFFFFFFFFFFFFFull /* a NaN pattern: h is always finite; as a key: above every cost's key */
+#define MK_KEY_NONE 0xFFFFFFFFFFFFFFFEull
 __device__ __forceinline__ u64 ctl_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

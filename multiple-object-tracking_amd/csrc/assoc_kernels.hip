@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) assoc_min_kernel(AssocArgs a)
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const int r = blockIdx.x * 64 + (threadIdx.x & 63);
     const int c0 = blockIdx.y * 64, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.ws.ctl) { a.ws.ctl[CTL_SEQ] = 0; a.ws.ctl[CTL_ARRIVE] = 0; a.ws.ctl[CTL_CMD] = 0; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.ws.ctl) { a.ws.ctl[CTL_SEQ] = 0; a.ws.ctl[CTL_ARRIVE] = 0; a.ws.ctl[CTL_H0] = MK_HSENT; a.ws.ctl[CTL_H0 + 1] = MK_HSENT; for (int i = 0; i < 2 * MK_HELPERS; i++) a.ws.ctl[CTL_PARTIAL + i] = MK_HSENT; }
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
     const bool perRow = nR <= nC;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.dims[0] = nR; a.dims[1] = nC; a.dims[2] = rowsTrk; a.dims[3] = perRow; }
@@ -95,13 +95,20 @@ struct MkShared {
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW];
     unsigned int taken32[2 * MK_MAXW], cont32[2 * MK_MAXW];
     double red[MK_THREADS / 64];
+    u64 hbits;
     int flag[8];
 };
 
 
 // ---- helper workgroups: own 64 consecutive columns each; execute the bulk of step 5 on them -----------------
 // Column ownership is fixed, so a column's elements are only ever touched by one CU (no cross-CU visibility issue for
-// the matrix itself); only the small control block crosses CUs.
+// the matrix itself); only the small control block crosses CUs.  One iteration = one step 5:
+//   wait SEQ -> read the cover masks -> minimum over my uncovered columns -> PARTIAL, arrive
+//   wait H   -> apply (:355-364) to my uncovered columns (the first 8 are still in registers) and +h to the covered
+//               rows of my covered columns -> new zero bits to BMOUT / COVBITS, arrive
+// All spins are executed by wave 0 as a whole on a wave-uniform (scalar) condition and are bounded: a spin loop
+// confined to one LANE is a divergent loop, and the structuriser may run the other lanes of that wave (and with them
+// the workgroup barrier behind the spin) ahead of it -- seen on gfx950: the barrier released before lane 0 had polled.
 __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
 {
     u64* ctl = a.ws.ctl;
@@ -111,73 +118,125 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
     const int wordsR = (nR + 63) >> 6;
     const int r = tid;
     const size_t rclamp = (size_t)min(r, nR - 1);
-    unsigned seen = 0;
-    if (tid == 0) S.flag[3] = 0;
-    __syncthreads();
+    const int cbase = g * 64;
+    const int nvalid = min(max(nC - cbase, 0), 64);
+    const u64 validC = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1);
+    unsigned step = 0;
     for (;;) {
-        // Wave 0 polls as a whole, on a wave-uniform (scalar) condition: a spin loop confined to one LANE is a divergent
-        // loop, and the structuriser may run the other lanes of that wave (and with them the workgroup barrier below)
-        // ahead of it -- seen on gfx950: the barrier then releases before lane 0 has polled.
         if (uwave == 0) {
             int spins = 0; unsigned now;
             for (;;) {
                 now = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_SEQ));
-                if (now != seen || ++spins > MK_SPIN_LIMIT) break;
-                __builtin_amdgcn_s_sleep(2);
+                if (now != step || ++spins > MK_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
             }
-            const int cmdv = __builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_CMD));
-            const int ncuv = __builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_NCU));
-            const int ncrv = __builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_NCR));
-            if (lane == 0) { S.flag[3] = (now == seen); S.flag[4] = (int)now; S.flag[5] = cmdv; S.flag[6] = ncuv; S.flag[7] = ncrv; S.flag[2] = 0; }
+            const u64 cv = (lane < 2 * MK_MAXW) ? ctl_ld(ctl + CTL_COVR + lane) : 0;      // COVR and COVC are adjacent
+            if (lane < MK_MAXW) S.covR[lane] = cv; else if (lane < 2 * MK_MAXW) S.covC[lane - MK_MAXW] = cv;
+            const u64 um = ~readlane64(cv, MK_MAXW + g) & validC;                          // my uncovered columns
+            if ((um >> lane) & 1) S.list[__popcll(um & ((1ull << lane) - 1))] = (unsigned short)(cbase + lane);
+            if (lane == 0) { S.flag[3] = (now == step); S.flag[4] = (int)now; S.flag[2] = __popcll(um); }
+        }
+        __syncthreads();
+        if (S.flag[3] || (unsigned)S.flag[4] == MK_SEQ_EXIT) return;   // the controller went away / is done
+        step = (unsigned)S.flag[4];
+        const int nmine = S.flag[2];
+        const bool rowcov = (S.covR[wave] >> lane) & 1;
+        const bool mine = r < nR && !rowcov;
+        // ---- phase A: minimum key over (uncovered rows) x (my uncovered columns); 8 loads in flight per thread ----
+        double v[8];
+        u64 best = ~0ull;
+        if (nmine > 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = d[rclamp + (size_t)nR * S.list[min(k, nmine - 1)]];
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (mine && k < nmine) { const u64 kk = dkey(v[k]); if (kk < best) best = kk; }
+            for (int q0 = 8; q0 < nmine; q0 += 8) {
+                double w[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * S.list[min(q0 + k, nmine - 1)]];
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (mine && q0 + k < nmine) { const u64 kk = dkey(w[k]); if (kk < best) best = kk; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(best, off); if (o < best) best = o; }
+        if (lane == 0) S.red[wave] = __longlong_as_double((long long)best);
+        __syncthreads();
+        if (uwave == 0) {
+            u64 b = (lane < MK_THREADS / 64) ? (u64)__double_as_longlong(S.red[lane]) : ~0ull;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { const u64 o = __shfl_xor(b, off); if (o < b) b = o; }
+            if (lane == 0) ctl_st(ctl + CTL_PARTIAL + (step & 1) * MK_HELPERS + g, b < MK_KEY_NONE ? b : MK_KEY_NONE);   // the word is its own flag
+            // ---- wait for h (slot step & 1) ----
+            int spins = 0; u64 hb;
+            for (;;) {
+                hb = ctl_ld(ctl + CTL_H0 + (step & 1));
+                hb = readlane64(hb, 0);
+                if (hb != MK_HSENT || ++spins > MK_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) { S.flag[3] = (hb == MK_HSENT); S.hbits = hb; }
         }
         __syncthreads();
         if (S.flag[3]) return;
-        seen = (unsigned)S.flag[4];
-        const int cmd = S.flag[5];
-        if (cmd == 3) return;
-        const int ncu = S.flag[6], ncr = S.flag[7];
-        const u64 cw = ctl_ld(ctl + CTL_COVR + wave);
-        const bool rowcov = (cw >> lane) & 1;
-        // my uncovered columns
-        for (int k = tid; k < ncu; k += MK_THREADS) { const int c = (int)ctl_ld(ctl + CTL_LIST + k); if ((c >> 6) == g) { const int q = atomicAdd(&S.flag[2], 1); S.list[q] = (unsigned short)c; } }
-        __syncthreads();
-        const int nmine = S.flag[2];
-        if (cmd == 1) {
-            u64 best = ~0ull;
-            for (int q = 0; q < nmine; q++) { const double v = d[rclamp + (size_t)nR * S.list[q]]; if (r < nR && !rowcov) { const u64 kk = dkey(v); if (kk < best) best = kk; } }
+        const double h = __longlong_as_double((long long)S.hbits);
+        // ---- phase B (:355-364) on my uncovered columns ----
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(best, off); if (o < best) best = o; }
-            if (lane == 0) S.red[wave] = __longlong_as_double((long long)best);
-            __syncthreads();
-            if (tid == 0) { u64 b = ~0ull; for (int w = 0; w < 16; w++) { const u64 o = (u64)__double_as_longlong(S.red[w]); if (o < b) b = o; } ctl_st(ctl + CTL_PARTIAL + g, b); }
-        } else {
-            const double h = __longlong_as_double((long long)ctl_ld(ctl + CTL_H));
-            for (int q = 0; q < nmine; q++) {
-                const int c = S.list[q];
-                const double v = d[rclamp + (size_t)nR * c];
-                bool z = false;
-                if (r < nR) { const double x = rowcov ? (v + h) - h : v - h; d[(size_t)r + (size_t)nR * c] = x; z = fabs(x) < DBL_EPSILON; }   // :355-364
-                const u64 bal = __ballot(z);
+        for (int k = 0; k < 8; k++) {
+            if (k < nmine) {                                            // uniform
+                const int c = S.list[k];
+                const double x = rowcov ? (v[k] + h) - h : v[k] - h;
+                if (r < nR) d[(size_t)r + (size_t)nR * c] = x;
+                const u64 bal = __ballot(r < nR && fabs(x) < DBL_EPSILON);
                 if (lane == 0) ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + wave, bal);
             }
-            // covered rows in my COVERED columns: += h (:355-358)
-            if (wave == 0) {
-                const int c = g * 64 + lane;
-                const u64 ccw = ctl_ld(ctl + CTL_COVC + g);
-                const bool act = c < nC && ((ccw >> lane) & 1);
-                for (int i = 0; i < ncr; i++) {
-                    const int rr = (int)ctl_ld(ctl + CTL_CROWS + i);
-                    bool z = false;
-                    if (act) { const double x = d[(size_t)rr + (size_t)nR * c] + h; d[(size_t)rr + (size_t)nR * c] = x; z = fabs(x) < DBL_EPSILON; }
-                    const u64 bal = __ballot(z);
-                    if (lane == 0) ctl_st(ctl + CTL_COVBITS + (size_t)i * MK_MAXW + g, bal);
+        }
+        for (int q0 = 8; q0 < nmine; q0 += 8) {
+            double w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * S.list[min(q0 + k, nmine - 1)]];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (q0 + k < nmine) {
+                    const int c = S.list[q0 + k];
+                    const double x = rowcov ? (w[k] + h) - h : w[k] - h;
+                    if (r < nR) d[(size_t)r + (size_t)nR * c] = x;
+                    const u64 bal = __ballot(r < nR && fabs(x) < DBL_EPSILON);
+                    if (lane == 0) ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + wave, bal);
+                }
+            }
+        }
+        // ---- covered rows of my COVERED columns: += h (:355-358); wave 0, lane = column, 4 rows in flight ----
+        if (uwave == 0) {
+            const int c = cbase + lane;
+            const bool act = c < nC && ((S.covC[g] >> lane) & 1);
+            const size_t coff = (size_t)nR * min(c, nC - 1);
+            int i = 0;                                                  // index among the covered rows, ascending
+            for (int w = 0; w < wordsR; w++) {
+                u64 rw = readlane64(S.covR[w], 0);
+                while (rw) {
+                    int rr[4]; int nq = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { rr[q] = rw ? w * 64 + __ffsll((long long)rw) - 1 : rr[0]; if (rw) { nq++; rw &= rw - 1; } }
+                    double x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) x[q] = d[(size_t)rr[q] + coff];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (q < nq) {
+                            x[q] += h;
+                            if (act) d[(size_t)rr[q] + coff] = x[q];
+                            const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
+                            if (lane == 0) ctl_st(ctl + CTL_COVBITS + (size_t)(i + q) * MK_MAXW + g, bal);
+                        }
+                    }
+                    i += nq;
                 }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctl + CTL_ARRIVE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)wordsR;
     }
 }
 
@@ -202,7 +261,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     const bool perRow = nR <= nC;
     u64* ctl = a.ws.ctl; unsigned myseq = 0; u64 arrived = 0;
     const int minDim = perRow ? nR : nC;
-    int n_s4 = 0, n_s5 = 0, n_sw = 0, n_cov5 = 0, ncu0 = 0; long long t_s3 = 0, t_s5 = 0;     // wave-0 / thread-0 statistics
+    int n_s4 = 0, n_s5 = 0, n_sw = 0, n_cov5 = 0, ncu0 = 0; long long t_s3 = 0, t_s5 = 0, t_h0 = 0, t_h1 = 0, t_h2 = 0, t_h3 = 0;     // wave-0 / thread-0 statistics
 
     for (int i = tid; i < MK_MAXN; i += MK_THREADS) { S.starColOfRow[i] = -1; S.starRowOfCol[i] = -1; S.primeColOfRow[i] = -1; }
     if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
@@ -394,60 +453,65 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         // ================= step 5 (:337-368): one row per thread =================
         n_s5++;
         if (HELP && nhelp > 0) {
-            // ---- step 5 on the helper workgroups: publish covers + column list, collect the minimum, publish h, merge bitmaps ----
+            // ---- step 5 on the helper workgroups: wave 0 publishes the cover masks, collects the minimum, publishes h
+            // and waits for the new zero bits; the other waves wait at the barrier in front of the merge ----
             const int ncu = S.flag[1];
             if (n_s5 == 1) ncu0 = ncu;
-            int ncr = 0;
-            for (int w = 0; w < wordsR; w++) ncr += __popcll(S.covR[w]);
-            for (int k = tid; k < ncu; k += MK_THREADS) ctl_st(ctl + CTL_LIST + k, (u64)S.list[k]);
-            if (tid < MK_MAXW) { ctl_st(ctl + CTL_COVR + tid, S.covR[tid]); ctl_st(ctl + CTL_COVC + tid, S.covC[tid]); }
-            if (wave == 0) {   // covered rows, ascending
-                const int n = wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);
-                for (int i = lane; i < n; i += 64) ctl_st(ctl + CTL_CROWS + i, (u64)S.clist[i]);
-            }
-            if (tid == 0) { ctl_st(ctl + CTL_NCU, (u64)ncu); ctl_st(ctl + CTL_NCR, (u64)ncr); ctl_st(ctl + CTL_CMD, 1ull); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            ++myseq; arrived += nhelp;
-            if (uwave == 0) {                                          // wave-uniform spin (see mk_helper_loop)
+            ++myseq;
+            if (uwave == 0) {
+                if (lane < MK_MAXW) ctl_st(ctl + CTL_COVR + lane, S.covR[lane]);
+                else if (lane < 2 * MK_MAXW) ctl_st(ctl + CTL_COVC + lane - MK_MAXW, S.covC[lane - MK_MAXW]);
+                else if (lane < 2 * MK_MAXW + MK_HELPERS) ctl_st(ctl + CTL_PARTIAL + ((myseq + 1) & 1) * MK_HELPERS + lane - 2 * MK_MAXW, MK_HSENT);   // re-arm the
+                else if (lane == 2 * MK_MAXW + MK_HELPERS) ctl_st(ctl + CTL_H0 + ((myseq + 1) & 1), MK_HSENT);                                          // NEXT step's slots
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) ctl_st(ctl + CTL_SEQ, (u64)myseq);
-                int spins = 0;
-                for (;;) {
-                    const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_ARRIVE));
-                    if (got >= (unsigned)arrived) break;
-                    if (++spins > MK_SPIN_LIMIT) { if (lane == 0) { stat[15] = 1; S.flag[7] = 1; } break; }
+                const long long tq0 = wall_clock64(); t_h0 += tq0 - t_b;
+                // covered rows, ascending (for the merge); overlaps the helpers' phase A
+                const int ncr = wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);
+                if (lane == 0) S.flag[2] = ncr;
+                int spins = 0; bool lost = false;
+                u64 hk;
+                for (;;) {                                              // every helper's partial minimum is its own arrival flag
+                    hk = (lane < nhelp) ? ctl_ld(ctl + CTL_PARTIAL + (myseq & 1) * MK_HELPERS + lane) : 0;
+                    if (!__ballot(hk == MK_HSENT)) break;
+                    if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-            }
-            __syncthreads();
-            if (S.flag[7]) break;                                      // helpers lost: give up (status[15] says where)
-            u64 hk = (tid < nhelp) ? ctl_ld(ctl + CTL_PARTIAL + tid) : ~0ull;
+                if (lane >= nhelp) hk = ~0ull;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(hk, off); if (o < hk) hk = o; }
-            if (tid == 0) { ctl_st(ctl + CTL_H, (u64)__double_as_longlong(dunkey(hk))); ctl_st(ctl + CTL_CMD, 2ull); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            ++myseq; arrived += nhelp;
-            if (uwave == 0) {                                          // wave-uniform spin (see mk_helper_loop)
-                if (lane == 0) ctl_st(ctl + CTL_SEQ, (u64)myseq);
-                int spins = 0;
-                for (;;) {
+                for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(hk, off); if (o < hk) hk = o; }
+                if (lane == 0) ctl_st(ctl + CTL_H0 + (myseq & 1), (u64)__double_as_longlong(dunkey(hk)));
+                const long long tq1 = wall_clock64(); t_h1 += tq1 - tq0;
+                arrived += nhelp;
+                for (spins = 0; !lost;) {
                     const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_ARRIVE));
                     if (got >= (unsigned)arrived) break;
-                    if (++spins > MK_SPIN_LIMIT) { if (lane == 0) { stat[15] = 2; S.flag[7] = 1; } break; }
+                    if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (lost && lane == 0) { stat[15] = 1; S.flag[7] = 1; }
+                t_h2 += wall_clock64() - tq1;
             }
             __syncthreads();
-            if (S.flag[7]) break;
+            if (S.flag[7]) break;                                      // helpers lost: give up (status[15] != 0)
+            const long long tq2 = wall_clock64();
+            const int ncr = S.flag[2];
             // merge: uncovered columns get their complete new words; covered columns only the covered rows' bits
             for (int i = tid; i < ncu * wordsR; i += MK_THREADS) { const int k = i / wordsR, w = i - k * wordsR; const int c = S.list[k]; S.bm[c * MK_MAXW + w] = ctl_ld(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + w); }
             if (ncr > 0 && tid < nC && ((S.covC[wave] >> lane) & 1)) {
-                for (int i = 0; i < ncr; i++) {
-                    const int rr = S.clist[i];
-                    const bool z = (ctl_ld(ctl + CTL_COVBITS + (size_t)i * MK_MAXW + wave) >> lane) & 1;
-                    u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
-                    wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                for (int i0 = 0; i0 < ncr; i0 += 4) {                   // 4 loads in flight
+                    u64 cb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cb[q] = ctl_ld(ctl + CTL_COVBITS + (size_t)min(i0 + q, ncr - 1) * MK_MAXW + wave);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (i0 + q < ncr) {
+                            const int rr = S.clist[i0 + q];
+                            const bool z = (cb[q] >> lane) & 1;
+                            u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
+                            wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -460,6 +524,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             }
             __syncthreads();
             if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
+            t_h3 += wall_clock64() - tq2;
         } else {
             const int ncu = S.flag[1];
             if (n_s5 == 1) ncu0 = ncu;
@@ -539,9 +604,10 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         if (++guard > 4 * MK_MAXN * MK_MAXN) break;                    // cannot happen for finite costs
     }
     __syncthreads();
-    if (HELP && nhelp > 0 && tid == 0) { ctl_st(ctl + CTL_CMD, 3ull); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ctl_st(ctl + CTL_SEQ, (u64)(++myseq)); }
+    if (HELP && nhelp > 0 && tid == 0) ctl_st(ctl + CTL_SEQ, (u64)MK_SEQ_EXIT);
     if (tid == 0) {
         stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0;
+        if (HELP) { stat[4] = (int)t_h0; stat[5] = (int)t_h1; stat[6] = (int)t_h2; stat[7] = (int)t_h3; }
         stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[10] = 0; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
         stat[13] = (int)((clock64() - c_begin) * 100 / max((long long)1, wall_clock64() - t_begin));   // shader MHz during this launch
     }
