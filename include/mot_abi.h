@@ -170,8 +170,11 @@ int mot_get_pos(mot_ctx* ctx, int id, bbox_t* pos);
 /* debug: enable / read the per-phase time stamps (100 MHz ticks) of workgroup 0 of the device-loop KCF kernels:
  * [0] start [1] crop [2] gradient [3] histogram [4] norm [5] channels [6] DFT [7] end */
 int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long long* update8);
-/* counters of the most recent Munkres launch: [0] step-4 augmentations [1] step-5 updates [2] step-3 sweeps,
- * [4..7] nRows nCols rowsAreTrackers perRow, [8..12] device time in 10 ns ticks: init, step 3, step 4/2a, step 5, total */
+/* counters of the most recent Munkres launch: [0] step-4 augmentations [1] step-5 updates [2] step-3 sweeps
+ * [3] step-5 passes with covered rows; [4..7] step-5 split in 10 ns ticks (helper workgroups: publish, wait for the
+ * minimum, wait for the update, merge; one workgroup: pass 1, reduce, uncovered rows, covered rows); [8..12] device time
+ * in 10 ns ticks: init, step 3 + 4, -, step 5, total; [13] shader MHz; [14] uncovered columns at the first step 5;
+ * [15] 0, or which helper hand-off timed out */
 int mot_get_assoc_stats(mot_ctx* ctx, int* out16);
 /* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
 int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);

@@ -147,13 +147,13 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
         u64 best = ~0ull;
         if (nmine > 0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = d[rclamp + (size_t)nR * S.list[min(k, nmine - 1)]];
+            for (int k = 0; k < 8; k++) v[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(k, nmine - 1)])];
 #pragma unroll
             for (int k = 0; k < 8; k++) if (mine && k < nmine) { const u64 kk = dkey(v[k]); if (kk < best) best = kk; }
             for (int q0 = 8; q0 < nmine; q0 += 8) {
                 double w[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * S.list[min(q0 + k, nmine - 1)]];
+                for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(q0 + k, nmine - 1)])];
 #pragma unroll
                 for (int k = 0; k < 8; k++) if (mine && q0 + k < nmine) { const u64 kk = dkey(w[k]); if (kk < best) best = kk; }
             }
@@ -184,7 +184,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (k < nmine) {                                            // uniform
-                const int c = S.list[k];
+                const int c = __builtin_amdgcn_readfirstlane((int)S.list[k]);
                 const double x = rowcov ? (v[k] + h) - h : v[k] - h;
                 if (r < nR) d[(size_t)r + (size_t)nR * c] = x;
                 const u64 bal = __ballot(r < nR && fabs(x) < DBL_EPSILON);
@@ -194,11 +194,11 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
         for (int q0 = 8; q0 < nmine; q0 += 8) {
             double w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * S.list[min(q0 + k, nmine - 1)]];
+            for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(q0 + k, nmine - 1)])];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 if (q0 + k < nmine) {
-                    const int c = S.list[q0 + k];
+                    const int c = __builtin_amdgcn_readfirstlane((int)S.list[q0 + k]);
                     const double x = rowcov ? (w[k] + h) - h : w[k] - h;
                     if (r < nR) d[(size_t)r + (size_t)nR * c] = x;
                     const u64 bal = __ballot(r < nR && fabs(x) < DBL_EPSILON);
@@ -534,31 +534,34 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             double h = DBL_MAX;
             double v[16];
             const size_t rclamp = (size_t)min(r, nR - 1);
+            const long long tp0 = wall_clock64();
             // pass 1: h = min over uncovered rows x uncovered columns; 16 columns per round, all loads in flight at once
             // (unconditional loads with clamped indices: a per-element guard would serialise them)
             for (int k0 = 0; k0 < ncu; k0 += 16) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = d[rclamp + (size_t)nR * S.list[min(k0 + k, ncu - 1)]];
+                for (int k = 0; k < 16; k++) v[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(k0 + k, ncu - 1)])];
 #pragma unroll
                 for (int k = 0; k < 16; k++) if (mine && k0 + k < ncu && v[k] < h) h = v[k];
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(h, off); if (o < h) h = o; }
+            const long long tp1 = wall_clock64(); t_h0 += tp1 - tp0;
             if (lane == 0) S.red[wave] = h;
             __syncthreads();
             h = S.red[0];
 #pragma unroll
             for (int w = 1; w < MK_THREADS / 64; w++) { const double o = S.red[w]; if (o < h) h = o; }
+            const long long tp2 = wall_clock64(); t_h1 += tp2 - tp1;
             // (a) uncovered rows x uncovered columns: d -= h; rebuild the uncovered-row bits of the bitmap word
             for (int k0 = 0; k0 < ncu; k0 += 16) {
                 if (ncu > 16) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++) v[k] = d[rclamp + (size_t)nR * S.list[min(k0 + k, ncu - 1)]];
+                    for (int k = 0; k < 16; k++) v[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(k0 + k, ncu - 1)])];
                 }
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     if (k0 + k < ncu) {
-                        const int c = S.list[k0 + k];
+                        const int c = __builtin_amdgcn_readfirstlane((int)S.list[k0 + k]);
                         bool z = false;
                         if (mine) { const double nv = v[k] - h; d[(size_t)r + (size_t)nR * c] = nv; z = fabs(nv) < DBL_EPSILON; }
                         const u64 bal = __ballot(z);
@@ -566,9 +569,11 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                     }
                 }
             }
+            t_h2 += wall_clock64() - tp2;
             // (b) covered rows, every column: d += h, then -= h where the column is uncovered (order of :355-364)
             bool anyCov = false;
             for (int w = 0; w < wordsR; w++) anyCov |= S.covR[w] != 0;
+            const long long tb0 = wall_clock64();
             if (anyCov) {
                 if (tid == 0) n_cov5++;
                 __syncthreads();
@@ -590,6 +595,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 }
             }
             __syncthreads();
+            t_h3 += wall_clock64() - tb0;
             {   // rebuild hz for the uncovered columns (their entries just changed)
                 const bool unc = tid < nC && !((S.covC[wave] >> lane) & 1);
                 bool has = false;
@@ -606,8 +612,9 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     __syncthreads();
     if (HELP && nhelp > 0 && tid == 0) ctl_st(ctl + CTL_SEQ, (u64)MK_SEQ_EXIT);
     if (tid == 0) {
-        stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0;
-        if (HELP) { stat[4] = (int)t_h0; stat[5] = (int)t_h1; stat[6] = (int)t_h2; stat[7] = (int)t_h3; }
+        stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0; 
+        // step-5 split (thread 0, 100 MHz ticks): helpers: publish / wait minimum / wait update / merge;  one workgroup: pass 1 / reduce / (a) / (b)
+        stat[4] = (int)t_h0; stat[5] = (int)t_h1; stat[6] = (int)t_h2; stat[7] = (int)t_h3;
         stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[10] = 0; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
         stat[13] = (int)((clock64() - c_begin) * 100 / max((long long)1, wall_clock64() - t_begin));   // shader MHz during this launch
     }
