@@ -15,26 +15,31 @@ typedef unsigned long long u64;
 // Control block of u64 words; every access is a relaxed agent-scope atomic (sc1 load / store) and flags follow G16 of
 // the HIP guide (payload stores drained with s_waitcnt vmcnt(0) before the flag store of the same wave).  Words that
 // are polled sit on 128-byte lines of their own.
-//   SEQ       number of the step 5 whose cover masks are published (0xFFFFFFFF: the controller is done)
-//   H0, H0+1  step k's h lands in slot k & 1 (MK_HSENT = not yet); the controller re-arms the other slot beforehand
-//   ARRIVE    one add per helper per phase (monotonic across the launch)
-//   COVR/COVC row / column cover masks of the current step 5
+//   COV       64 granules {32 bits, 32-bit tag}: the 16 row and 16 column cover-mask words of the current step 5,
+//             two granules per word; written by ONE store instruction of the controller's wave 0, polled by the 64
+//             lanes of each helper's wave 0.  Tag MK_TAG_EXIT: the controller is done.
+//   EPOCH     tag base: tags are EPOCH + step, unique across launches (the controller advances it when it is done)
 //   PARTIAL   [step & 1][g]: helper g's minimum key over (uncovered rows) x (its uncovered columns); MK_HSENT = not
-//             yet, MK_KEY_NONE = no such element; the controller re-arms the other parity's 16 words beforehand
-//   BMOUT     [column][row word]: new zero bits of the uncovered columns;  COVBITS [i-th covered row][column word]
+//             yet, MK_KEY_NONE = no such element.  Every helper with work in the update phase reads all 16 and takes
+//             h = their minimum; the controller re-arms them when the step's zero bits are in
+//   BMOUT     [column][row word][2]: new zero bits of an uncovered column as two granules; a column's 32 granules are
+//             staged in LDS and written by one store instruction (256 contiguous bytes), not as 32 scalar writes
+//   COVBITS   [column word][i-th covered row][2]: zero bits of (covered row) x (64 covered columns), two granules
+// A granule is an aligned 8-byte word written by ONE store and carrying its own tag, so none of these hand-offs needs
+// a separate flag, an arrival counter or a store drain (guide: R2 granule, "needs no ordering at all"); the re-armed
+// words are drained by the controller one step before they are used again.
 #define MK_HELPERS 16
-#define CTL_SEQ 0
-#define CTL_H0 16
-#define CTL_ARRIVE 32
-#define CTL_COVR 48
-#define CTL_COVC 64
-#define CTL_PARTIAL 80                 /* 2 x 16 words */
-#define CTL_COVBITS 128                /* [1024 rows][16 words] */
-#define CTL_BMOUT (128 + 16384)        /* [1024 cols][16 words] */
-#define MK_CTL_WORDS (128 + 2 * 16384)
-#define MK_SEQ_EXIT 0xFFFFFFFFu
+#define CTL_EPOCH 32
+#define CTL_COV 64                     /* 64 granules */
+#define CTL_PARTIAL 128                /* [2][16] words, each on a 128-byte line of its own (16 writers) */
+#define MK_PARTIAL_STRIDE 16
+#define CTL_COVBITS 1024               /* [16 column words][1024 rows][2]: a helper's granules are contiguous */
+#define CTL_BMOUT (1024 + 2 * 16384)   /* [1024 cols][16 row words][2] */
+#define MK_CTL_WORDS (1024 + 4 * 16384)
+#define MK_TAG_EXIT 0xFFFFFFFFu
 #define MK_HSENT 0xFFFFFFFFFFFFFFFFull /* a NaN pattern: h is always finite; as a key: above every cost's key */
 #define MK_KEY_NONE 0xFFFFFFFFFFFFFFFEull
+static_assert(MK_CTL_WORDS == MOT_ASSOC_CTL_WORDS, "control block size");
 __device__ __forceinline__ u64 ctl_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

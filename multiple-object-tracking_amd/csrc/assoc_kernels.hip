@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) assoc_min_kernel(AssocArgs a)
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const int r = blockIdx.x * 64 + (threadIdx.x & 63);
     const int c0 = blockIdx.y * 64, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.ws.ctl) { a.ws.ctl[CTL_SEQ] = 0; a.ws.ctl[CTL_ARRIVE] = 0; a.ws.ctl[CTL_H0] = MK_HSENT; a.ws.ctl[CTL_H0 + 1] = MK_HSENT; for (int i = 0; i < 2 * MK_HELPERS; i++) a.ws.ctl[CTL_PARTIAL + i] = MK_HSENT; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.ws.ctl) { for (int i = 0; i < 2 * MK_HELPERS; i++) a.ws.ctl[CTL_PARTIAL + i * MK_PARTIAL_STRIDE] = MK_HSENT; for (int i = 0; i < 64; i++) a.ws.ctl[CTL_COV + i] = 0; }
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
     const bool perRow = nR <= nC;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.dims[0] = nR; a.dims[1] = nC; a.dims[2] = rowsTrk; a.dims[3] = perRow; }
@@ -103,9 +103,9 @@ struct MkShared {
 // ---- helper workgroups: own 64 consecutive columns each; execute the bulk of step 5 on them -----------------
 // Column ownership is fixed, so a column's elements are only ever touched by one CU (no cross-CU visibility issue for
 // the matrix itself); only the small control block crosses CUs.  One iteration = one step 5:
-//   wait SEQ -> read the cover masks -> minimum over my uncovered columns -> PARTIAL, arrive
-//   wait H   -> apply (:355-364) to my uncovered columns (the first 8 are still in registers) and +h to the covered
-//               rows of my covered columns -> new zero bits to BMOUT / COVBITS, arrive
+//   poll the cover-mask granules -> minimum over (uncovered rows) x (my uncovered columns) -> PARTIAL[g]
+//   poll h -> apply (:355-364) to my uncovered columns and +h to (covered rows) x (my covered columns); every value
+//             needed is already in registers (loaded before the wait) -> ballots of the zero test as tagged granules
 // All spins are executed by wave 0 as a whole on a wave-uniform (scalar) condition and are bounded: a spin loop
 // confined to one LANE is a divergent loop, and the structuriser may run the other lanes of that wave (and with them
 // the workgroup barrier behind the spin) ahead of it -- seen on gfx950: the barrier released before lane 0 had polled.
@@ -121,33 +121,55 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
     const int cbase = g * 64;
     const int nvalid = min(max(nC - cbase, 0), 64);
     const u64 validC = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1);
+    const size_t coff = (size_t)nR * min(cbase + lane, nC - 1);        // covered-rows part: lane = column
     unsigned step = 0;
+    const unsigned epoch = (unsigned)ctl_ld(ctl + CTL_EPOCH);          // written by the previous launch's controller
     for (;;) {
+        ++step;
+        const unsigned tag = epoch + step;
         if (uwave == 0) {
-            int spins = 0; unsigned now;
+            int spins = 0; u64 gv; int state;                           // 0 published, 1 exit, 2 timed out
             for (;;) {
-                now = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_SEQ));
-                if (now != step || ++spins > MK_SPIN_LIMIT) break;
+                gv = ctl_ld(ctl + CTL_COV + lane);
+                const unsigned tg = (unsigned)(gv >> 32);
+                if (!__ballot(tg != tag)) { state = 0; break; }
+                if (__ballot(tg == MK_TAG_EXIT && tag != MK_TAG_EXIT) == ~0ull) { state = 1; break; }
+                if (++spins > MK_SPIN_LIMIT) { state = 2; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            const u64 cv = (lane < 2 * MK_MAXW) ? ctl_ld(ctl + CTL_COVR + lane) : 0;      // COVR and COVC are adjacent
+            const u64 lo = (u64)__shfl((unsigned)gv, (lane & 31) * 2) , hi = (u64)__shfl((unsigned)gv, (lane & 31) * 2 + 1);
+            const u64 cv = lo | (hi << 32);                              // lanes 0..15: COVR words, 16..31: COVC words
             if (lane < MK_MAXW) S.covR[lane] = cv; else if (lane < 2 * MK_MAXW) S.covC[lane - MK_MAXW] = cv;
-            const u64 um = ~readlane64(cv, MK_MAXW + g) & validC;                          // my uncovered columns
+            const u64 um = ~readlane64(cv, MK_MAXW + g) & validC;        // my uncovered columns
             if ((um >> lane) & 1) S.list[__popcll(um & ((1ull << lane) - 1))] = (unsigned short)(cbase + lane);
-            if (lane == 0) { S.flag[3] = (now == step); S.flag[4] = (int)now; S.flag[2] = __popcll(um); }
+            if (lane == 0) { S.flag[3] = state; S.flag[2] = __popcll(um); }
         }
         __syncthreads();
-        if (S.flag[3] || (unsigned)S.flag[4] == MK_SEQ_EXIT) return;   // the controller went away / is done
-        step = (unsigned)S.flag[4];
+        if (S.flag[3]) return;                                          // the controller is done / went away
         const int nmine = S.flag[2];
         const bool rowcov = (S.covR[wave] >> lane) & 1;
         const bool mine = r < nR && !rowcov;
+        // work in the update phase: my uncovered columns, or covered rows crossing my covered columns
+        int ncr = 0;
+        for (int w = 0; w < wordsR; w++) ncr += __popcll(S.covR[w]);
+        const bool part2 = ncr > 0 && (S.covC[g] & validC) != 0;
         // ---- phase A: minimum key over (uncovered rows) x (my uncovered columns); 8 loads in flight per thread ----
         double v[8];
         u64 best = ~0ull;
         if (nmine > 0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(k, nmine - 1)])];
+            for (int k = 0; k < 8; k++) if (k < nmine) v[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[k])];   // uniform guard
+        }
+        // wave 1 (wave 0 is the poller): the first 4 covered rows of my covered columns, needed after h only
+        double x2[4]; int rr2[4] = {0, 0, 0, 0};
+        if (uwave == 1 && part2) {
+            wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);   // covered rows, ascending (== ncr entries)
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr2[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(q, ncr - 1)]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) x2[q] = d[(size_t)rr2[q] + coff];
+        }
+        if (nmine > 0) {
 #pragma unroll
             for (int k = 0; k < 8; k++) if (mine && k < nmine) { const u64 kk = dkey(v[k]); if (kk < best) best = kk; }
             for (int q0 = 8; q0 < nmine; q0 += 8) {
@@ -166,21 +188,62 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             u64 b = (lane < MK_THREADS / 64) ? (u64)__double_as_longlong(S.red[lane]) : ~0ull;
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) { const u64 o = __shfl_xor(b, off); if (o < b) b = o; }
-            if (lane == 0) ctl_st(ctl + CTL_PARTIAL + (step & 1) * MK_HELPERS + g, b < MK_KEY_NONE ? b : MK_KEY_NONE);   // the word is its own flag
-            // ---- wait for h (slot step & 1) ----
-            int spins = 0; u64 hb;
-            for (;;) {
-                hb = ctl_ld(ctl + CTL_H0 + (step & 1));
-                hb = readlane64(hb, 0);
-                if (hb != MK_HSENT || ++spins > MK_SPIN_LIMIT) break;
-                __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) ctl_st(ctl + CTL_PARTIAL + ((step & 1) * MK_HELPERS + g) * MK_PARTIAL_STRIDE, b < MK_KEY_NONE ? b : MK_KEY_NONE);   // the word is its own flag
+            if (nmine > 0 || part2) {
+                // ---- h = minimum of the 16 partial minima: every helper with work reads them itself (no detour
+                // through the controller) ----
+                int spins = 0; u64 pk; bool lost = false;
+                for (;;) {
+                    pk = ctl_ld(ctl + CTL_PARTIAL + ((step & 1) * MK_HELPERS + (lane & (MK_HELPERS - 1))) * MK_PARTIAL_STRIDE);
+                    if (!__ballot(pk == MK_HSENT)) break;
+                    if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) { const u64 o = __shfl_xor(pk, off); if (o < pk) pk = o; }
+                if (lane == 0) { S.flag[3] = lost ? 2 : 0; S.hbits = (u64)__double_as_longlong(dunkey(pk)); }
             }
-            if (lane == 0) { S.flag[3] = (hb == MK_HSENT); S.hbits = hb; }
         }
         __syncthreads();
+        if (nmine == 0 && !part2) continue;                            // nothing of mine changes in this step 5 (the controller expects no bits from me)
         if (S.flag[3]) return;
         const double h = __longlong_as_double((long long)S.hbits);
-        // ---- phase B (:355-364) on my uncovered columns ----
+        const u64 tagw = (u64)tag << 32;                                 // every granule carries the tag of its step 5
+        // ---- covered rows of my COVERED columns: += h (:355-358); wave 1, lane = column ----
+        if (uwave == 1 && part2) {
+            const bool act = cbase + lane < nC && ((S.covC[g] >> lane) & 1);
+            {
+                u64 bl[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double x = x2[q] + h;
+                    if (act && q < ncr) d[(size_t)rr2[q] + coff] = x;
+                    bl[q] = __ballot(act && fabs(x) < DBL_EPSILON);
+                }
+                // 8 granules (4 rows x 2 halves), contiguous, one store instruction
+                const int q = (lane >> 1) & 3;
+                const u64 bq = q == 0 ? bl[0] : q == 1 ? bl[1] : q == 2 ? bl[2] : bl[3];
+                if (lane < 2 * min(ncr, 4)) ctl_st(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + q) * 2 + (lane & 1), ((lane & 1) ? bq >> 32 : bq & 0xFFFFFFFFull) | tagw);
+            }
+            for (int i0 = 4; i0 < ncr; i0 += 4) {                       // more covered rows: 4 at a time
+                int rr[4]; double x[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) x[q] = d[(size_t)rr[q] + coff];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (i0 + q < ncr) {
+                        x[q] += h;
+                        if (act) d[(size_t)rr[q] + coff] = x[q];
+                        const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
+                        if (lane < 2) ctl_st(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw);
+                    }
+                }
+            }
+        }
+        // ---- phase B (:355-364) on my uncovered columns; the ballots are staged in LDS (the helpers do not use the zero
+        // bitmap) and each column's 32 granules leave as ONE 256-byte store ----
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (k < nmine) {                                            // uniform
@@ -188,13 +251,20 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
                 const double x = rowcov ? (v[k] + h) - h : v[k] - h;
                 if (r < nR) d[(size_t)r + (size_t)nR * c] = x;
                 const u64 bal = __ballot(r < nR && fabs(x) < DBL_EPSILON);
-                if (lane == 0) ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + wave, bal);
+                if (lane == 0) S.bm[k * MK_MAXW + wave] = bal;
             }
+        }
+        __syncthreads();
+        if (uwave < min(nmine, 8) && lane < 2 * MK_MAXW) {
+            const int c = S.list[uwave];
+            const u64 bal = S.bm[uwave * MK_MAXW + (lane >> 1)];
+            ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw);
         }
         for (int q0 = 8; q0 < nmine; q0 += 8) {
             double w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) w[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[min(q0 + k, nmine - 1)])];
+            __syncthreads();                                            // the staging words of the previous batch have been read
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 if (q0 + k < nmine) {
@@ -202,41 +272,17 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
                     const double x = rowcov ? (w[k] + h) - h : w[k] - h;
                     if (r < nR) d[(size_t)r + (size_t)nR * c] = x;
                     const u64 bal = __ballot(r < nR && fabs(x) < DBL_EPSILON);
-                    if (lane == 0) ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + wave, bal);
+                    if (lane == 0) S.bm[k * MK_MAXW + wave] = bal;
                 }
             }
-        }
-        // ---- covered rows of my COVERED columns: += h (:355-358); wave 0, lane = column, 4 rows in flight ----
-        if (uwave == 0) {
-            const int c = cbase + lane;
-            const bool act = c < nC && ((S.covC[g] >> lane) & 1);
-            const size_t coff = (size_t)nR * min(c, nC - 1);
-            int i = 0;                                                  // index among the covered rows, ascending
-            for (int w = 0; w < wordsR; w++) {
-                u64 rw = readlane64(S.covR[w], 0);
-                while (rw) {
-                    int rr[4]; int nq = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { rr[q] = rw ? w * 64 + __ffsll((long long)rw) - 1 : rr[0]; if (rw) { nq++; rw &= rw - 1; } }
-                    double x[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) x[q] = d[(size_t)rr[q] + coff];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (q < nq) {
-                            x[q] += h;
-                            if (act) d[(size_t)rr[q] + coff] = x[q];
-                            const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
-                            if (lane == 0) ctl_st(ctl + CTL_COVBITS + (size_t)(i + q) * MK_MAXW + g, bal);
-                        }
-                    }
-                    i += nq;
-                }
+            __syncthreads();
+            if (uwave < min(nmine - q0, 8) && lane < 2 * MK_MAXW) {
+                const int c = S.list[q0 + uwave];
+                const u64 bal = S.bm[uwave * MK_MAXW + (lane >> 1)];
+                ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctl + CTL_ARRIVE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                               // S.list / S.covR are rewritten by wave 0 for the next step
     }
 }
 
@@ -259,7 +305,8 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     if (nR <= 0 || nC <= 0) { if (tid == 0) *a.ws.cost = 0.0; for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
-    u64* ctl = a.ws.ctl; unsigned myseq = 0; u64 arrived = 0;
+    u64* ctl = a.ws.ctl; unsigned myseq = 0;
+    const unsigned epoch = (HELP && ctl) ? (unsigned)ctl_ld(ctl + CTL_EPOCH) : 0;
     const int minDim = perRow ? nR : nC;
     int n_s4 = 0, n_s5 = 0, n_sw = 0, n_cov5 = 0, ncu0 = 0; long long t_s3 = 0, t_s5 = 0, t_h0 = 0, t_h1 = 0, t_h2 = 0, t_h3 = 0;     // wave-0 / thread-0 statistics
 
@@ -459,12 +506,13 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             if (n_s5 == 1) ncu0 = ncu;
             ++myseq;
             if (uwave == 0) {
-                if (lane < MK_MAXW) ctl_st(ctl + CTL_COVR + lane, S.covR[lane]);
-                else if (lane < 2 * MK_MAXW) ctl_st(ctl + CTL_COVC + lane - MK_MAXW, S.covC[lane - MK_MAXW]);
-                else if (lane < 2 * MK_MAXW + MK_HELPERS) ctl_st(ctl + CTL_PARTIAL + ((myseq + 1) & 1) * MK_HELPERS + lane - 2 * MK_MAXW, MK_HSENT);   // re-arm the
-                else if (lane == 2 * MK_MAXW + MK_HELPERS) ctl_st(ctl + CTL_H0 + ((myseq + 1) & 1), MK_HSENT);                                          // NEXT step's slots
+                // the slots re-armed during the previous step 5 must have landed before anybody can act on this publish
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) ctl_st(ctl + CTL_SEQ, (u64)myseq);
+                {   // 64 granules = 32 cover-mask words, one store instruction
+                    const int j = lane >> 1;
+                    const u64 src = j < MK_MAXW ? S.covR[j] : S.covC[j - MK_MAXW];
+                    ctl_st(ctl + CTL_COV + lane, ((lane & 1) ? src >> 32 : src & 0xFFFFFFFFull) | ((u64)(epoch + myseq) << 32));
+                }
                 const long long tq0 = wall_clock64(); t_h0 += tq0 - t_b;
                 // covered rows, ascending (for the merge); overlaps the helpers' phase A
                 const int ncr = wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);
@@ -472,7 +520,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 int spins = 0; bool lost = false;
                 u64 hk;
                 for (;;) {                                              // every helper's partial minimum is its own arrival flag
-                    hk = (lane < nhelp) ? ctl_ld(ctl + CTL_PARTIAL + (myseq & 1) * MK_HELPERS + lane) : 0;
+                    hk = (lane < nhelp) ? ctl_ld(ctl + CTL_PARTIAL + ((myseq & 1) * MK_HELPERS + lane) * MK_PARTIAL_STRIDE) : 0;
                     if (!__ballot(hk == MK_HSENT)) break;
                     if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -480,40 +528,78 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 if (lane >= nhelp) hk = ~0ull;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(hk, off); if (o < hk) hk = o; }
-                if (lane == 0) ctl_st(ctl + CTL_H0 + (myseq & 1), (u64)__double_as_longlong(dunkey(hk)));
                 const long long tq1 = wall_clock64(); t_h1 += tq1 - tq0;
-                arrived += nhelp;
-                for (spins = 0; !lost;) {
-                    const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl_ld(ctl + CTL_ARRIVE));
-                    if (got >= (unsigned)arrived) break;
-                    if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
                 if (lost && lane == 0) { stat[15] = 1; S.flag[7] = 1; }
-                t_h2 += wall_clock64() - tq1;
             }
             __syncthreads();
             if (S.flag[7]) break;                                      // helpers lost: give up (status[15] != 0)
             const long long tq2 = wall_clock64();
             const int ncr = S.flag[2];
-            // merge: uncovered columns get their complete new words; covered columns only the covered rows' bits
-            for (int i = tid; i < ncu * wordsR; i += MK_THREADS) { const int k = i / wordsR, w = i - k * wordsR; const int c = S.list[k]; S.bm[c * MK_MAXW + w] = ctl_ld(ctl + CTL_BMOUT + (size_t)c * MK_MAXW + w); }
-            if (ncr > 0 && tid < nC && ((S.covC[wave] >> lane) & 1)) {
-                for (int i0 = 0; i0 < ncr; i0 += 4) {                   // 4 loads in flight
-                    u64 cb[4];
+            // ---- collect + merge: every thread polls exactly the tagged granules it merges.  Uncovered columns get their
+            // complete new words (BMOUT); covered columns only the covered rows' bits (COVBITS). ----
+            {
+                const unsigned tag = epoch + myseq;
+                const bool ccol = ncr > 0 && tid < nC && ((S.covC[wave] >> lane) & 1);
+                const bool wcov = __ballot(ccol) != 0;                  // this wave's column word holds covered columns
+                // one round covers 64 uncovered columns (two granule slots per thread: a column's 32 granules are
+                // contiguous, so a wave instruction reads two whole columns = 4 lines) and 4 covered rows
+                const int rounds = max(max((ncu + 63) / 64, (ncr + 3) / 4), 1);
+                bool lostB = false;
+                for (int rd = 0; rd < rounds && !lostB; rd++) {
+                    int bk[2]; bool hb[2]; const u64* bp[2]; u64 bv[2] = {0, 0};
 #pragma unroll
-                    for (int q = 0; q < 4; q++) cb[q] = ctl_ld(ctl + CTL_COVBITS + (size_t)min(i0 + q, ncr - 1) * MK_MAXW + wave);
+                    for (int j = 0; j < 2; j++) {
+                        const int gi = (rd * 2 + j) * MK_THREADS + tid;
+                        bk[j] = gi >> 5;
+                        hb[j] = bk[j] < ncu && ((gi & 31) >> 1) < wordsR;
+                        bp[j] = ctl + CTL_BMOUT + (size_t)S.list[min(bk[j], ncu - 1)] * MK_MAXW * 2 + (gi & 31);
+                    }
+                    const int nrow = min(ncr - rd * 4, 4);              // covered rows of this round (may be <= 0)
+                    const bool hc = wcov && lane < 2 * nrow;
+                    const u64* cp = ctl + CTL_COVBITS + ((size_t)wave * MK_MAXN + rd * 4) * 2 + lane;
+                    u64 cvv = 0;
+                    bool mylost = false;
+                    for (int spins = 0;; ) {                            // every wave polls its own granules at its own pace
+                        bool ok = true;
+                        if (hb[0]) bv[0] = ctl_ld(bp[0]);
+                        if (hb[1]) bv[1] = ctl_ld(bp[1]);
+                        if (hc) cvv = ctl_ld(cp);
+                        if (hb[0]) ok &= (unsigned)(bv[0] >> 32) == tag;
+                        if (hb[1]) ok &= (unsigned)(bv[1] >> 32) == tag;
+                        if (hc) ok &= (unsigned)(cvv >> 32) == tag;
+                        if (!__ballot(!ok)) break;
+                        if (++spins > MK_SPIN_LIMIT) { mylost = true; break; }
+                    }
+                    lostB = __syncthreads_or(mylost);
+                    if (lostB) break;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (i0 + q < ncr) {
-                            const int rr = S.clist[i0 + q];
-                            const bool z = (cb[q] >> lane) & 1;
-                            u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
-                            wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                    for (int j = 0; j < 2; j++) {
+                        const u64 hi = __shfl_down(bv[j], 1);           // lane pairs: even lane = low half, odd lane = high half
+                        if (hb[j] && !(lane & 1)) {
+                            const int gi = (rd * 2 + j) * MK_THREADS + tid;
+                            S.bm[S.list[bk[j]] * MK_MAXW + ((gi & 31) >> 1)] = (bv[j] & 0xFFFFFFFFull) | (hi << 32);
+                        }
+                    }
+                    if (wcov && nrow > 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const u64 lo = readlane64(cvv, 2 * q), hi2 = readlane64(cvv, 2 * q + 1);
+                            if (q < nrow && ccol) {
+                                const int rr = S.clist[rd * 4 + q];
+                                const bool z = (((lane < 32) ? lo : hi2) >> (lane & 31)) & 1;
+                                u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
+                                wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                            }
                         }
                     }
                 }
+                if (lostB) { if (tid == 0) { stat[15] = 2; S.flag[7] = 1; } }
+                else if (tid < MK_HELPERS) ctl_st(ctl + CTL_PARTIAL + ((myseq & 1) * MK_HELPERS + tid) * MK_PARTIAL_STRIDE, MK_HSENT);   // every helper that needed the partial minima has used them: re-arm for step + 2
+                t_h2 += wall_clock64() - tq2;
             }
+            __syncthreads();
+            if (S.flag[7]) break;
+            const long long tq3 = wall_clock64();
             __syncthreads();
             {   // rebuild hz for the uncovered columns (their entries just changed)
                 const bool unc = tid < nC && !((S.covC[wave] >> lane) & 1);
@@ -524,7 +610,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             }
             __syncthreads();
             if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
-            t_h3 += wall_clock64() - tq2;
+            t_h3 += wall_clock64() - tq3;
         } else {
             const int ncu = S.flag[1];
             if (n_s5 == 1) ncu0 = ncu;
@@ -610,7 +696,10 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         if (++guard > 4 * MK_MAXN * MK_MAXN) break;                    // cannot happen for finite costs
     }
     __syncthreads();
-    if (HELP && nhelp > 0 && tid == 0) ctl_st(ctl + CTL_SEQ, (u64)MK_SEQ_EXIT);
+    if (HELP && nhelp > 0 && uwave == 0) {
+        if (lane == 0) ctl_st(ctl + CTL_EPOCH, (u64)(epoch + myseq));
+        ctl_st(ctl + CTL_COV + lane, (u64)MK_TAG_EXIT << 32);
+    }
     if (tid == 0) {
         stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0; 
         // step-5 split (thread 0, 100 MHz ticks): helpers: publish / wait minimum / wait update / merge;  one workgroup: pass 1 / reduce / (a) / (b)

@@ -330,7 +330,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
-    HIPCHK(c->a_ctl.alloc(2112 + 2 * 16384)); HIPCHK(hipMemset(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n)); c->assoc.ctl = c->a_ctl.p;
+    HIPCHK(c->a_ctl.alloc(MOT_ASSOC_CTL_WORDS)); HIPCHK(hipMemset(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n)); c->assoc.ctl = c->a_ctl.p;
     c->slots_per_rank = (cfg->max_tracks + cfg->world - 1) / cfg->world;
     HIPCHK(c->d_gather.alloc((size_t)c->slots_per_rank * cfg->world));
     HIPCHK(hipMemset(c->d_gather.p, 0, sizeof(bbox_t) * c->d_gather.n));

@@ -7,6 +7,7 @@
 #define MOT_NCHAN 31          // FHOG channels used by KCF (trackers/kcf.cpp:157)
 #define MOT_NORI 18           // contrast-sensitive orientations (libhog/gradientMex.cpp:305)
 #define MOT_CELL 4            // trackers/kcf.cpp:488
+#define MOT_ASSOC_CTL_WORDS (1024 + 4 * 16384)   // assoc_common.h: control words + tagged COVBITS / BMOUT granules
 #define MOT_KCF_THREADS 512   // one workgroup per track
 #define MOT_LDS_LIMIT (160 * 1024)
 
@@ -80,7 +81,7 @@ struct AssocWs {
     int* assignment;          // [1024]
     double* cost;             // [1]
     int* status;              // [16]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow, timers
-    unsigned long long* ctl;  // control block + result buffers of the step-5 helper workgroups (MK_CTL_WORDS u64)
+    unsigned long long* ctl;  // control block + result buffers of the step-5 helper workgroups (MOT_ASSOC_CTL_WORDS u64)
 };
 
 // host-side launchers implemented in the .hip files
