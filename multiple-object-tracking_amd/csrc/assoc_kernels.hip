@@ -286,6 +286,66 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
     }
 }
 
+// ---- small problems: cost, line minima, working matrix and zero bitmaps computed by the Munkres workgroup itself --
+// same arithmetic as assoc_min_kernel / assoc_sub_kernel, two launches and a memset fewer per frame.  The layout
+// handles up to MK_FUSE_MAX lines, but one CU's fp64 sqrt rate makes it slower than the tiled kernels beyond
+// MK_FUSE_LINES (64 lines: 22 vs 28 us; 256 lines: 85 vs 48 us).
+// Thread = (row r = tid & 255, column class tid >> 8); scratch lives in the not yet used bitmap region.
+#define MK_FUSE_MAX 256
+#define MK_FUSE_LINES 64
+__device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, bool rowsTrk)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = tid & (MK_FUSE_MAX - 1), part = tid >> 8;
+    const bool perRow = nR <= nC;
+    const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
+    u64* lm = S.bm;                                                    // [256] keys of the line minima
+    u64* zrs = S.bm + MK_FUSE_MAX;                                     // [256 rows][4 words] row-major zero bitmap
+    bbox_t* colb = reinterpret_cast<bbox_t*>(S.bm + 2 * MK_FUSE_MAX + MK_THREADS);   // [256] boxes of the column side
+    if (tid < MK_FUSE_MAX) lm[tid] = ~0ull;
+    zrs[tid] = 0;
+    // the boxes of both sides once: the row's box in registers, the column boxes in LDS (td.cpp:407-419 per element)
+    bbox_t rowb = {};
+    if (!a.user) {
+        if (r < nR) rowb = rowsTrk ? a.trk[r] : a.det[r];
+        if (tid < nC) colb[tid] = rowsTrk ? a.det[tid] : a.trk[tid];
+    }
+    __syncthreads();
+    auto cost = [&](int c) -> double {
+        if (a.user) return a.user[(size_t)r + (size_t)nR * c];
+        return rowsTrk ? pair_cost(rowb, colb[c]) : pair_cost(colb[c], rowb);
+    };
+    u64 best = ~0ull;                                                  // pass 1 (hungarian.cpp:69-81 / :107-119)
+    for (int c = part; c < nC; c += MK_THREADS / MK_FUSE_MAX) {
+        const u64 kk = r < nR ? dkey(cost(c)) : ~0ull;
+        if (perRow) { if (kk < best) best = kk; }
+        else {
+            u64 m = kk;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_down(m, off); if (o < m) m = o; }
+            if (lane == 0) atomicMin(&lm[c], m);
+        }
+    }
+    if (perRow && r < nR && best != ~0ull) atomicMin(&lm[r], best);
+    __syncthreads();
+    const double rmin = (perRow && r < nR) ? dunkey(lm[r]) : 0.0;      // pass 2
+    for (int c = part; c < nC; c += MK_THREADS / MK_FUSE_MAX) {
+        bool z = false;
+        if (r < nR) {
+            const double v = cost(c);
+            const double dv = v - (perRow ? rmin : dunkey(lm[c]));
+            a.ws.dist[(size_t)r + (size_t)nR * c] = dv;
+            z = fabs(dv) < DBL_EPSILON;
+        }
+        const u64 bal = __ballot(z);
+        if (lane == 0 && (r >> 6) < wordsR) a.ws.zc[(size_t)c * wordsR + (r >> 6)] = bal;
+        if (z) atomicOr(&zrs[r * 4 + (c >> 6)], 1ull << (c & 63));
+    }
+    __syncthreads();
+    for (int i = tid; i < nR * wordsC; i += MK_THREADS) { const int rr = i / wordsC, w = i - rr * wordsC; a.ws.zr[(size_t)rr * wordsC + w] = zrs[rr * 4 + w]; }
+    __syncthreads();
+}
+
 // HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
 // HELP = true : launched with 1 + MK_HELPERS workgroups; workgroups 1.. run mk_helper_loop.
 template <bool HELP>
@@ -303,6 +363,8 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     const int nhelp = HELP ? (int)gridDim.x - 1 : 0;                   // 0: everything in this workgroup
     if (HELP && blockIdx.x > 0) { if (nR > 0 && nC > 0) mk_helper_loop(a, S, nR, nC); return; }
     if (nR <= 0 || nC <= 0) { if (tid == 0) *a.ws.cost = 0.0; for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
+    if (!HELP && (want_cost & 2)) mk_fused_cost(a, S, nR, nC, rowsTrk);
+    if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
     u64* ctl = a.ws.ctl; unsigned myseq = 0;
@@ -709,7 +771,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     }
     // buildassignmentvector (:161-176) + computeassignmentcost (:179-189)
     for (int r = tid; r < nR; r += MK_THREADS) a.ws.assignment[r] = S.starColOfRow[r];
-    if (want_cost) {
+    if (want_cost & 1) {
         double* vals = reinterpret_cast<double*>(S.bm);                // bitmap no longer needed
         __syncthreads();
         for (int r = tid; r < nR; r += MK_THREADS) { const int c = S.starColOfRow[r]; vals[r] = (c >= 0) ? elem_cost(a, r, c, nR, rowsTrk) : 0.0; }
@@ -751,9 +813,14 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     if (user_dist) { maxR = nR; maxC = nC; }
     else { maxR = nT < nD ? nT : nD; maxC = nT < nD ? nD : nT; if (nT_dev) { maxR = nD < nT ? nD : nT; maxC = nD > nT ? nD : nT; } }
     if (maxR > MK_MAXN || maxC > MK_MAXN) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(a.linemin, 0xFF, sizeof(u64) * MK_MAXN, s);
-    if (e != hipSuccess) return e;
-    if (maxR > 0 && maxC > 0) {
+    static int use_lazy = -1;
+    if (use_lazy < 0) { const char* ev = getenv("MOT_MUNKRES_LAZY"); use_lazy = (ev && ev[0] == '1') ? 1 : 0; }
+    const int lines = maxR > maxC ? maxR : maxC;
+    // small problems: the Munkres workgroup computes cost, minima and bitmaps itself (mk_fused_cost)
+    const bool fused = !use_lazy && lines <= MK_FUSE_LINES;
+    hipError_t e = hipSuccess;
+    if (!fused && maxR > 0 && maxC > 0) {
+        if (use_lazy) { e = hipMemsetAsync(a.linemin, 0xFF, sizeof(u64) * MK_MAXN, s); if (e != hipSuccess) return e; }   // the eager kernels re-arm it themselves
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
         hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
@@ -761,8 +828,6 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     }
     // default: the eager emulation below; MOT_MUNKRES_LAZY=1 selects the lazy-column variant (munkres_lazy.hip:
     // same results, touches far fewer bytes per step 5, but its per-event bookkeeping is not yet faster end to end)
-    static int use_lazy = -1;
-    if (use_lazy < 0) { const char* ev = getenv("MOT_MUNKRES_LAZY"); use_lazy = (ev && ev[0] == '1') ? 1 : 0; }
     if (use_lazy) return launch_munkres_lazy(a, want_cost, s);
     static bool attr_set = false;
     if (!attr_set) {
@@ -777,9 +842,8 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // every problem above 256 lines, =0 off; default: above MK_HELP_MIN lines.
     static int helpers = -1;
     if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
-    const int lines = maxR > maxC ? maxR : maxC;
     const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN));
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost);
-    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost);
+    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0));
     return hipGetLastError();
 }

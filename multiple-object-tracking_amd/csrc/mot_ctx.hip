@@ -326,7 +326,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     const size_t n2 = (size_t)1024 * 1024;
     const size_t mr = std::max(cfg->max_tracks, cfg->max_dets);
     const size_t mat = std::min(n2, mr * mr);
-    HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024));
+    HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024)); HIPCHK(hipMemset(c->a_linemin.p, 0xFF, 1024 * sizeof(unsigned long long)));
     HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
