@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tracks", type=int, default=1024, help="total concurrent KCF tracks (all GPUs)")
     ap.add_argument("--size", type=int, default=80, help="square template / object size in pixels")
+    ap.add_argument("--mode", choices=["sharded", "streams"], default="sharded",
+                    help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded tid %% N, one all-gather per frame (BASELINE configs[3], strong scaling); "
+                         "streams = N independent camera streams of --tracks tracks each, one per GPU, no collective (BASELINE configs[4], weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=20)
     ap.add_argument("--debug-assoc", action="store_true", help="print Munkres step counters / phase times per profiled frame to stderr")
@@ -136,9 +139,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_tracks, size = args.tracks, args.size
+    streams = args.mode == "streams" and world > 1
+    mot_rank, mot_world = (0, 1) if streams else (rank, world)
     n_prof = args.profile_frames if world == 1 else 0
     n_frames = 1 + args.warmup + args.steps + n_prof
-    frames_h, dets_h = gen_stream(n_tracks, size, n_frames)
+    frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0)
     frames_d = torch.from_numpy(frames_h).cuda()
     dets_d = torch.from_numpy(dets_h.view(np.uint8).reshape(n_frames, -1)).cuda()
     frame_bytes = 720 * 1280 * 3
@@ -146,20 +151,20 @@ def main():
 
     stream = torch.cuda.Stream()
     ctx = mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(n_tracks, 1), max_dets=max(n_tracks, 1),
-                             rank=rank, world=world, stream=stream.cuda_stream, dev_size=size)
+                             rank=mot_rank, world=mot_world, stream=stream.cuda_stream, dev_size=size)
 
     gathered = None
 
     def step(f):
         fp = frames_d.data_ptr() + f * frame_bytes
         dp = dets_d.data_ptr() + f * det_bytes
-        if world == 1:
+        if mot_world == 1:
             ctx.step_frame_device(fp, dp, n_tracks)
         else:
             seg_ptr, spr = ctx.step_begin_device(fp)
             nonlocal gathered
             if gathered is None:
-                gathered = torch.empty(world * spr * 24, dtype=torch.uint8, device="cuda")
+                gathered = torch.empty(mot_world * spr * 24, dtype=torch.uint8, device="cuda")
                 step.local = torch.as_tensor(par.DevArray(seg_ptr, spr * 24), device="cuda")
             par.all_gather_boxes(step.local, gathered)             # the single collective of the frame (RCCL over xGMI)
             ctx.step_finish_device(gathered.data_ptr(), dp, n_tracks)
@@ -187,6 +192,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         n_live = ctx.live_count()
+        if streams:                                                  # every rank tracks its own stream: whole-job units = sum over ranks
+            t = torch.tensor([n_live], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            n_live = int(t.item())
 
         # per-kernel device time, HIP events on the launch stream (world == 1 only)
         stage = None
@@ -209,12 +218,15 @@ def main():
         out = {
             "metric": "tracker-updates/sec (KCF, 80x80 patch)", "value": value, "unit": "tracker-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n_tracks} concurrent {size}x{size} KCF tracks (31-ch FHOG, cell 4), 1280x720 BGR synthetic stream, "
-                                   f"{n_tracks} detections/frame, Munkres {n_tracks}x{n_tracks}, tracks sharded tid % {world}; "
-                                   f"BASELINE configs[{2 if n_tracks == 1024 else 1}]" + ("/[3]" if world > 1 else ""),
-                       "tracks_total": n_tracks, "tracks_per_gpu": n_tracks // world, "live_tracks_end": n_live, "patch": size,
-                       "parallelism": f"track-shard x{world}, 1 all-gather/frame" if world > 1 else "single GPU"},
+            "higher_is_better": True, "scaling": "weak" if streams else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"{world} independent camera streams (one per GPU, no collective), each {n_tracks} concurrent {size}x{size} KCF tracks, "
+                                    f"1280x720 BGR synthetic stream, Munkres {n_tracks}x{n_tracks}; BASELINE configs[4]") if streams else
+                                   (f"{n_tracks} concurrent {size}x{size} KCF tracks (31-ch FHOG, cell 4), 1280x720 BGR synthetic stream, "
+                                    f"{n_tracks} detections/frame, Munkres {n_tracks}x{n_tracks}, tracks sharded tid % {world}; "
+                                    f"BASELINE configs[{2 if n_tracks == 1024 else 1}]" + ("/[3]" if world > 1 else "")),
+                       "tracks_total": n_tracks * (world if streams else 1), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
+                       "live_tracks_end": n_live, "patch": size,
+                       "parallelism": (f"{world} replicas, no collective" if streams else f"track-shard x{world}, 1 all-gather/frame") if world > 1 else "single GPU"},
         }
         ab = alg_bytes(size)
         if stage is not None:

@@ -208,13 +208,15 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // (x outer, y inner), so every R1 value is bit-identical.  Then :225-230.
 // ---------------------------------------------------------------------------
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
-                           float* __restrict__ R1, int tid, int nt)
+                           float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt)
 {
     const int hb = p.hb, wb = p.wb, nb = p.nb, LP = p.ldp;
     const int h0 = hb * 4, w0 = wb * 4;
     for (int cell = tid; cell < nb; cell += nt) {
         uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
-        float* __restrict__ Rc = R1 + cell * R1S;
+        // HBM-slab templates accumulate in a per-thread LDS scratch (the read-modify-write chain would otherwise run at L2
+        // latency) and copy the finished cell out
+        float* __restrict__ Rc = scratch ? scratch + tid * R1S : R1 + cell * R1S;
 #pragma unroll
         for (int o = 0; o < MOT_NORI; o++) Rc[o] = 0.0f;
         const int x_lo = max(0, 4 * (int)cx - 2), x_hi = min(w0 - 1, 4 * (int)cx + 5);
@@ -259,6 +261,11 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 for (int k = 0; k < nmul; k++) v *= c;
                 Rc[o] = v;
             }
+        }
+        if (scratch) {
+            float* out = R1 + cell * R1S;
+#pragma unroll
+            for (int o = 0; o < MOT_NORI; o++) out[o] = Rc[o];
         }
     }
 }
@@ -484,7 +491,8 @@ __device__ __forceinline__ void cfft20_inplace(float2* __restrict__ base, int st
 // forward 2-D r2c of `nch` feature planes; result S[(ch*wb + x')*fh + k] in region B.
 // F lives in region B (row stride ldf = 2*fh floats); T is the ping-pong buffer of the generic path.
 __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* __restrict__ regB,
-                            const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt)
+                            const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt,
+                            float* __restrict__ stage = nullptr)
 {
     if (p.fft20) {
         const int nrows = nch * p.wb;
@@ -497,6 +505,21 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
             cfft20_inplace<-1>(S + ch * 220 + k, 11);
         }
         __syncthreads();
+    } else if (stage && p.stage_G > 0) {
+        // HBM-slab templates: G channel planes at a time through LDS (features in, rows DFT, columns DFT, spectrum out
+        // in place: a channel's spectrum occupies exactly the bytes of its feature plane); same arithmetic as below
+        const int planeF = p.wb * 2 * p.fh;                           // floats of one feature plane == floats of its half spectrum
+        float* sF = stage; float2* sT = reinterpret_cast<float2*>(stage + p.stage_G * planeF);
+        for (int c0 = 0; c0 < nch; c0 += p.stage_G) {
+            const int g = min(p.stage_G, nch - c0);
+            const float2* src = reinterpret_cast<const float2*>(regB + (size_t)c0 * planeF);   // planeF is even
+            for (int i = tid; i < g * planeF / 2; i += nt) reinterpret_cast<float2*>(sF)[i] = src[i];
+            __syncthreads();
+            dft_rows_generic(p, sF, sT, twr, g, tid, nt);
+            __syncthreads();
+            dft_cols_generic<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
+            __syncthreads();
+        }
     } else {
         float2* T = reinterpret_cast<float2*>(regT);
         dft_rows_generic(p, regB, T, twr, nch, tid, nt);
@@ -565,10 +588,10 @@ struct Regions {
     uint16_t* tab;
 };
 
-__device__ __forceinline__ Regions carve(const KcfPool& p, float* base)
+__device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* cbase = nullptr)
 {
     Regions r;
-    r.A = base + p.offA; r.B = base + p.offB; r.C = base + p.offC; r.T = base + p.offT;
+    r.A = base + p.offA; r.B = base + p.offB; r.C = cbase ? cbase : base + p.offC; r.T = base + p.offT;
     float* c = r.C;
     r.tab = reinterpret_cast<uint16_t*>(c); c += 2048;               // 4096 u16
     r.twr = reinterpret_cast<float2*>(c); c += 2 * p.hb;
@@ -584,7 +607,7 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base)
 }
 
 // Everything up to R1 (region A) and the norm matrix: shared by predict / update.
-__device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt)
+__device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt, float* stage = nullptr)
 {
 #define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
     DBG_STAMP(0);
@@ -600,7 +623,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
-    phase_hist(p, Mq, bins, r.A, tid, nt);                           // R1 overlays the patch
+    phase_hist(p, Mq, bins, r.A, stage, tid, nt);                    // R1 overlays the patch
     __syncthreads();
     DBG_STAMP(3);
     phase_energy(p, r.A, r.E, tid, nt);
@@ -612,12 +635,12 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
 
 // one half of the channels -> windowed features -> spectrum in region B (overlays Mq / bins, then itself)
 template <int HALF>
-__device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum)
+__device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum, float* stage = nullptr)
 {
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
     phase_channels<HALF>(p, r.A, r.N, r.B, fo, l.feat_windowed, tid, nt);
     __syncthreads();
-    if (spectrum) fft_forward(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt);
+    if (spectrum) fft_forward(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
 }
 
 template <bool kLds>
@@ -628,7 +651,8 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const K
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
     float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
-    const Regions r = carve(p, base);
+    float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;      // HBM-slab templates: region C + staging in LDS
+    const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int slot = l.slots[item];
     const bbox_t pos = p.pos[slot];                                    // kcf_t::pos == tracker_info.bbox (td.cpp:351-354)
@@ -643,12 +667,12 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const K
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
-    features_prepare(p, l, item, pos, r, tid, nt);
+    features_prepare(p, l, item, pos, r, tid, nt, stage);
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
     float zr = 0.f, zi = 0.f;
-    half_spectrum<0>(p, l, item, r, tid, nt, true);
+    half_spectrum<0>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     if (pre) {
         if (tid < p.nbins) {
@@ -665,7 +689,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const K
         }
     }
     __syncthreads();
-    half_spectrum<1>(p, l, item, r, tid, nt, true);
+    half_spectrum<1>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(6);
     if (pre) {
         if (tid < p.nbins) {
@@ -718,7 +742,8 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_update_kernel(const Kc
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
     float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
-    const Regions r = carve(p, base);
+    float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
+    const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int slot = l.slots[item];
     const bbox_t box = l.boxes_in[item];
@@ -732,7 +757,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_update_kernel(const Kc
 #pragma unroll
         for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
     }
-    features_prepare(p, l, item, box, r, tid, nt);
+    features_prepare(p, l, item, box, r, tid, nt, stage);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -761,11 +786,11 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_update_kernel(const Kc
                 m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y; xm[i] = m; }                    \
         }                                                                                                         \
     } while (0)
-    half_spectrum<0>(p, l, item, r, tid, nt, true);
+    half_spectrum<0>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     UPDATE_HALF(0, MOT_HALF0);
     __syncthreads();
-    half_spectrum<1>(p, l, item, r, tid, nt, true);
+    half_spectrum<1>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(6);
     UPDATE_HALF(MOT_HALF0, MOT_NCHAN);
 #undef UPDATE_HALF
@@ -843,9 +868,23 @@ void kcf_pool_layout(KcfPool& p)
     p.offA = 0; p.offB = up4(szA); p.offC = p.offB + up4(szB); p.offT = p.offC + up4(szC);
     p.lds_floats = p.offT + up4(szT);
     p.use_lds = ((size_t)p.lds_floats * sizeof(float) <= MOT_LDS_LIMIT) ? 1 : 0;
+    // HBM-slab templates keep region C (tables, twiddles, the single-plane buffers) in LDS, plus a staging area: the
+    // per-thread histogram scratch and G channel planes (features + row spectra) of the generic DFT
+    p.szC = 0; p.stage_floats = 0; p.stage_G = 0;
+    if (!p.use_lds) {
+        const int avail = (int)(MOT_LDS_LIMIT / sizeof(float)) - up4(szC);
+        const int hist = up4(MOT_KCF_THREADS * R1S);
+        const int plane2 = 2 * p.wb * 2 * p.fh;                      // feature plane + its row spectrum, floats
+        if (avail >= hist) {
+            p.szC = up4(szC);
+            int G = avail / plane2; if (G > MOT_HALF0) G = MOT_HALF0;
+            p.stage_G = G;
+            p.stage_floats = up4(G * plane2 > hist ? G * plane2 : hist);
+        }
+    }
 }
 
-size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats * sizeof(float) : 0; }
+size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats * sizeof(float) : (size_t)(p.szC + p.stage_floats) * sizeof(float); }
 
 template <typename K>
 static hipError_t set_lds_attr(K kern, size_t bytes)
@@ -867,7 +906,10 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_predict_kernel<true>, lds); if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
-    } else hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), 0, s, p, l, n);
+    } else {
+        hipError_t e = set_lds_attr(kcf_predict_kernel<false>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+    }
     return hipGetLastError();
 }
 
@@ -878,7 +920,10 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_update_kernel<true>, lds); if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
-    } else hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), 0, s, p, l, n);
+    } else {
+        hipError_t e = set_lds_attr(kcf_update_kernel<false>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+    }
     return hipGetLastError();
 }
 

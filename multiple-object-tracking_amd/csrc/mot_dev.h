@@ -37,7 +37,8 @@ struct KcfPool {
     int fhog_mode, fft20;
     // scratch carve (float offsets) and size
     int offA, offB, offC, offT, lds_floats;   // offT: ping-pong buffer of the generic DFT (unused by the 20x20 register FFT)
-    int use_lds;              // 1: scratch in LDS, 0: per-workgroup slab in HBM
+    int use_lds;              // 1: scratch in LDS, 0: per-workgroup slab in HBM, with region C and a staging area in LDS
+    int szC, stage_floats, stage_G;   // !use_lds: LDS floats of region C / of the staging area, channel planes per DFT stage
     float* gscratch;          // [grid][lds_floats] when !use_lds
     // state, indexed by slot
     float2* xm;               // [cap][31][nbins]
