@@ -133,10 +133,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MOT_BENCH_BACKEND=gloo is a smoke-test mode for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the
+    # all-gather is staged through the host.  It exercises the sharded device path, not RCCL, and is never a measurement.
+    backend = os.environ.get("MOT_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_tracks, size = args.tracks, args.size
     streams = args.mode == "streams" and world > 1
@@ -166,7 +174,11 @@ def main():
             if gathered is None:
                 gathered = torch.empty(mot_world * spr * 24, dtype=torch.uint8, device="cuda")
                 step.local = torch.as_tensor(par.DevArray(seg_ptr, spr * 24), device="cuda")
-            par.all_gather_boxes(step.local, gathered)             # the single collective of the frame (RCCL over xGMI)
+            if backend == "gloo":
+                stream.synchronize()
+                gathered.copy_(par.all_gather_boxes(step.local.cpu()))
+            else:
+                par.all_gather_boxes(step.local, gathered)         # the single collective of the frame (RCCL over xGMI)
             ctx.step_finish_device(gathered.data_ptr(), dp, n_tracks)
 
     with torch.cuda.stream(stream):
@@ -218,6 +230,7 @@ def main():
         out = {
             "metric": "tracker-updates/sec (KCF, 80x80 patch)", "value": value, "unit": "tracker-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            **({"smoke_backend": "gloo (not a measurement)"} if backend == "gloo" and world > 1 else {}),
             "higher_is_better": True, "scaling": "weak" if streams else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{world} independent camera streams (one per GPU, no collective), each {n_tracks} concurrent {size}x{size} KCF tracks, "
                                     f"1280x720 BGR synthetic stream, Munkres {n_tracks}x{n_tracks}; BASELINE configs[4]") if streams else
