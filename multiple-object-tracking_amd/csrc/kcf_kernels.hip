@@ -70,7 +70,7 @@ struct Ctx {
 // Phase 0: crop + gray + (bilinear resize) -> P[c*ldp + r]
 // ---------------------------------------------------------------------------
 __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, const float* __restrict__ patch,
-                           bbox_t box, float* __restrict__ P, uint8_t* __restrict__ raw, int tid, int nt)
+                           bbox_t box, float* __restrict__ P, uint8_t* __restrict__ raw, int tid, int nt, int raw_cap = 1 << 30)
 {
     const int rows = p.rows, cols = p.cols, npx = rows * cols;
     if (patch) {
@@ -94,6 +94,7 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
             const int mis = (int)(g0 & 15);                            // same for every row: 3840 = 240 * 16
             const int nch = (mis + cols * 3 + 15) >> 4;                // 16-byte chunks per row
             const int stride = nch * 16;
+            if (rows * stride <= raw_cap) {
             const uint8_t* fend = frame + (size_t)MOT_FRAME_W * MOT_FRAME_H * 3;
             for (int i = tid; i < rows * nch; i += nt) {
                 const int r = i / nch, j = i - r * nch;
@@ -111,6 +112,7 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
                 P[c * p.ldp + r] = (float)(0.144 * B + 0.587 * G + 0.299 * R);   // drawlib.c:234
             }
             return;
+            }
         }
         for (int i = tid; i < npx; i += nt) {
             uint32_t r, c; p.d_cols.divmod((uint32_t)i, r, c);         // c fastest: contiguous BGR bytes
@@ -397,6 +399,82 @@ __device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in
     }
 }
 
+// ---- register-resident generic DFTs for lengths up to MOT_DFT_REG_MAX (templates up to 164 px): one thread owns a
+// whole line, folds it once into sums / differences of the mirrored pairs (x, n-x) -- cos is even and sin is odd, so
+// every output needs half the multiplies -- and walks the outputs with a WAVE-UNIFORM twiddle index (broadcast LDS
+// reads, no per-lane index arithmetic).  Used by the LDS-staged path of the HBM-slab templates.
+#define MOT_DFT_REG_MAX 41
+#define MOT_DFT_PAIRS ((MOT_DFT_REG_MAX - 1) / 2)
+
+// real rows: F[row*ldf + y] -> T[row*fh + k], k = 0..fh-1 (same convention as dft_rows_generic)
+__device__ void dft_rows_reg(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
+                             const float2* __restrict__ twr, int nrows, int tid, int nt)
+{
+    const int hb = p.hb, fh = p.fh, ldf = 2 * fh, H = (hb - 1) >> 1;
+    const bool even = !(hb & 1);
+    for (int row = tid; row < nrows; row += nt) {
+        const float* in = F + row * ldf;
+        float s[MOT_DFT_PAIRS], d[MOT_DFT_PAIRS];
+#pragma unroll
+        for (int y = 1; y <= MOT_DFT_PAIRS; y++) {
+            const float a = in[min(y, hb - 1)], b = in[max(hb - y, 0)];
+            s[y - 1] = (y <= H) ? a + b : 0.f; d[y - 1] = (y <= H) ? a - b : 0.f;
+        }
+        const float in0 = in[0], mid = even ? in[hb >> 1] : 0.f;
+        float2* out = T + row * fh;
+        for (int k = 0; k < fh; k++) {                                // wave-uniform
+            float re = in0 + ((k & 1) ? -mid : mid), im = 0.f;
+            int j = 0;
+#pragma unroll
+            for (int y = 1; y <= MOT_DFT_PAIRS; y++) {
+                j += k; if (j >= hb) j -= hb;
+                const float2 w = twr[j];
+                re += s[y - 1] * w.x; im -= d[y - 1] * w.y;
+            }
+            out[k] = make_float2(re, im);
+        }
+    }
+}
+
+// complex columns: in[(ch*wb + x)*fh + k] -> out[(ch*wb + x')*fh + k]; the two halves of the output range go to the
+// two halves of the workgroup (uniform per wave)
+template <int SIGN>
+__device__ void dft_cols_reg(const KcfPool& p, const float2* __restrict__ in, float2* __restrict__ out,
+                             const float2* __restrict__ twc, int nch, int tid, int nt)
+{
+    const int wb = p.wb, fh = p.fh, H = (wb - 1) >> 1, ncols = nch * fh, half = nt >> 1;
+    const bool even = !(wb & 1);
+    const int part = tid >= half ? 1 : 0, hw = (wb + 1) >> 1;
+    const int x0 = part * hw, x1 = min(wb, x0 + hw);
+    for (int col = tid - part * half; col < ncols; col += half) {
+        uint32_t ch, k; p.d_fh.divmod((uint32_t)col, ch, k);
+        const float2* src = in + (size_t)ch * wb * fh + k;
+        float2 s[MOT_DFT_PAIRS], d[MOT_DFT_PAIRS];
+#pragma unroll
+        for (int x = 1; x <= MOT_DFT_PAIRS; x++) {
+            const float2 a = src[min(x, wb - 1) * fh], b = src[max(wb - x, 0) * fh];
+            const bool on = x <= H;
+            s[x - 1] = on ? make_float2(a.x + b.x, a.y + b.y) : make_float2(0.f, 0.f);
+            d[x - 1] = on ? make_float2(a.x - b.x, a.y - b.y) : make_float2(0.f, 0.f);
+        }
+        const float2 a0 = src[0], mid = even ? src[(wb >> 1) * fh] : make_float2(0.f, 0.f);
+        float2* dst = out + (size_t)ch * wb * fh + k;
+        for (int xp = x0; xp < x1; xp++) {                            // uniform per wave
+            const float sg = (xp & 1) ? -1.f : 1.f;
+            float re = a0.x + sg * mid.x, im = a0.y + sg * mid.y;
+            int j = 0;
+#pragma unroll
+            for (int x = 1; x <= MOT_DFT_PAIRS; x++) {
+                j += xp; if (j >= wb) j -= wb;
+                const float2 w = twc[j];
+                if (SIGN < 0) { re += s[x - 1].x * w.x + d[x - 1].y * w.y; im += s[x - 1].y * w.x - d[x - 1].x * w.y; }
+                else          { re += s[x - 1].x * w.x - d[x - 1].y * w.y; im += s[x - 1].y * w.x + d[x - 1].x * w.y; }
+            }
+            dst[xp * fh] = make_float2(re, im);
+        }
+    }
+}
+
 // ---- radix 4x5 prime-factor 20-point transforms, one thread per transform ----
 #define C1_5 0.30901699437494742f   /* cos(2pi/5) */
 #define C2_5 (-0.80901699437494742f) /* cos(4pi/5) */
@@ -515,9 +593,11 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
             const float2* src = reinterpret_cast<const float2*>(regB + (size_t)c0 * planeF);   // planeF is even
             for (int i = tid; i < g * planeF / 2; i += nt) reinterpret_cast<float2*>(sF)[i] = src[i];
             __syncthreads();
-            dft_rows_generic(p, sF, sT, twr, g, tid, nt);
+            const bool reg = p.hb <= MOT_DFT_REG_MAX && p.wb <= MOT_DFT_REG_MAX && p.hb >= 2 && p.wb >= 2;
+            if (reg) dft_rows_reg(p, sF, sT, twr, g * p.wb, tid, nt); else dft_rows_generic(p, sF, sT, twr, g, tid, nt);
             __syncthreads();
-            dft_cols_generic<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
+            if (reg) dft_cols_reg<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
+            else dft_cols_generic<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
             __syncthreads();
         }
     } else {
@@ -616,7 +696,9 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     for (int i = tid; i < p.hb; i += nt) r.twr[i] = p.tw_r[i];
     for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
     const float* patch = l.patches ? l.patches + (size_t)item * p.rows * p.cols : nullptr;
-    phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
+    // byte staging area of the crop: region B, or the LDS staging area of an HBM-slab template
+    if (stage) phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(stage), tid, nt, p.stage_floats * 4);
+    else phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
     __syncthreads();
     DBG_STAMP(1);
     float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.cols * p.ldp);
@@ -644,7 +726,7 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -659,7 +741,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const K
     // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
     // they land while the features are computed
     const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
-    const bool pre = p.nbins <= nt;
+    const bool pre = kLds && p.nbins <= nt;                            // HBM-slab templates never prefetch (frees the registers for the DFTs)
     const int bpre = min(tid, p.nbins - 1);
     float2 xmr[MOT_HALF0]; float alr = 0.f;                            // 16 planes at a time (register budget for 2 workgroups / CU)
     if (pre) {
@@ -735,7 +817,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_predict_kernel(const K
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -751,7 +833,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, 4) kcf_update_kernel(const Kc
     float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
     const int tot = MOT_NCHAN * p.nbins;
     // old model values do not depend on this frame: load them now (<= 16 independent loads per thread)
-    const bool pre = tot <= 16 * nt;
+    const bool pre = kLds && tot <= 16 * nt;
     float2 xold[16];
     if (pre) {
 #pragma unroll
