@@ -1,4 +1,4 @@
-// assoc_common.h -- shared device helpers of the association kernels (assoc_kernels.hip, munkres_lazy.hip)
+// assoc_common.h -- shared device helpers of the association kernels (assoc_kernels.hip)
 #pragma once
 #include "mot_dev.h"
 #include <float.h>
@@ -116,4 +116,3 @@ __device__ __forceinline__ int wave_list_bits(u64 w, int from, unsigned short* o
 
 } // namespace assoc
 
-hipError_t launch_munkres_lazy(const assoc::AssocArgs& a, int want_cost, hipStream_t s);

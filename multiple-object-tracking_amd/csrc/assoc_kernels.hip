@@ -12,7 +12,10 @@
 //   * the sequential part runs in ONE 1024-thread workgroup whose LDS holds the
 //     zero structure as bitmaps (n <= 1024 -> 128 KB), so "first uncovered
 //     zero in column-major order" is a ballot + ctz instead of a scan;
-//   * step 5 touches only covered rows and uncovered columns.
+//   * step 5 touches only covered rows and uncovered columns; above 512 lines it runs on 16 helper workgroups that
+//     own 64 columns each and exchange cover masks, partial minima and new zero bits with the controller workgroup
+//     as self-tagged 8-byte granules (mk_helper_loop, assoc_common.h);
+//   * below 65 lines the Munkres workgroup computes costs, minima and bitmaps itself (mk_fused_cost).
 #include "assoc_common.h"
 #include <stdlib.h>
 
@@ -362,8 +365,9 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int nhelp = HELP ? (int)gridDim.x - 1 : 0;                   // 0: everything in this workgroup
     if (HELP && blockIdx.x > 0) { if (nR > 0 && nC > 0) mk_helper_loop(a, S, nR, nC); return; }
-    if (nR <= 0 || nC <= 0) { if (tid == 0) *a.ws.cost = 0.0; for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
+    if (nR <= 0 || nC <= 0) { if (tid == 0) { *a.ws.cost = 0.0; stat[15] = 0; } for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
     if (!HELP && (want_cost & 2)) mk_fused_cost(a, S, nR, nC, rowsTrk);
+    if (tid == 0) stat[15] = 0;                                        // set again only if a helper hand-off times out
     if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
@@ -813,22 +817,16 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     if (user_dist) { maxR = nR; maxC = nC; }
     else { maxR = nT < nD ? nT : nD; maxC = nT < nD ? nD : nT; if (nT_dev) { maxR = nD < nT ? nD : nT; maxC = nD > nT ? nD : nT; } }
     if (maxR > MK_MAXN || maxC > MK_MAXN) return hipErrorInvalidValue;
-    static int use_lazy = -1;
-    if (use_lazy < 0) { const char* ev = getenv("MOT_MUNKRES_LAZY"); use_lazy = (ev && ev[0] == '1') ? 1 : 0; }
     const int lines = maxR > maxC ? maxR : maxC;
     // small problems: the Munkres workgroup computes cost, minima and bitmaps itself (mk_fused_cost)
-    const bool fused = !use_lazy && lines <= MK_FUSE_LINES;
+    const bool fused = lines <= MK_FUSE_LINES;
     hipError_t e = hipSuccess;
     if (!fused && maxR > 0 && maxC > 0) {
-        if (use_lazy) { e = hipMemsetAsync(a.linemin, 0xFF, sizeof(u64) * MK_MAXN, s); if (e != hipSuccess) return e; }   // the eager kernels re-arm it themselves
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
         hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
         hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     }
-    // default: the eager emulation below; MOT_MUNKRES_LAZY=1 selects the lazy-column variant (munkres_lazy.hip:
-    // same results, touches far fewer bytes per step 5, but its per-event bookkeeping is not yet faster end to end)
-    if (use_lazy) return launch_munkres_lazy(a, want_cost, s);
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));

@@ -276,7 +276,9 @@ int assign_device(mot_ctx* c, const bbox_t* trk, int nT, const bbox_t* det, int 
     const int nR = nT < nD ? nT : nD;
     HIPCHK(hipMemcpyAsync(c->h_assign.p, c->assoc.assignment, sizeof(int) * nR, hipMemcpyDeviceToHost, c->stream));
     if (cost_out) HIPCHK(hipMemcpyAsync(c->h_cost.p, c->assoc.cost, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_assign.p + 1024, c->assoc.status + 15, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_assign.p[1024]) return fail(MOT_ERR_DEVICE, "Munkres helper workgroups timed out (hand-off %d)", c->h_assign.p[1024]);
     if (nT < nD) { for (int i = 0; i < nT; i++) { int j = c->h_assign.p[i]; assigned_trackers[i] = j; if (j >= 0) assigned_detected[j] = i; } } // td.cpp:481-491
     else { for (int j = 0; j < nD; j++) { int i = c->h_assign.p[j]; if (i >= 0) assigned_trackers[i] = j; assigned_detected[j] = i; } }           // td.cpp:492-502
     if (cost_out) *cost_out = c->h_cost.p[0];
@@ -317,7 +319,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     c->stage_cap = cfg->max_tracks + cfg->max_dets;
     const int sc = c->stage_cap;
     HIPCHK(c->d_slots.alloc(sc)); HIPCHK(c->d_boxes_a.alloc(sc)); HIPCHK(c->d_boxes_b.alloc(sc)); HIPCHK(c->d_dets.alloc(sc));
-    HIPCHK(c->h_slots.alloc(sc)); HIPCHK(c->h_boxes_a.alloc(sc)); HIPCHK(c->h_boxes_b.alloc(sc)); HIPCHK(c->h_assign.alloc(1024)); HIPCHK(c->h_cost.alloc(1));
+    HIPCHK(c->h_slots.alloc(sc)); HIPCHK(c->h_boxes_a.alloc(sc)); HIPCHK(c->h_boxes_b.alloc(sc)); HIPCHK(c->h_assign.alloc(1024 + 1)); /* + the Munkres status word */ HIPCHK(c->h_cost.alloc(1));
     if (cfg->tracker_kind == MOT_TRACKER_KALMAN) {
         HIPCHK(c->kal_x.alloc((size_t)cfg->max_tracks * 6)); HIPCHK(c->kal_P.alloc((size_t)cfg->max_tracks * 36));
         c->kal.x = c->kal_x.p; c->kal.P = c->kal_P.p;
@@ -327,7 +329,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     const size_t mr = std::max(cfg->max_tracks, cfg->max_dets);
     const size_t mat = std::min(n2, mr * mr);
     HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024)); HIPCHK(hipMemset(c->a_linemin.p, 0xFF, 1024 * sizeof(unsigned long long)));
-    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(c->a_cost.alloc(1));
+    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(hipMemset(c->a_status.p, 0, 16 * sizeof(int))); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
     HIPCHK(c->a_ctl.alloc(MOT_ASSOC_CTL_WORDS)); HIPCHK(hipMemset(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n)); c->assoc.ctl = c->a_ctl.p;
@@ -464,7 +466,9 @@ int mot_assignment_optimal(mot_ctx* c, int* assignment, double* cost, const doub
     HIPCHK(launch_assoc(c->assoc, nullptr, nullptr, 0, nullptr, 0, c->a_user.p, nRows, nCols, 1, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_assign.p, c->assoc.assignment, sizeof(int) * nRows, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_cost.p, c->assoc.cost, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_assign.p + 1024, c->assoc.status + 15, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_assign.p[1024]) return fail(MOT_ERR_DEVICE, "Munkres helper workgroups timed out (hand-off %d)", c->h_assign.p[1024]);
     memcpy(assignment, c->h_assign.p, sizeof(int) * nRows);
     *cost = c->h_cost.p[0];
     return MOT_OK;

@@ -416,13 +416,12 @@ for n in (64, 300, 1024):
     at, ad, cost = c.assign(trk, det)
     ra, rc = orc.assignment_optimal(lib, orc.cost_matrix(lib, trk, det), n, n)
     assert np.array_equal(ad, ra) and cost == rc, n
-lazy = os.environ.get("MOT_MUNKRES_LAZY") == "1"
-for n in ((257,) if lazy else (257, 520, 1024)):            # dense uniform costs: hundreds of step-5 passes with hundreds of uncovered columns
+for n in (257, 520, 1024):            # dense uniform costs: hundreds of step-5 passes with hundreds of uncovered columns
     d = rng.uniform(0, 1, size=n * n)
     a, cost = c.assignment_optimal(d, n, n)
     ra, rc = orc.assignment_optimal(lib, d, n, n)
     assert np.array_equal(a, ra) and cost == rc, ("uniform", n)
-    assert lazy or c.assoc_stats()[15] == 0, ("helper protocol timed out", n)
+    assert c.assoc_stats()[15] == 0, ("helper protocol timed out", n)
 d = rng.uniform(0, 1, size=700 * 400)  # rectangular, both orientations
 for nr, nc in ((700, 400), (400, 700)):
     a, cost = c.assignment_optimal(d, nr, nc)
@@ -437,12 +436,6 @@ def _run_variant(env_extra):
     env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, "-c", _VARIANT_CODE], cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert "VARIANT_OK" in out.stdout, out.stdout + out.stderr
-
-
-def test_munkres_lazy_variant_subprocess():
-    """the lazy-column Munkres kernel (MOT_MUNKRES_LAZY=1, csrc/munkres_lazy.hip) must give the same bit-exact
-    assignments; the switch is read once per process, so it runs in a child process."""
-    _run_variant({"MOT_MUNKRES_LAZY": "1"})
 
 
 @pytest.mark.parametrize("helpers", ["0", "1"])
