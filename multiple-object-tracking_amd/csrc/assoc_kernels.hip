@@ -804,7 +804,7 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
 }
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
-                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s)
+                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid)
 {
     AssocArgs a;
     a.trk = trk; a.det = det; a.nT_dev = nT_dev; a.nT = nT; a.nD = nD;
@@ -827,6 +827,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
         hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     }
+    if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }   // cost kernels submitted, the Munkres kernel comes next
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));

@@ -827,19 +827,23 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
     float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int slot = l.slots[item];
+    const bool feat_only = l.spec_out != nullptr;                      // launch-uniform
+    const int slot = feat_only ? 0 : l.slots[item];
     const bbox_t box = l.boxes_in[item];
-    const int first = p.first_update[slot];
+    const int first = feat_only ? 1 : p.first_update[slot];
     float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
     const int tot = MOT_NCHAN * p.nbins;
+    // split mode: this track's detection already has its spectra in HBM (workgroup-uniform)
+    const int dj = (!feat_only && l.det_index) ? l.det_index[item] : -1;
+    const float2* dspec = dj >= 0 ? l.det_spec + (size_t)dj * tot : nullptr;
     // old model values do not depend on this frame: load them now (<= 16 independent loads per thread)
     const bool pre = kLds && tot <= 16 * nt;
     float2 xold[16];
-    if (pre) {
+    if (pre && !dspec) {
 #pragma unroll
         for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
     }
-    features_prepare(p, l, item, box, r, tid, nt, stage);
+    if (!dspec) features_prepare(p, l, item, box, r, tid, nt, stage);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -848,6 +852,12 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
     // per half: kf partial sums, then kcf_update_xf (kcf.cpp:380-395) for the channels of this half
 #define UPDATE_HALF(C0, C1)                                                                                      \
     do {                                                                                                          \
+        if (dspec) S = dspec + (size_t)(C0) * p.nbins;                                                            \
+        if (feat_only) {                                                                                          \
+            float2* so = l.spec_out + (size_t)item * tot + (size_t)(C0) * p.nbins;                                \
+            for (int i = tid; i < ((C1) - (C0)) * p.nbins; i += nt) so[i] = S[i];                                 \
+            break;                                                                                                \
+        }                                                                                                         \
         if (p.nbins <= nt) {                                                                                      \
             if (tid < p.nbins) for (int ch = (C0); ch < (C1); ch++) { const float2 a = S[(ch - (C0)) * p.nbins + tid]; kf = (a.x * a.x + a.y * a.y) + kf; } \
         } else {                                                                                                  \
@@ -868,15 +878,37 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
                 m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y; xm[i] = m; }                    \
         }                                                                                                         \
     } while (0)
-    half_spectrum<0>(p, l, item, r, tid, nt, true, stage);
+    if (dspec && pre) {
+        // blend-only fast path: everything streams from HBM, all loads of a thread in flight at once (same arithmetic
+        // and order as the macro below: kf over ch = 0..30, then kcf_update_xf)
+        const int bq = min(tid, p.nbins - 1);
+#pragma unroll
+        for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + bq]; kf = (a.x * a.x + a.y * a.y) + kf; }
+#pragma unroll
+        for (int j0 = 0; j0 < 16; j0 += 8) {                          // 16 loads in flight, twice
+            float2 a8[8], m8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int i = min(tid + (j0 + j) * nt, tot - 1); a8[j] = dspec[i]; m8[j] = first ? make_float2(0.f, 0.f) : xm[i]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = tid + (j0 + j) * nt;
+                if (i < tot) { float2 m = m8[j]; m.x = keep * m.x + factor * a8[j].x; m.y = keep * m.y + factor * a8[j].y; xm[i] = m; }
+            }
+        }
+    } else {
+    if (!dspec) half_spectrum<0>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     UPDATE_HALF(0, MOT_HALF0);
-    __syncthreads();
-    half_spectrum<1>(p, l, item, r, tid, nt, true, stage);
+    if (!dspec) {
+        __syncthreads();
+        half_spectrum<1>(p, l, item, r, tid, nt, true, stage);
+    }
     DBG_STAMP(6);
     UPDATE_HALF(MOT_HALF0, MOT_NCHAN);
+    }
 #undef UPDATE_HALF
     (void)tot0;
+    if (feat_only) return;
     // kcf_update_alpha (kcf.cpp:364-378)
     for (int b = tid; b < p.nbins; b += nt) {
         float kq = (p.nbins <= nt) ? kf : r.tmp[b].x;
@@ -995,10 +1027,13 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
+hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu)
 {
     if (n <= 0) return hipSuccess;
-    const size_t lds = kcf_lds_bytes(p);
+    size_t lds = kcf_lds_bytes(p);
+    // exclusive_cu: ask for more than half of a CU's LDS so that no second workgroup (of this or of a concurrently running
+    // KCF kernel) is placed on the same CU
+    if (exclusive_cu && lds < MOT_LDS_LIMIT / 2 + 2048) lds = MOT_LDS_LIMIT / 2 + 2048;
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_update_kernel<true>, lds); if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);

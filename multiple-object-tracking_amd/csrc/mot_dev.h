@@ -66,6 +66,11 @@ struct KcfLaunch {
     float* feat_out;          // debug: [n][32][nb] FHOG (optional)
     int feat_windowed;
     long long* dbg;           // debug: phase time stamps of workgroup 0 (100 MHz ticks), or null
+    // update kernel, split mode (device-resident loop): the features of every DETECTION box are computed once, while the
+    // association runs, and the per-track update only blends them into the model
+    float2* spec_out;         // feature-only launch: [n][31][nbins] spectra of boxes_in[item] are written here, no model update
+    const float2* det_spec;   // blend launch: spectra written by a feature-only launch ...
+    const int* det_index;     // ... and [n] the detection whose spectrum item uses (-1: compute from boxes_in[item] as usual)
 };
 
 struct KalmanPool {
@@ -87,7 +92,7 @@ struct AssocWs {
 
 // host-side launchers implemented in the .hip files
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
-hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
+hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu = false);
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
 hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s);
 size_t kcf_lds_bytes(const KcfPool& p);
@@ -98,5 +103,5 @@ hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int
 hipError_t launch_kalman_init(const KalmanPool& p, const int* slots, int n, const bbox_t* boxes, hipStream_t s);
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
-                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s);
+                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid = nullptr);   // ev_mid: recorded between the cost kernels and the Munkres kernel
 hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int nD, double* dist_out, hipStream_t s);

@@ -16,12 +16,17 @@ using namespace mot_impl;
 
 namespace {
 
+// split update: detection features start beside the predict when predict + feature workgroups fit the chip at 2 per CU
+#define MOT_SPLIT_EARLY_MAX 512
+#define MOT_SPLIT_EXCL_MAX 256    // ... and one per CU (no sharing with predict workgroups) while they all fit that way
+
 struct DLState {
     int* nlive; unsigned* next_tid; int* nfree; int* free_slots;
     int* slot; unsigned* tid; int* age; int* vis; int* inv; bbox_t* bbox;   // [cap] live list, td.cpp order
     int* rankpos;                 // [cap] index inside the owner's all-gather segment
     int* loc_slots; int* loc_count;
     int* upd_slots; bbox_t* upd_boxes; int* upd_count;
+    int* upd_det;                 // [cap + max_dets] detection whose box an update item adopts (-1: the predicted box, td.cpp:540-560)
     bbox_t* pred;                 // [cap] predicted boxes in live order
     bbox_t* gather;               // [world*spr] all-gather buffer (own segment written by predict)
     int* err;                     // [4]: spawns dropped for template-size mismatch, capacity drops, pool exhausted, -
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(1024) dl_lifecycle_kernel(DLState S, KcfPool k
         keep = !lost;
         mine = ((int)(tid % (unsigned)S.world) == S.rank);
         if (mine) {
-            if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; }
+            if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; }
             else { const int q = atomicAdd(&cnt[1], 1); S.free_slots[q] = slot; }   // tracker_delete (td.cpp:599)
         }
     }
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(1024) dl_lifecycle_kernel(DLState S, KcfPool k
             if (ns >= 0) {
                 if (S.kind == MOT_TRACKER_KCF) {
                     kp.pos[ns] = db; kp.scale[ns] = make_float2(1.f, 1.f); kp.first_update[ns] = 1;     // kcf.cpp:200-210
-                    const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = ns; S.upd_boxes[q] = db;       // first update, td.cpp:631-640
+                    const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = ns; S.upd_boxes[q] = db; S.upd_det[q] = t;   // first update, td.cpp:631-640
                 } else {
                     const double v[6] = { (double)db.l, (double)db.t, (double)db.r, (double)db.b, 0.0, 0.0 }; // kalman.cpp:152-157
                     for (int q = 0; q < 6; q++) kal.x[(size_t)ns * 6 + q] = v[q];
@@ -165,12 +170,20 @@ struct DevLoop {
     DevBuf<int> ints; DevBuf<bbox_t> boxes; DevBuf<unsigned> tids;
     bool begun = false; const void* frame = nullptr;
     hipEvent_t ev[8]{}; bool ev_ok = false;
+    // split update (KCF): the spectra of all detection boxes are computed on a second, low-priority stream while the
+    // association runs; the per-track update then only blends them into the model
+    DevBuf<float2> det_spec; hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr; bool split = false;
+    bool feat_early = false;      // this frame's detection features were launched at the start of the frame
 };
 
 void devloop_destroy(DevLoop* d)
 {
     if (!d) return;
     if (d->ev_ok) for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
+    if (d->ev_feat) (void)hipEventDestroy(d->ev_feat);
+    if (d->ev_upd) (void)hipEventDestroy(d->ev_upd);
+    if (d->side) (void)hipStreamDestroy(d->side);
     delete d;
 }
 
@@ -189,14 +202,14 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     S.rows = c->cfg.dev_rows > 0 ? c->cfg.dev_rows : 80; S.cols = c->cfg.dev_cols > 0 ? c->cfg.dev_cols : 80;
     if (S.kind == MOT_TRACKER_KCF) { int rc = get_pool(c, S.rows, S.cols, &d->pool); if (rc) return rc; }
     // one int arena: nlive, next_tid(as tids), nfree, loc_count, upd_count, err[4], then arrays
-    const size_t nints = 16 + (size_t)cap * 8 + (size_t)(cap + md) + 64;
+    const size_t nints = 16 + (size_t)cap * 8 + 2 * (size_t)(cap + md) + 64;
     HIPCHK(d->ints.alloc(nints)); HIPCHK(hipMemsetAsync(d->ints.p, 0, nints * sizeof(int), c->stream));
     HIPCHK(d->tids.alloc((size_t)cap + 4)); HIPCHK(hipMemsetAsync(d->tids.p, 0, (cap + 4) * sizeof(unsigned), c->stream));
     HIPCHK(d->boxes.alloc((size_t)cap * 2 + cap + md + 8)); HIPCHK(hipMemsetAsync(d->boxes.p, 0, d->boxes.n * sizeof(bbox_t), c->stream));
     int* ip = d->ints.p;
     S.nlive = ip; S.nfree = ip + 1; S.loc_count = ip + 2; S.upd_count = ip + 3; S.err = ip + 4; ip += 16;
     S.free_slots = ip; ip += cap; S.slot = ip; ip += cap; S.age = ip; ip += cap; S.vis = ip; ip += cap; S.inv = ip; ip += cap;
-    S.rankpos = ip; ip += cap; S.loc_slots = ip; ip += cap; S.upd_slots = ip; ip += cap + md;
+    S.rankpos = ip; ip += cap; S.loc_slots = ip; ip += cap; S.upd_slots = ip; ip += cap + md; S.upd_det = ip; ip += cap + md;
     S.next_tid = d->tids.p; S.tid = d->tids.p + 4;
     S.bbox = d->boxes.p; S.pred = S.bbox + cap; S.upd_boxes = S.pred + cap;
     S.gather = c->d_gather.p;
@@ -206,14 +219,29 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     HIPCHK(hipMemcpyAsync(S.free_slots, fs.data(), sizeof(int) * cap, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(S.nfree, &cap, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (S.kind == MOT_TRACKER_KCF) { c->pools[d->pool]->free_slots.clear(); }   // the device owns the pool now
+    if (S.kind == MOT_TRACKER_KCF) {
+        c->pools[d->pool]->free_slots.clear();                           // the device owns the pool now
+        const char* ev = getenv("MOT_SPLIT_UPDATE");                     // default on; 0 keeps the fused update kernel
+        if (!ev || atoi(ev) != 0) {
+            const KcfPool& kp = c->pools[d->pool]->dev;
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // lo = numerically largest = lowest priority
+            HIPCHK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_mid, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_feat, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_upd, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(d->ev_upd, c->stream));
+            HIPCHK(d->det_spec.alloc((size_t)md * MOT_NCHAN * kp.nbins));
+            d->split = true;
+        }
+    }
     else c->kal_free.clear();
     c->devloop = d.release();
     *out = c->devloop;
     return MOT_OK;
 }
 
-int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev)
+int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, const void* dets_dev = nullptr, int nD = 0)
 {
     DLState& S = d->S;
     if (d->begun) return fail(MOT_ERR_STATE, "mot_step_begin_device called twice");
@@ -221,6 +249,16 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev)
     d->frame = frame_dev;
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
     if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
+    d->feat_early = false;
+    if (d->split && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= MOT_SPLIT_EARLY_MAX) {
+        // small frames leave most CUs idle during the predict: the detection features run beside it (they only need the
+        // frame and the boxes); the spectra buffer is free once the previous frame's update has finished
+        HIPCHK(hipStreamWaitEvent(d->side, d->ev_upd, 0));
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = d->det_spec.p;
+        HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
+        HIPCHK(hipEventRecord(d->ev_feat, d->side));
+        d->feat_early = true;
+    }
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
         HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
@@ -240,16 +278,27 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const bbox_t* trk = g;
     if (S.world > 1) { hipLaunchKernelGGL(dl_scatter_kernel, dim3(1), dim3(1024), 0, c->stream, S, g); HIPCHK(hipGetLastError()); trk = S.pred; }
     const bbox_t* dets = (const bbox_t*)dets_dev;
-    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream));
-    if (ev) HIPCHK(hipEventRecord(ev[2], c->stream));
     KcfPool kp{}; if (S.kind == MOT_TRACKER_KCF) kp = c->pools[d->pool]->dev;
+    const bool split = d->split && S.kind == MOT_TRACKER_KCF && nD > 0;
+    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (split && !d->feat_early) ? d->ev_mid : nullptr));
+    if (split && !d->feat_early) {
+        // features of every detection box, on the side stream, from the moment the Munkres kernel has been handed to the
+        // dispatcher (so its 17 workgroups are placed first); the frame and the boxes are inputs of this call
+        HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->frame; lf.boxes_in = dets; lf.spec_out = d->det_spec.p;
+        HIPCHK(launch_kcf_update(kp, lf, nD, d->side));
+        HIPCHK(hipEventRecord(d->ev_feat, d->side));
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[2], c->stream));
     hipLaunchKernelGGL(dl_lifecycle_kernel, dim3(1), dim3(1024), 0, c->stream, S, kp, c->kal, trk, dets, nD, c->assoc.assignment);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev[3], c->stream));
     const int upd_max = S.spr + nD;
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
+        if (split) { HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = d->det_spec.p; l.det_index = S.upd_det; }
         HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
+        if (split) HIPCHK(hipEventRecord(d->ev_upd, c->stream));
     } else HIPCHK(launch_kalman_update(c->kal, S.upd_slots, S.upd_count, upd_max, S.upd_boxes, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[4], c->stream));
     return MOT_OK;
@@ -283,7 +332,7 @@ int mot_step_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_de
     if (c->cfg.world != 1) return fail(MOT_ERR_STATE, "sharded context: use mot_step_begin_device / all-gather / mot_step_finish_device");
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
-    rc = dl_begin(c, d, frame_dev, nullptr); if (rc) return rc;
+    rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
     return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
 }
 
@@ -294,7 +343,7 @@ int mot_profile_frame_device(mot_ctx* c, const void* frame_dev, const void* dets
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
     if (!d->ev_ok) { for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i])); d->ev_ok = true; }
-    rc = dl_begin(c, d, frame_dev, d->ev); if (rc) return rc;
+    rc = dl_begin(c, d, frame_dev, d->ev, dets_dev, nD); if (rc) return rc;
     rc = dl_finish(c, d, nullptr, dets_dev, nD, d->ev); if (rc) return rc;
     HIPCHK(hipEventSynchronize(d->ev[4]));
     // [0] predict  [1] cost/min/sub + munkres (see note)  [2] munkres -- reported together in [1], [2]=0  [3] lifecycle  [4] update

@@ -92,3 +92,15 @@ def test_device_loop_steady_1024(mot):
     last = {tuple(int(v) for v in d[:4]) for d in dets[-1]}
     assert all(tuple(int(v) for v in bnp(boxes)[i][:4]) in last for i in range(1024))
     c.close()
+
+
+def test_device_loop_fused_update_subprocess():
+    """MOT_SPLIT_UPDATE=0 keeps the single fused update kernel (features + model update in one launch, no side stream);
+    the default splits it into detection features beside the association and a blend.  Both must reproduce the oracle:
+    the switch is read when the device loop is created, so the fused variant runs in a child process."""
+    import subprocess, sys
+    env = dict(os.environ, MOT_SPLIT_UPDATE="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(orc.ROOT, "tests", "test_gpu_devloop.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "test_device_loop_vs_oracle or test_device_loop_sharded_two_ranks"],
+                         cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
