@@ -39,7 +39,9 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/
 def alg_bytes(size):
     nb = (size // 4) * ((size // 4) // 2 + 1)
     crop = size * size * 3
-    return {"predict": crop + 31 * nb * 8 + nb * 4 + 48, "update": crop + 2 * 31 * nb * 8 + 2 * nb * 4 + 24}
+    return {"predict": crop + 31 * nb * 8 + nb * 4 + 48, "update": crop + 2 * 31 * nb * 8 + 2 * nb * 4 + 24,
+            # split update (default in the device loop): spectrum of the detection read once, model read + written, alpha r/w
+            "blend": 3 * 31 * nb * 8 + 3 * nb * 4 + 24}
 
 
 def gen_stream(n_tracks, size, n_frames, stream_id=0):
@@ -248,7 +250,7 @@ def main():
             per_launch = ab["update" if dom == "kcf_update" else "predict"] * n_live
             dur_s = kern[dom] * 1e-3
             achieved = per_launch / dur_s / 1e9
-            traffic = None
+            traffic = None; tj = {}
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath):
                 try:
@@ -259,6 +261,14 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "alg_bytes_per_launch": per_launch, "avg_launch_ms": kern[dom]}
+            if os.environ.get("MOT_SPLIT_UPDATE", "1") != "0":
+                # the update stage is the HBM-bound blend of the split update (its feature half runs beside the association)
+                bb = ab["blend"] * n_live
+                out["roofline_blend"] = {"bound": "hbm", "kernel": "kcf_update (blend launch)", "achieved": bb / (kern["kcf_update"] * 1e-3) / 1e9,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bb / (kern["kcf_update"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "traffic": (tj.get(f"kcf_update_blend_bytes_per_launch_n{n_tracks}") if traffic is not None else None),
+                                         "alg_bytes_per_launch": bb, "avg_launch_ms": kern["kcf_update"],
+                                         "note": "stage time between HIP events incl. the dispatch gap; the kernel alone is shorter (profiles/)"}
             out["kernel_ms"] = {k: float(v) for k, v in kern.items()}
             out["hbm_frac_whole_frame"] = (ab["predict"] + ab["update"]) * n_live / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:

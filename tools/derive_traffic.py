@@ -19,6 +19,10 @@ def med(path, counter):
                 if key in name:
                     per.setdefault(key, []).append(float(row["Counter_Value"]))
                     break
+    # split update (device loop): every frame launches kcf_update twice, first the detection features, then the blend
+    if "kcf_update" in per and "kcf_predict" in per and len(per["kcf_update"]) >= 2 * len(per["kcf_predict"]) - 2:
+        u = per.pop("kcf_update")
+        per["kcf_update_features"], per["kcf_update_blend"] = u[0::2], u[1::2]
     return {k: statistics.median(v) for k, v in per.items()}
 
 def main():
@@ -28,7 +32,7 @@ def main():
                    f"--no-cpu-baseline --profile-frames 0, {n} tracks; median per launch, KiB. bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                    "(gfx950: FETCH_SIZE reports 1/2 of streamed read bytes, MI355X_MICROARCH.md)",
            "raw_kib": raw}
-    for k in ("kcf_predict", "kcf_update"):
+    for k in ("kcf_predict", "kcf_update", "kcf_update_features", "kcf_update_blend"):
         if k in fetch and k in write:
             out[f"{k}_bytes_per_launch_n{n}"] = int((2 * fetch[k] + write[k]) * 1024)
     json.dump(out, sys.stdout, indent=1); print()
