@@ -555,7 +555,8 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 found_in_sweep = true;
                 from = col + 1;                                        // the sweep continues with the next column (:273)
             }
-            if (action == 2) { const int ncu = wave_list_bits(~cC & vC, 0, S.list, lane); if (lane == 0) S.flag[1] = ncu; }
+            // list of the uncovered columns for step 5 (with helper workgroups it is built after the publish, off the critical path)
+            if (action == 2 && !(HELP && nhelp > 0)) { const int ncu = wave_list_bits(~cC & vC, 0, S.list, lane); if (lane == 0) S.flag[1] = ncu; }
             if (lane == 0) S.flag[0] = action;
         }
         __syncthreads();
@@ -566,10 +567,9 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         // ================= step 5 (:337-368): one row per thread =================
         n_s5++;
         if (HELP && nhelp > 0) {
-            // ---- step 5 on the helper workgroups: wave 0 publishes the cover masks, collects the minimum, publishes h
-            // and waits for the new zero bits; the other waves wait at the barrier in front of the merge ----
-            const int ncu = S.flag[1];
-            if (n_s5 == 1) ncu0 = ncu;
+            // ---- step 5 on the helper workgroups: wave 0 publishes the cover masks and waits until every helper has
+            // published its partial minimum (the helpers take h = min of the 16 themselves); then all waves poll and merge
+            // the new zero bits ----
             ++myseq;
             if (uwave == 0) {
                 // the slots re-armed during the previous step 5 must have landed before anybody can act on this publish
@@ -580,27 +580,26 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                     ctl_st(ctl + CTL_COV + lane, ((lane & 1) ? src >> 32 : src & 0xFFFFFFFFull) | ((u64)(epoch + myseq) << 32));
                 }
                 const long long tq0 = wall_clock64(); t_h0 += tq0 - t_b;
-                // covered rows, ascending (for the merge); overlaps the helpers' phase A
+                // uncovered columns and covered rows, ascending (for the merge); overlaps the helpers' phase A
+                const int ncu_l = wave_list_bits(~cC & vC, 0, S.list, lane);
                 const int ncr = wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);
-                if (lane == 0) S.flag[2] = ncr;
+                if (lane == 0) { S.flag[1] = ncu_l; S.flag[2] = ncr; }
                 int spins = 0; bool lost = false;
                 u64 hk;
-                for (;;) {                                              // every helper's partial minimum is its own arrival flag
+                for (;;) {                                              // the granules of this step cannot arrive before all 16 partial minima exist
                     hk = (lane < nhelp) ? ctl_ld(ctl + CTL_PARTIAL + ((myseq & 1) * MK_HELPERS + lane) * MK_PARTIAL_STRIDE) : 0;
                     if (!__ballot(hk == MK_HSENT)) break;
                     if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (lane >= nhelp) hk = ~0ull;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(hk, off); if (o < hk) hk = o; }
                 const long long tq1 = wall_clock64(); t_h1 += tq1 - tq0;
                 if (lost && lane == 0) { stat[15] = 1; S.flag[7] = 1; }
             }
             __syncthreads();
             if (S.flag[7]) break;                                      // helpers lost: give up (status[15] != 0)
             const long long tq2 = wall_clock64();
-            const int ncr = S.flag[2];
+            const int ncu = S.flag[1], ncr = S.flag[2];
+            if (n_s5 == 1) ncu0 = ncu;
             // ---- collect + merge: every thread polls exactly the tagged granules it merges.  Uncovered columns get their
             // complete new words (BMOUT); covered columns only the covered rows' bits (COVBITS). ----
             {
