@@ -640,9 +640,19 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         const u64 hi = __shfl_down(bv[j], 1);           // lane pairs: even lane = low half, odd lane = high half
-                        if (hb[j] && !(lane & 1)) {
+                        const u64 word = (bv[j] & 0xFFFFFFFFull) | (hi << 32);
+                        const bool mineW = hb[j] && !(lane & 1);
+                        if (mineW) {
                             const int gi = (rd * 2 + j) * MK_THREADS + tid;
-                            S.bm[S.list[bk[j]] * MK_MAXW + ((gi & 31) >> 1)] = (bv[j] & 0xFFFFFFFFull) | (hi << 32);
+                            S.bm[S.list[bk[j]] * MK_MAXW + ((gi & 31) >> 1)] = word;
+                        }
+                        // hz ("the column may hold a zero") of the two columns this wave instruction covers: exact again
+                        const u64 nzb = __ballot(mineW && word != 0);
+                        if ((lane & 31) == 0 && hb[j]) {
+                            const int c = S.list[bk[j]];
+                            unsigned int* wp = reinterpret_cast<unsigned int*>(&S.hz[c >> 6]) + ((c & 63) >> 5);
+                            const unsigned int bit = 1u << (c & 31);
+                            if ((lane ? nzb >> 32 : nzb & 0xFFFFFFFFull) != 0) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
                         }
                     }
                     if (wcov && nrow > 0) {
@@ -665,16 +675,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             __syncthreads();
             if (S.flag[7]) break;
             const long long tq3 = wall_clock64();
-            __syncthreads();
-            {   // rebuild hz for the uncovered columns (their entries just changed)
-                const bool unc = tid < nC && !((S.covC[wave] >> lane) & 1);
-                bool has = false;
-                if (unc) for (int w = 0; w < wordsR; w++) has |= S.bm[tid * MK_MAXW + w] != 0;
-                const u64 bal = __ballot(has);
-                if (lane == 0) S.hz[wave] = (S.hz[wave] & S.covC[wave]) | bal;
-            }
-            __syncthreads();
-            if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
+            if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;      // updated column by column during the merge
             t_h3 += wall_clock64() - tq3;
         } else {
             const int ncu = S.flag[1];
