@@ -1,0 +1,54 @@
+"""CPU checks of the measurement plumbing: algorithmic byte counts, the PMC -> traffic derivation
+on the committed counter files, and the shape of the committed bench line (the contract bench.py has to keep)."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import orc
+
+ROOT = orc.ROOT
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_bytes_match_baseline():
+    bench = _load(os.path.join(ROOT, "bench.py"), "bench_mod")
+    ab = bench.alg_bytes(80)
+    assert ab["predict"] == 19200 + 54560 + 880 + 48                    # u8 crop + xm + alpha + pos in / box out
+    assert ab["update"] == 19200 + 2 * 54560 + 2 * 880 + 24
+    assert ab["predict"] + ab["update"] == 204792
+    assert ab["blend"] == 3 * 54560 + 3 * 880 + 24                      # spectrum read, model read + write, alpha
+
+
+def test_traffic_derivation_on_committed_counters():
+    prof = os.path.join(ROOT, "profiles")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "derive_traffic.py"),
+                          os.path.join(prof, "r01_pmc_fetch_size.csv"), os.path.join(prof, "r01_pmc_write_size.csv"), "1024"],
+                         capture_output=True, text=True, check=True)
+    tj = json.loads(out.stdout)
+    committed = json.load(open(os.path.join(prof, "r01_traffic.json")))
+    assert tj == committed
+    alg_predict = 1024 * (19200 + 54560 + 880 + 48)
+    # measured HBM traffic of the predict launch is within 5 % of the algorithmic bytes (no wasted re-reads)
+    assert 1.0 <= tj["kcf_predict_bytes_per_launch_n1024"] / alg_predict < 1.05
+
+
+def test_committed_bench_line_keeps_the_contract():
+    j = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_n1024.json")).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert abs(j["value"] - j["config"]["live_tracks_end"] * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) / j["value"] < 1e-6
