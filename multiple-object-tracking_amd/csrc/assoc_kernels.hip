@@ -17,6 +17,7 @@
 //     as self-tagged 8-byte granules (mk_helper_loop, assoc_common.h);
 //   * below 65 lines the Munkres workgroup computes costs, minima and bitmaps itself (mk_fused_cost).
 #include "assoc_common.h"
+#include "dl_lifecycle.h"
 #include <stdlib.h>
 
 using namespace assoc;
@@ -352,7 +353,7 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
 // HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
 // HELP = true : launched with 1 + MK_HELPERS workgroups; workgroups 1.. run mk_helper_loop.
 template <bool HELP>
-__global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost)
+__global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char mk_raw[];
     MkShared& S = *reinterpret_cast<MkShared*>(mk_raw);
@@ -365,7 +366,12 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int nhelp = HELP ? (int)gridDim.x - 1 : 0;                   // 0: everything in this workgroup
     if (HELP && blockIdx.x > 0) { if (nR > 0 && nC > 0) mk_helper_loop(a, S, nR, nC); return; }
-    if (nR <= 0 || nC <= 0) { if (tid == 0) { *a.ws.cost = 0.0; stat[15] = 0; } for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1; return; }
+    if (nR <= 0 || nC <= 0) {
+        if (tid == 0) { *a.ws.cost = 0.0; stat[15] = 0; }
+        for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1;
+        if (life.enabled) { __syncthreads(); dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, reinterpret_cast<int*>(S.bm) + 4096); }
+        return;
+    }
     if (!HELP && (want_cost & 2)) mk_fused_cost(a, S, nR, nC, rowsTrk);
     if (tid == 0) stat[15] = 0;                                        // set again only if a helper hand-off times out
     if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
@@ -782,6 +788,11 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         __syncthreads();
         if (tid == 0) { double cst = 0.0; for (int r = 0; r < nR; r++) if (S.starColOfRow[r] >= 0) cst += vals[r]; *a.ws.cost = cst; }
     }
+    // device-resident loop: the lifecycle step (td.cpp:472-644) runs here instead of in a launch of its own
+    if (life.enabled) {
+        __syncthreads();                                               // the assignment vector is complete (same workgroup wrote it)
+        dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, reinterpret_cast<int*>(S.bm) + 4096);
+    }
 }
 
 __global__ void assoc_cost_kernel(AssocArgs a)
@@ -804,8 +815,9 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
 }
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
-                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid)
+                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid, const LifeArgs* life_in)
 {
+    LifeArgs life{}; if (life_in) life = *life_in;
     AssocArgs a;
     a.trk = trk; a.det = det; a.nT_dev = nT_dev; a.nT = nT; a.nD = nD;
     a.user = user_dist; a.userR = nR; a.userC = nC;
@@ -842,7 +854,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     static int helpers = -1;
     if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
     const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN));
-    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost);
-    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0));
+    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life);
+    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life);
     return hipGetLastError();
 }

@@ -103,5 +103,6 @@ hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int
 hipError_t launch_kalman_init(const KalmanPool& p, const int* slots, int n, const bbox_t* boxes, hipStream_t s);
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
-                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid = nullptr);   // ev_mid: recorded between the cost kernels and the Munkres kernel
+                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid = nullptr,
+                        const struct LifeArgs* life = nullptr);   // life: run the device loop's lifecycle step as the kernel's tail (dl_lifecycle.h)   // ev_mid: recorded between the cost kernels and the Munkres kernel
 hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int nD, double* dist_out, hipStream_t s);

@@ -4,13 +4,14 @@
 // synchronisation or copy: the live-track list (tracker_info[] of td.cpp:312),
 // its counters and the lifecycle rules live in HBM and are advanced by one
 // single-workgroup kernel per frame.  Per frame (one GPU):
-//     kcf_predict (1 WG/track) -> assoc_min -> assoc_sub -> munkres (1 WG)
-//     -> dl_lifecycle (1 WG) -> kcf_update (1 WG/track)
+//     kcf_predict (1 WG/track) -> assoc_min -> assoc_sub -> munkres (+ the lifecycle step as its tail,
+//     dl_lifecycle.h) -> kcf_update (1 WG/track; split into detection features + blend, see DevLoop)
 // With world > 1 the predicted boxes of the local shard are written into this
 // rank's segment of an all-gather buffer (mot_step_begin_device), the caller
 // runs ONE ncclAllGather, and mot_step_finish_device continues; association and
 // lifecycle are replicated (deterministic) on every rank.
 #include "mot_ctx.h"
+#include "dl_lifecycle.h"
 
 using namespace mot_impl;
 
@@ -20,54 +21,6 @@ namespace {
 #define MOT_SPLIT_EARLY_MAX 512
 #define MOT_SPLIT_EXCL_MAX 256    // ... and one per CU (no sharing with predict workgroups) while they all fit that way
 
-struct DLState {
-    int* nlive; unsigned* next_tid; int* nfree; int* free_slots;
-    int* slot; unsigned* tid; int* age; int* vis; int* inv; bbox_t* bbox;   // [cap] live list, td.cpp order
-    int* rankpos;                 // [cap] index inside the owner's all-gather segment
-    int* loc_slots; int* loc_count;
-    int* upd_slots; bbox_t* upd_boxes; int* upd_count;
-    int* upd_det;                 // [cap + max_dets] detection whose box an update item adopts (-1: the predicted box, td.cpp:540-560)
-    bbox_t* pred;                 // [cap] predicted boxes in live order
-    bbox_t* gather;               // [world*spr] all-gather buffer (own segment written by predict)
-    int* err;                     // [4]: spawns dropped for template-size mismatch, capacity drops, pool exhausted, -
-    int cap, max_dets, rank, world, spr, rows, cols, kind;
-};
-
-__device__ __forceinline__ int block_excl_scan_flag(bool flag, int* wave_tot, int& total)
-{   // exclusive prefix count of `flag` over a 1024-thread workgroup
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(flag);
-    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (lane == 0) wave_tot[wave] = __popcll(bal);
-    __syncthreads();
-    int off = 0; total = 0;
-    for (int w = 0; w < 16; w++) { const int t = wave_tot[w]; if (w < wave) off += t; total += t; }
-    return off + pre;
-}
-
-// builds rankpos[] and this rank's predict list for the CURRENT live list
-__device__ void dl_build_lists(const DLState& S, int n, int* wave_tot)
-{
-    const int t = threadIdx.x;
-    const unsigned mytid = (t < n) ? S.tid[t] : 0u;
-    const int r = (t < n) ? (int)(mytid % (unsigned)S.world) : -1;
-    int mine_total = 0;
-    for (int rk = 0; rk < S.world; rk++) {
-        int total;
-        const int pos = block_excl_scan_flag(r == rk, wave_tot, total);
-        if (r == rk) {
-            S.rankpos[t] = pos;
-            if (rk == S.rank) {
-                S.loc_slots[pos] = S.slot[t];
-                if (S.kind == MOT_TRACKER_KALMAN) S.gather[(size_t)S.rank * S.spr + pos] = S.bbox[t];   // predict is in/out (kalman.cpp:112-115)
-            }
-        }
-        if (rk == S.rank) mine_total = total;
-    }
-    if (t == 0) *S.loc_count = mine_total;
-}
-
 __global__ void __launch_bounds__(1024) dl_scatter_kernel(DLState S, const bbox_t* gathered)
 {   // gathered segments -> live order (world > 1)
     const int n = *S.nlive, t = threadIdx.x;
@@ -75,89 +28,6 @@ __global__ void __launch_bounds__(1024) dl_scatter_kernel(DLState S, const bbox_
         const int r = (int)(S.tid[t] % (unsigned)S.world);
         S.pred[t] = gathered[(size_t)r * S.spr + S.rankpos[t]];
     }
-}
-
-__global__ void __launch_bounds__(1024) dl_lifecycle_kernel(DLState S, KcfPool kp, KalmanPool kal, const bbox_t* trk_pred,
-                                                            const bbox_t* dets, int nD, const int* assignment)
-{
-    __shared__ int at[1024], ad[1024];
-    __shared__ int wave_tot[16];
-    __shared__ int cnt[4];            // [0] update list, [1] free stack top
-    const int t = threadIdx.x;
-    const int nT = *S.nlive;
-    if (t == 0) { cnt[0] = 0; cnt[1] = *S.nfree; }
-    at[t] = -1; ad[t] = -1;
-    __syncthreads();
-    // td.cpp:472-502 -- scatter of the assignment vector (rows = the smaller side, td.cpp:462-469)
-    if (nT > 0 && nD > 0) {
-        if (nT < nD) { if (t < nT) { const int j = assignment[t]; at[t] = j; if (j >= 0) ad[j] = t; } }
-        else { if (t < nD) { const int i = assignment[t]; if (i >= 0) at[i] = t; ad[t] = i; } }
-    }
-    __syncthreads();
-    // td.cpp:512-582 (counters, update box) and :585-609 (lost rule)
-    int slot = -1, age = 0, vis = 0, inv = 0; unsigned tid = 0; bbox_t bb{}; bool keep = false, mine = false;
-    if (t < nT) {
-        slot = S.slot[t]; tid = S.tid[t]; age = S.age[t]; vis = S.vis[t]; inv = S.inv[t];
-        bb = trk_pred[t];
-        const int j = at[t];
-        if (j >= 0) { bb = dets[j]; vis++; age++; inv = 0; }
-        else { age++; inv++; }
-        const bool lost = ((age < 10) && (vis * 5 < 3 * age)) || (inv >= 20);
-        keep = !lost;
-        mine = ((int)(tid % (unsigned)S.world) == S.rank);
-        if (mine) {
-            if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; }
-            else { const int q = atomicAdd(&cnt[1], 1); S.free_slots[q] = slot; }   // tracker_delete (td.cpp:599)
-        }
-    }
-    int n_keep;
-    const int newpos = block_excl_scan_flag(keep, wave_tot, n_keep);
-    __syncthreads();
-    if (keep) { S.slot[newpos] = slot; S.tid[newpos] = tid; S.age[newpos] = age; S.vis[newpos] = vis; S.inv[newpos] = inv; S.bbox[newpos] = bb; }
-    // td.cpp:612-644 -- spawn a tracker per unassigned detection, in detection order
-    bool spawn = false; bbox_t db{};
-    if (t < nD && ad[t] < 0) {
-        db = dets[t];
-        spawn = true;
-        if (S.kind == MOT_TRACKER_KCF && ((db.b - db.t + 1) != S.rows || (db.r - db.l + 1) != S.cols)) { spawn = false; atomicAdd(&S.err[0], 1); }
-    }
-    int n_spawn;
-    const int spos = block_excl_scan_flag(spawn, wave_tot, n_spawn);
-    const unsigned tid0 = *S.next_tid;
-    __syncthreads();
-    if (spawn) {
-        const int idx = n_keep + spos;
-        if (idx < S.cap) {
-            const unsigned ntid = tid0 + (unsigned)spos;
-            const bool m2 = ((int)(ntid % (unsigned)S.world) == S.rank);
-            int ns = -1;
-            if (m2) {
-                const int top = atomicSub(&cnt[1], 1) - 1;
-                if (top >= 0) ns = S.free_slots[top]; else atomicAdd(&S.err[2], 1);
-            }
-            S.slot[idx] = ns; S.tid[idx] = ntid; S.age[idx] = 0; S.vis[idx] = 0; S.inv[idx] = 0; S.bbox[idx] = db;
-            if (ns >= 0) {
-                if (S.kind == MOT_TRACKER_KCF) {
-                    kp.pos[ns] = db; kp.scale[ns] = make_float2(1.f, 1.f); kp.first_update[ns] = 1;     // kcf.cpp:200-210
-                    const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = ns; S.upd_boxes[q] = db; S.upd_det[q] = t;   // first update, td.cpp:631-640
-                } else {
-                    const double v[6] = { (double)db.l, (double)db.t, (double)db.r, (double)db.b, 0.0, 0.0 }; // kalman.cpp:152-157
-                    for (int q = 0; q < 6; q++) kal.x[(size_t)ns * 6 + q] = v[q];
-                    for (int q = 0; q < 36; q++) kal.P[(size_t)ns * 36 + q] = (q % 6 == q / 6) ? 1e+4 : 0.0;
-                }
-            }
-        } else atomicAdd(&S.err[1], 1);
-    }
-    __syncthreads();
-    int n_new = n_keep + n_spawn; if (n_new > S.cap) n_new = S.cap;
-    if (t == 0) {
-        *S.nlive = n_new; *S.next_tid = tid0 + (unsigned)(n_new - n_keep);
-        *S.upd_count = cnt[0]; *S.nfree = max(cnt[1], 0);
-    }
-    __threadfence_block();
-    __syncthreads();
-    // lists for the next frame's predict
-    dl_build_lists(S, n_new, wave_tot);
 }
 
 } // namespace
@@ -280,7 +150,9 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const bbox_t* dets = (const bbox_t*)dets_dev;
     KcfPool kp{}; if (S.kind == MOT_TRACKER_KCF) kp = c->pools[d->pool]->dev;
     const bool split = d->split && S.kind == MOT_TRACKER_KCF && nD > 0;
-    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (split && !d->feat_early) ? d->ev_mid : nullptr));
+    // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
+    LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
+    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (split && !d->feat_early) ? d->ev_mid : nullptr, &life));
     if (split && !d->feat_early) {
         // features of every detection box, on the side stream, from the moment the Munkres kernel has been handed to the
         // dispatcher (so its 17 workgroups are placed first); the frame and the boxes are inputs of this call
@@ -290,8 +162,6 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
         HIPCHK(hipEventRecord(d->ev_feat, d->side));
     }
     if (ev) HIPCHK(hipEventRecord(ev[2], c->stream));
-    hipLaunchKernelGGL(dl_lifecycle_kernel, dim3(1), dim3(1024), 0, c->stream, S, kp, c->kal, trk, dets, nD, c->assoc.assignment);
-    HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev[3], c->stream));
     const int upd_max = S.spr + nD;
     if (S.kind == MOT_TRACKER_KCF) {
