@@ -406,13 +406,24 @@ __device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in
 #define MOT_DFT_REG_MAX 41
 #define MOT_DFT_PAIRS ((MOT_DFT_REG_MAX - 1) / 2)
 
+// twiddle j of a table held one entry per lane (n <= 64): two v_readlane with a scalar lane index instead of an LDS read
+// per multiply-add pair (the LDS pipeline of the CU, shared by all waves, was the bottleneck of these loops)
+__device__ __forceinline__ float2 lane_twiddle(float2 mine, int j)
+{
+    return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), j)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), j)));
+}
+
 // real rows: F[row*ldf + y] -> T[row*fh + k], k = 0..fh-1 (same convention as dft_rows_generic)
 __device__ void dft_rows_reg(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
                              const float2* __restrict__ twr, int nrows, int tid, int nt)
 {
     const int hb = p.hb, fh = p.fh, ldf = 2 * fh, H = (hb - 1) >> 1;
     const bool even = !(hb & 1);
-    for (int row = tid; row < nrows; row += nt) {
+    const float2 twl = twr[min(tid & 63, hb - 1)];                    // lane l holds twiddle l
+    for (int row0 = 0; row0 < nrows; row0 += nt) {                    // whole waves stay in the loop (readlane needs the table lanes)
+        const int row = min(row0 + tid, nrows - 1);
+        const bool live = row0 + tid < nrows;
         const float* in = F + row * ldf;
         float s[MOT_DFT_PAIRS], d[MOT_DFT_PAIRS];
 #pragma unroll
@@ -428,10 +439,10 @@ __device__ void dft_rows_reg(const KcfPool& p, const float* __restrict__ F, floa
 #pragma unroll
             for (int y = 1; y <= MOT_DFT_PAIRS; y++) {
                 j += k; if (j >= hb) j -= hb;
-                const float2 w = twr[j];
+                const float2 w = lane_twiddle(twl, j);
                 re += s[y - 1] * w.x; im -= d[y - 1] * w.y;
             }
-            out[k] = make_float2(re, im);
+            if (live) out[k] = make_float2(re, im);
         }
     }
 }
@@ -446,7 +457,11 @@ __device__ void dft_cols_reg(const KcfPool& p, const float2* __restrict__ in, fl
     const bool even = !(wb & 1);
     const int part = tid >= half ? 1 : 0, hw = (wb + 1) >> 1;
     const int x0 = part * hw, x1 = min(wb, x0 + hw);
-    for (int col = tid - part * half; col < ncols; col += half) {
+    const float2 twl = twc[min(tid & 63, wb - 1)];                    // lane l holds twiddle l
+    for (int col0 = 0; col0 < ncols; col0 += half) {
+        const int colr = col0 + tid - part * half;
+        const bool live = colr < ncols;
+        const int col = min(colr, ncols - 1);
         uint32_t ch, k; p.d_fh.divmod((uint32_t)col, ch, k);
         const float2* src = in + (size_t)ch * wb * fh + k;
         float2 s[MOT_DFT_PAIRS], d[MOT_DFT_PAIRS];
@@ -466,11 +481,11 @@ __device__ void dft_cols_reg(const KcfPool& p, const float2* __restrict__ in, fl
 #pragma unroll
             for (int x = 1; x <= MOT_DFT_PAIRS; x++) {
                 j += xp; if (j >= wb) j -= wb;
-                const float2 w = twc[j];
+                const float2 w = lane_twiddle(twl, j);
                 if (SIGN < 0) { re += s[x - 1].x * w.x + d[x - 1].y * w.y; im += s[x - 1].y * w.x - d[x - 1].x * w.y; }
                 else          { re += s[x - 1].x * w.x - d[x - 1].y * w.y; im += s[x - 1].y * w.x + d[x - 1].x * w.y; }
             }
-            dst[xp * fh] = make_float2(re, im);
+            if (live) dst[xp * fh] = make_float2(re, im);
         }
     }
 }
