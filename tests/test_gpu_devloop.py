@@ -104,3 +104,31 @@ def test_device_loop_fused_update_subprocess():
                           "-k", "test_device_loop_vs_oracle or test_device_loop_sharded_two_ranks"],
                          cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_device_loop_empty_and_bursty_frames(mot, oracle, kind):
+    """frames without any detection (every track coasts on its predicted box until the lost rule removes it, td.cpp:589),
+    a burst of new detections, then an empty stream again: the device loop (split update, fused lifecycle) must follow the
+    oracle's tracker thread through all of it"""
+    from multiple_object_tracking_amd import synth
+    n, size, nframes = 24, 80, 34
+    scene = synth.Scene(n, size, stream_id=77 + kind, miss_pct=5, fp_pct=5)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [list(d) for _, d in items]
+    for f in (3, 4, 11):                       # isolated empty frames
+        dets[f] = []
+    for f in range(14, nframes):               # the detector goes silent: all tracks are lost after 20 invisible frames
+        dets[f] = []
+    dets[12] = dets[12] + dets[12][: n // 2]   # duplicated boxes: more detections than tracks, ties in the cost matrix
+    fd, dd, da = _dev(frames, dets, mot)
+    c = mot.MotContext(tracker_kind=kind, max_tracks=128, max_dets=128, dev_size=size)
+    m = orc.OracleMot(oracle, kind, 0, 128)
+    for f in range(nframes):
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        boxes, tids, ages = c.live_tracks()
+        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    assert len(ref["tids"]) == 0, "every track must have been dropped by the lost rule"
+    m.close(); c.close()
