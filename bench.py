@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--mode", choices=["sharded", "streams"], default="sharded",
                     help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded tid %% N, one all-gather per frame (BASELINE configs[3], strong scaling); "
                          "streams = N independent camera streams of --tracks tracks each, one per GPU, no collective (BASELINE configs[4], weak scaling)")
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="single GPU only: K independent camera streams of --tracks tracks each run concurrently (K contexts, K HIP streams); "
+                         "value = all K streams. Informative (small track counts leave most CUs idle); the default 1 is the measured config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=20)
     ap.add_argument("--debug-assoc", action="store_true", help="print Munkres step counters / phase times per profiled frame to stderr")
@@ -151,7 +154,7 @@ def main():
     n_tracks, size = args.tracks, args.size
     streams = args.mode == "streams" and world > 1
     mot_rank, mot_world = (0, 1) if streams else (rank, world)
-    n_prof = args.profile_frames if world == 1 else 0
+    n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
     n_frames = 1 + args.warmup + args.steps + n_prof
     frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0)
     frames_d = torch.from_numpy(frames_h).cuda()
@@ -164,12 +167,20 @@ def main():
                              rank=mot_rank, world=mot_world, stream=stream.cuda_stream, dev_size=size)
 
     gathered = None
+    extra = []                                                       # --streams-per-gpu: more independent contexts on streams of their own
+    if args.streams_per_gpu > 1 and world == 1:
+        for _ in range(args.streams_per_gpu - 1):
+            st = torch.cuda.Stream()
+            extra.append((st, mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(n_tracks, 1),
+                                                 max_dets=max(n_tracks, 1), stream=st.cuda_stream, dev_size=size)))
 
     def step(f):
         fp = frames_d.data_ptr() + f * frame_bytes
         dp = dets_d.data_ptr() + f * det_bytes
         if mot_world == 1:
             ctx.step_frame_device(fp, dp, n_tracks)
+            for _, cx in extra:
+                cx.step_frame_device(fp, dp, n_tracks)
         else:
             seg_ptr, spr = ctx.step_begin_device(fp)
             nonlocal gathered
@@ -205,7 +216,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        n_live = ctx.live_count()
+        n_live = ctx.live_count() + sum(cx.live_count() for _, cx in extra)
         if streams:                                                  # every rank tracks its own stream: whole-job units = sum over ranks
             t = torch.tensor([n_live], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -239,7 +250,8 @@ def main():
                                    (f"{n_tracks} concurrent {size}x{size} KCF tracks (31-ch FHOG, cell 4), 1280x720 BGR synthetic stream, "
                                     f"{n_tracks} detections/frame, Munkres {n_tracks}x{n_tracks}, tracks sharded tid % {world}; "
                                     f"BASELINE configs[{2 if n_tracks == 1024 else 1}]" + ("/[3]" if world > 1 else "")),
-                       "tracks_total": n_tracks * (world if streams else 1), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
+                       **({"streams_per_gpu": args.streams_per_gpu, "note": "K independent contexts on K HIP streams of one GPU; value = all streams"} if extra else {}),
+                       "tracks_total": n_tracks * (world if streams else 1) * (1 + len(extra)), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
                        "live_tracks_end": n_live, "patch": size,
                        "parallelism": (f"{world} replicas, no collective" if streams else f"track-shard x{world}, 1 all-gather/frame") if world > 1 else "single GPU"},
         }
@@ -275,6 +287,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_tracks, size)
         print(json.dumps(out))
+    for _, cx in extra:
+        cx.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
