@@ -18,6 +18,8 @@ typedef unsigned long long u64;
 //   COV       64 granules {32 bits, 32-bit tag}: the 16 row and 16 column cover-mask words of the current step 5,
 //             two granules per word; written by ONE store instruction of the controller's wave 0, polled by the 64
 //             lanes of each helper's wave 0.  Tag MK_TAG_EXIT: the controller is done.
+//   XCCTAB    every helper reports the XCD it runs on; MODE: the controller's verdict "all 17 workgroups share one XCD"
+//             (then the hand-off stores are plain and stay in that XCD's L2, ctl_stx)
 //   EPOCH     tag base: tags are EPOCH + step, unique across launches (the controller advances it when it is done)
 //   PARTIAL   [step & 1][g]: helper g's minimum key over (uncovered rows) x (its uncovered columns); MK_HSENT = not
 //             yet, MK_KEY_NONE = no such element.  Every helper with work in the update phase reads all 16 and takes
@@ -30,6 +32,8 @@ typedef unsigned long long u64;
 // words are drained by the controller one step before they are used again.
 #define MK_HELPERS 16
 #define CTL_EPOCH 32
+#define CTL_MODE 33                    /* {same-XCD flag, tag = EPOCH + 1}: written by the controller before its first publish */
+#define CTL_XCCTAB 48                  /* 16 granules {XCC id of helper g, tag = EPOCH + 1} */
 #define CTL_COV 64                     /* 64 granules */
 #define CTL_PARTIAL 128                /* [2][16] words, each on a 128-byte line of its own (16 writers) */
 #define MK_PARTIAL_STRIDE 16
@@ -42,6 +46,15 @@ typedef unsigned long long u64;
 static_assert(MK_CTL_WORDS == MOT_ASSOC_CTL_WORDS, "control block size");
 __device__ __forceinline__ u64 ctl_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Hand-off store.  `same_xcd`: producer and every consumer were VERIFIED (HW_REG_XCC_ID) to sit on one XCD, i.e. behind one
+// L2: a plain 8-byte store keeps the line in that L2 and the consumers' sc1 loads (L1 bypass) are served from it, instead of
+// the write-through + memory-side read of the agent-scope form.
+__device__ __forceinline__ void ctl_stx(u64* p, u64 v, bool same_xcd)
+{
+    if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int xcc_id() { int x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xF; }
 
 __device__ __forceinline__ u64 dkey(double v) { u64 b = (u64)__double_as_longlong(v); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
 __device__ __forceinline__ double dunkey(u64 k) { u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; return __longlong_as_double((long long)b); }

@@ -129,6 +129,8 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
     const size_t coff = (size_t)nR * min(cbase + lane, nC - 1);        // covered-rows part: lane = column
     unsigned step = 0;
     const unsigned epoch = (unsigned)ctl_ld(ctl + CTL_EPOCH);          // written by the previous launch's controller
+    if (tid == 0) ctl_st(ctl + CTL_XCCTAB + g, (u64)xcc_id() | ((u64)(epoch + 1) << 32));   // where do I run?
+    bool fast = false;                                                  // the controller's verdict, read after its first publish
     for (;;) {
         ++step;
         const unsigned tag = epoch + step;
@@ -147,10 +149,14 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             if (lane < MK_MAXW) S.covR[lane] = cv; else if (lane < 2 * MK_MAXW) S.covC[lane - MK_MAXW] = cv;
             const u64 um = ~readlane64(cv, MK_MAXW + g) & validC;        // my uncovered columns
             if ((um >> lane) & 1) S.list[__popcll(um & ((1ull << lane) - 1))] = (unsigned short)(cbase + lane);
-            if (lane == 0) { S.flag[3] = state; S.flag[2] = __popcll(um); }
+            if (lane == 0) {
+                S.flag[3] = state; S.flag[2] = __popcll(um);
+                if (step == 1 && state == 0) { const u64 md = ctl_ld(ctl + CTL_MODE); S.flag[5] = ((unsigned)(md >> 32) == epoch + 1) ? (int)(md & 1) : 0; }
+            }
         }
         __syncthreads();
         if (S.flag[3]) return;                                          // the controller is done / went away
+        if (step == 1) fast = S.flag[5] != 0;
         const int nmine = S.flag[2];
         const bool rowcov = (S.covR[wave] >> lane) & 1;
         const bool mine = r < nR && !rowcov;
@@ -193,7 +199,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             u64 b = (lane < MK_THREADS / 64) ? (u64)__double_as_longlong(S.red[lane]) : ~0ull;
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) { const u64 o = __shfl_xor(b, off); if (o < b) b = o; }
-            if (lane == 0) ctl_st(ctl + CTL_PARTIAL + ((step & 1) * MK_HELPERS + g) * MK_PARTIAL_STRIDE, b < MK_KEY_NONE ? b : MK_KEY_NONE);   // the word is its own flag
+            if (lane == 0) ctl_stx(ctl + CTL_PARTIAL + ((step & 1) * MK_HELPERS + g) * MK_PARTIAL_STRIDE, b < MK_KEY_NONE ? b : MK_KEY_NONE, fast);   // the word is its own flag
             if (nmine > 0 || part2) {
                 // ---- h = minimum of the 16 partial minima: every helper with work reads them itself (no detour
                 // through the controller) ----
@@ -228,7 +234,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
                 // 8 granules (4 rows x 2 halves), contiguous, one store instruction
                 const int q = (lane >> 1) & 3;
                 const u64 bq = q == 0 ? bl[0] : q == 1 ? bl[1] : q == 2 ? bl[2] : bl[3];
-                if (lane < 2 * min(ncr, 4)) ctl_st(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + q) * 2 + (lane & 1), ((lane & 1) ? bq >> 32 : bq & 0xFFFFFFFFull) | tagw);
+                if (lane < 2 * min(ncr, 4)) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + q) * 2 + (lane & 1), ((lane & 1) ? bq >> 32 : bq & 0xFFFFFFFFull) | tagw, fast);
             }
             for (int i0 = 4; i0 < ncr; i0 += 4) {                       // more covered rows: 4 at a time
                 int rr[4]; double x[4];
@@ -242,7 +248,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
                         x[q] += h;
                         if (act) d[(size_t)rr[q] + coff] = x[q];
                         const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
-                        if (lane < 2) ctl_st(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw);
+                        if (lane < 2) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
                     }
                 }
             }
@@ -263,7 +269,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
         if (uwave < min(nmine, 8) && lane < 2 * MK_MAXW) {
             const int c = S.list[uwave];
             const u64 bal = S.bm[uwave * MK_MAXW + (lane >> 1)];
-            ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw);
+            ctl_stx(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
         }
         for (int q0 = 8; q0 < nmine; q0 += 8) {
             double w[8];
@@ -284,7 +290,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             if (uwave < min(nmine - q0, 8) && lane < 2 * MK_MAXW) {
                 const int c = S.list[q0 + uwave];
                 const u64 bal = S.bm[uwave * MK_MAXW + (lane >> 1)];
-                ctl_st(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw);
+                ctl_stx(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
             }
         }
         __syncthreads();                                               // S.list / S.covR are rewritten by wave 0 for the next step
@@ -471,6 +477,21 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
     bool covRany = false;
     int guard = 0;
+    // Do all 17 workgroups share one XCD (they should: blocks 0, 8, 16, ...)?  Every helper reported its XCC id at its
+    // start, tens of microseconds ago.  If yes the hand-off stores stay in that XCD's L2 (ctl_stx); if a report is missing
+    // or differs, the agent-scope form is used.  The verdict is published before the first cover-mask publish.
+    bool fast = false;
+    if (HELP && nhelp > 0) {
+        if (uwave == 0) {
+            const u64 rep = (lane < nhelp) ? ctl_ld(ctl + CTL_XCCTAB + lane) : 0;
+            const bool okl = lane >= nhelp || ((unsigned)(rep >> 32) == epoch + 1 && (int)(rep & 0xF) == xcc_id());
+            const bool all = __ballot(!okl) == 0;
+            if (lane == 0) { ctl_st(ctl + CTL_MODE, (u64)(all ? 1 : 0) | ((u64)(epoch + 1) << 32)); S.flag[5] = all; }
+        }
+        __syncthreads();
+        fast = S.flag[5] != 0;
+        if (tid == 0) stat[10] = fast;
+    }
     while (!done) {
         const long long t_a = wall_clock64();
         // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wave 0 until a step 5 is needed ==========
@@ -586,7 +607,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 {   // 64 granules = 32 cover-mask words, one store instruction
                     const int j = lane >> 1;
                     const u64 src = j < MK_MAXW ? S.covR[j] : S.covC[j - MK_MAXW];
-                    ctl_st(ctl + CTL_COV + lane, ((lane & 1) ? src >> 32 : src & 0xFFFFFFFFull) | ((u64)(epoch + myseq) << 32));
+                    ctl_stx(ctl + CTL_COV + lane, ((lane & 1) ? src >> 32 : src & 0xFFFFFFFFull) | ((u64)(epoch + myseq) << 32), fast);
                 }
                 const long long tq0 = wall_clock64(); t_h0 += tq0 - t_b;
                 // uncovered columns and covered rows, ascending (for the merge); overlaps the helpers' phase A
@@ -678,7 +699,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                     }
                 }
                 if (lostB) { if (tid == 0) { stat[15] = 2; S.flag[7] = 1; } }
-                else if (tid < MK_HELPERS) ctl_st(ctl + CTL_PARTIAL + ((myseq & 1) * MK_HELPERS + tid) * MK_PARTIAL_STRIDE, MK_HSENT);   // every helper that needed the partial minima has used them: re-arm for step + 2
+                else if (tid < MK_HELPERS) ctl_stx(ctl + CTL_PARTIAL + ((myseq & 1) * MK_HELPERS + tid) * MK_PARTIAL_STRIDE, MK_HSENT, fast);   // every helper that needed the partial minima has used them: re-arm for step + 2
                 t_h2 += wall_clock64() - tq2;
             }
             __syncthreads();
@@ -772,14 +793,14 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     }
     __syncthreads();
     if (HELP && nhelp > 0 && uwave == 0) {
-        if (lane == 0) ctl_st(ctl + CTL_EPOCH, (u64)(epoch + myseq));
+        if (lane == 0) ctl_st(ctl + CTL_EPOCH, (u64)(epoch + myseq + 1));   // + 1: the tags of a launch without any step 5 (XCCTAB, MODE) are spent too
         ctl_st(ctl + CTL_COV + lane, (u64)MK_TAG_EXIT << 32);
     }
     if (tid == 0) {
         stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0; 
         // step-5 split (thread 0, 100 MHz ticks): helpers: publish / wait minimum / wait update / merge;  one workgroup: pass 1 / reduce / (a) / (b)
         stat[4] = (int)t_h0; stat[5] = (int)t_h1; stat[6] = (int)t_h2; stat[7] = (int)t_h3;
-        stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[10] = 0; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
+        stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
         stat[13] = (int)((clock64() - c_begin) * 100 / max((long long)1, wall_clock64() - t_begin));   // shader MHz during this launch
     }
     // buildassignmentvector (:161-176) + computeassignmentcost (:179-189)
