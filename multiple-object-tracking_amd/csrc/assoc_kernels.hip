@@ -406,10 +406,14 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         const u64* lineBm = perRow ? a.ws.zr : a.ws.zc;
         const u64* crossBm = perRow ? a.ws.zc : a.ws.zr;
         for (int i = tid; i < nL * W; i += MK_THREADS) S.bm[(i / W) * MK_MAXW + (i % W)] = lineBm[i];
-        for (int x = tid; x < nX; x += MK_THREADS) {
-            int cnt = 0;
-            for (int w = 0; w < WX; w++) cnt += __popcll(crossBm[(size_t)x * WX + w]);
-            S.crosscnt[x] = (unsigned short)min(cnt, 65535);
+        // zeros per cross line: the bitmap is read once, coalesced (consecutive lanes = consecutive words), and the WX
+        // words of a line are summed across lanes (WX is 1..16: segments of 16 lanes never straddle a wave)
+        for (int i0 = 0; i0 < nX * 16; i0 += MK_THREADS) {
+            const int i = i0 + tid, x = i >> 4, w = i & 15;
+            int cnt = (x < nX && w < WX) ? __popcll(crossBm[(size_t)x * WX + w]) : 0;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 16);
+            if (w == 0 && x < nX) S.crosscnt[x] = (unsigned short)min(cnt, 65535);
         }
         __syncthreads();
         for (int l = tid; l < nL; l += MK_THREADS) {
