@@ -209,6 +209,9 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // contributions of its <= 8x8 pixel footprint in the reference's order
 // (x outer, y inner), so every R1 value is bit-identical.  Then :225-230.
 // ---------------------------------------------------------------------------
+// PRELOAD (HBM-slab templates, 256-VGPR budget): the eight footprint columns are loaded first, all in flight at once,
+// because there every load is an L2 round trip; the LDS-resident kernels load column by column (128-VGPR budget).
+template <bool PRELOAD>
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
                            float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt)
 {
@@ -232,15 +235,26 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         // to exactly these values (all operands are multiples of 1/8, products multiples of 1/64).
         const float wq[8] = { 0.125f, 0.375f, 0.625f, 0.875f, 0.875f, 0.625f, 0.375f, 0.125f };
         const int x0 = 4 * (int)cx - 2, y0 = 4 * (int)cy - 2;
+        float4 pma[PRELOAD ? 8 : 1], pmb[PRELOAD ? 8 : 1]; uint32_t pba[PRELOAD ? 8 : 1], pbb[PRELOAD ? 8 : 1];
+        if (PRELOAD) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int x = min(max(x0 + i, x_lo), x_hi);               // clamped: always a valid column
+                const float* mp = Mq + x * LP + 4 * (int)cy;
+                pma[i] = *reinterpret_cast<const float4*>(mp); pmb[i] = *reinterpret_cast<const float4*>(mp + 4);
+                pba[i] = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
+                pbb[i] = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int x = x0 + i;
             if (x < x_lo || x > x_hi) continue;
             int ob[8]; float term[8];
             const float* mp = Mq + x * LP + 4 * (int)cy;               // = [x][2 + (4cy-2)], 16-byte aligned
-            const float4 ma = *reinterpret_cast<const float4*>(mp), mb = *reinterpret_cast<const float4*>(mp + 4);
-            const uint32_t ba = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
-            const uint32_t bb = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
+            const float4 ma = PRELOAD ? pma[i] : *reinterpret_cast<const float4*>(mp), mb = PRELOAD ? pmb[i] : *reinterpret_cast<const float4*>(mp + 4);
+            const uint32_t ba = PRELOAD ? pba[i] : *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
+            const uint32_t bb = PRELOAD ? pbb[i] : *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
             const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -702,6 +716,7 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* c
 }
 
 // Everything up to R1 (region A) and the norm matrix: shared by predict / update.
+template <bool SLAB>
 __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt, float* stage = nullptr)
 {
 #define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
@@ -720,7 +735,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
-    phase_hist(p, Mq, bins, r.A, stage, tid, nt);                    // R1 overlays the patch
+    phase_hist<SLAB>(p, Mq, bins, r.A, stage, tid, nt);              // R1 overlays the patch
     __syncthreads();
     DBG_STAMP(3);
     phase_energy(p, r.A, r.E, tid, nt);
@@ -764,7 +779,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_ker
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
-    features_prepare(p, l, item, pos, r, tid, nt, stage);
+    features_prepare<!kLds>(p, l, item, pos, r, tid, nt, stage);
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -858,7 +873,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
 #pragma unroll
         for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
     }
-    if (!dspec) features_prepare(p, l, item, box, r, tid, nt, stage);
+    if (!dspec) features_prepare<!kLds>(p, l, item, box, r, tid, nt, stage);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -949,7 +964,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool
     float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
     const Regions r = carve(p, base);
     bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
-    features_prepare(p, l, item, box, r, threadIdx.x, blockDim.x);
+    features_prepare<false>(p, l, item, box, r, threadIdx.x, blockDim.x);
     half_spectrum<0>(p, l, item, r, threadIdx.x, blockDim.x, false);
     __syncthreads();
     half_spectrum<1>(p, l, item, r, threadIdx.x, blockDim.x, false);
