@@ -1,0 +1,181 @@
+/* lap_model.c -- TEST INFRASTRUCTURE ONLY (never linked, loaded or called by the product path).
+ *
+ * CPU model of the device assignment fast path (multiple-object-tracking_amd/csrc/lap_kernels.hip):
+ *   stage 1  row scan      K smallest entries of every row (candidate lists)
+ *   stage 2  sparse solve  shortest-augmenting-path searches on the candidate graph, run in rounds: every free row
+ *                          searches on the same snapshot of (prices, matching); a search commits only if it holds the
+ *                          lock (lowest searcher id) of every column it scanned and of its end column
+ *   stage 3  verify        dense pass over ALL entries: dual feasibility of the prices, and the list of near-tight edges
+ *   stage 4  certificate   the optimum is unique with margin eps iff the near-tight digraph is acyclic
+ * The reference's Munkres (trackers/hungarian/hungarian.cpp:29-368) returns SOME optimal assignment; which one depends
+ * on its scan order only when optima tie.  So "certified" must imply "equal to the reference's assignment":
+ * tests/test_lap_model.py checks exactly that against oracle/mot_oracle.c:orc_assignment_optimal on thousands of
+ * problems (and that uncertified problems exist, i.e. the fallback is exercised).
+ *
+ * Margin: every reference element is the result of at most 2*S5+1 roundings (row minimum,
+ * then +h / -h per step 5, hungarian.cpp:69-90, :355-364), S5 <= n^2, each rounding <= 2^-53 * mag where mag bounds
+ * the working values: mag = max cost + Gamma, Gamma = sum_i (c[i][M(i)] - rowmin_i) >= total dual growth.  Hence the
+ * reference's result is optimal up to delta <= 2n * ((2n^2+1) * 2^-53 * mag + DBL_EPSILON) ~ 4.4e-16 * n^3 * mag, and
+ * eps = max(1e-9, 1e-15 * n^3) * mag > 2 * delta.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LAPM_KMAX 16
+#define LAPM_TS 32          /* touched columns per search */
+#define LAPM_MAXN 1024
+#define LAPM_EDGES 8192
+
+typedef struct {
+    int status;         /* 0 certified, 1 solver gave up, 2 infeasible dual, 3 too many near-tight edges, 4 cyclic (tie), 5 not applicable */
+    int rounds, free0, searches, commits, nedges, ncyclic;
+    double eps, gamma, cmax;
+} lapm_info;
+
+static int cmp_cand(double a, int ja, double b, int jb) { return a < b || (a == b && ja < jb); }
+
+/* cost: column-major c[r + nR*col] (hungarian.cpp:45-54), nR <= nC required */
+int lapm_solve(const double* c, int nR, int nC, int K, int S, int* assignment, lapm_info* info)
+{
+    memset(info, 0, sizeof *info);
+    for (int i = 0; i < nR; i++) assignment[i] = -1;
+    if (nR <= 0 || nC <= 0 || nR > nC || nC > LAPM_MAXN || K < 1 || K > LAPM_KMAX) { info->status = 5; return 5; }
+    if (K > nC) K = nC;
+    /* ---- stage 1 ---- */
+    unsigned short* cj = malloc(sizeof(unsigned short) * (size_t)nR * K);
+    double* cv = malloc(sizeof(double) * (size_t)nR * K);
+    double cmax = 0.0; int bad = 0;
+    for (int i = 0; i < nR; i++) {
+        int nk = 0;
+        for (int j = 0; j < nC; j++) {
+            const double x = c[i + (size_t)nR * j];
+            if (!(x >= 0.0) || !(x <= DBL_MAX)) bad = 1;
+            if (x > cmax) cmax = x;
+            int p = nk;
+            if (nk == K) { if (!cmp_cand(x, j, cv[i * K + K - 1], cj[i * K + K - 1])) continue; p = K - 1; } else nk++;
+            while (p > 0 && cmp_cand(x, j, cv[i * K + p - 1], cj[i * K + p - 1])) { cv[i * K + p] = cv[i * K + p - 1]; cj[i * K + p] = cj[i * K + p - 1]; p--; }
+            cv[i * K + p] = x; cj[i * K + p] = (unsigned short)j;
+        }
+    }
+    info->cmax = cmax;
+    if (bad) { info->status = 5; free(cj); free(cv); return 5; }
+    /* ---- stage 2 ---- */
+    double* v = calloc((size_t)nC, sizeof(double));
+    int* rowOfCol = malloc(sizeof(int) * (size_t)nC); int* colOfRow = malloc(sizeof(int) * (size_t)nR);
+    unsigned char* matchK = calloc((size_t)nR, 1);
+    for (int j = 0; j < nC; j++) rowOfCol[j] = -1;
+    for (int i = 0; i < nR; i++) colOfRow[i] = -1;
+    for (int i = 0; i < nR; i++) { const int j = cj[i * K]; if (rowOfCol[j] < 0) { rowOfCol[j] = i; colOfRow[i] = j; matchK[i] = 0; } }   /* lowest row wins */
+    typedef struct { int ok, nt, jend_slot; double Delta; unsigned short col[LAPM_TS]; double d[LAPM_TS]; short pred[LAPM_TS]; unsigned char predk[LAPM_TS], scanned[LAPM_TS]; } search_t;
+    search_t* sr = malloc(sizeof(search_t) * (size_t)(S > 0 ? S : 1));
+    int* flist = malloc(sizeof(int) * (size_t)nR);
+    int* lock = malloc(sizeof(int) * (size_t)nC);
+    int giveup = 0;
+    for (int i = 0; i < nR; i++) if (colOfRow[i] < 0) info->free0++;
+    for (;;) {
+        int nf = 0;
+        for (int i = 0; i < nR; i++) if (colOfRow[i] < 0) flist[nf++] = i;
+        if (nf == 0) break;
+        if (++info->rounds > 4 * LAPM_MAXN) { giveup = 1; break; }
+        const int ns = nf < S ? nf : S;
+        for (int j = 0; j < nC; j++) lock[j] = 0x7fffffff;
+        for (int q = 0; q < ns; q++) {                                  /* searches on the snapshot */
+            search_t* s = &sr[q]; const int s0 = flist[q];
+            s->ok = 0; s->nt = 0; s->jend_slot = -1; info->searches++;
+            double us = DBL_MAX;
+            for (int k = 0; k < K; k++) { const double x = cv[s0 * K + k] - v[cj[s0 * K + k]]; if (x < us) us = x; }
+            for (int k = 0; k < K; k++) { const int j = cj[s0 * K + k]; s->col[s->nt] = (unsigned short)j; s->d[s->nt] = (cv[s0 * K + k] - v[j]) - us; s->pred[s->nt] = (short)s0; s->predk[s->nt] = (unsigned char)k; s->scanned[s->nt] = 0; s->nt++; }
+            int fail = 0;
+            for (;;) {
+                int b = -1; double best = DBL_MAX;
+                for (int t = 0; t < s->nt; t++) if (!s->scanned[t] && s->d[t] < best) { best = s->d[t]; b = t; }
+                if (b < 0) { fail = 1; break; }
+                s->Delta = best;
+                const int j = s->col[b];
+                if (rowOfCol[j] < 0) { s->jend_slot = b; break; }
+                s->scanned[b] = 1;
+                const int i = rowOfCol[j];
+                const double ui = cv[i * K + matchK[i]] - v[j];
+                for (int k = 0; k < K && !fail; k++) {
+                    const int j2 = cj[i * K + k];
+                    if (j2 == j) continue;
+                    const double nd = best + ((cv[i * K + k] - v[j2]) - ui);
+                    int t; for (t = 0; t < s->nt; t++) if (s->col[t] == j2) break;
+                    if (t < s->nt) { if (!s->scanned[t] && nd < s->d[t]) { s->d[t] = nd; s->pred[t] = (short)i; s->predk[t] = (unsigned char)k; } }
+                    else if (s->nt == LAPM_TS) fail = 1;
+                    else { s->col[t] = (unsigned short)j2; s->d[t] = nd; s->pred[t] = (short)i; s->predk[t] = (unsigned char)k; s->scanned[t] = 0; s->nt++; }
+                }
+                if (fail) break;
+            }
+            if (fail) { giveup = 1; continue; }
+            s->ok = 1;
+            for (int t = 0; t < s->nt; t++) if (s->scanned[t] || t == s->jend_slot) { if (q < lock[s->col[t]]) lock[s->col[t]] = q; }
+        }
+        if (giveup) break;
+        for (int q = 0; q < ns; q++) {                                  /* commits */
+            search_t* s = &sr[q]; const int s0 = flist[q];
+            int mine = 1;
+            for (int t = 0; t < s->nt; t++) if ((s->scanned[t] || t == s->jend_slot) && lock[s->col[t]] != q) mine = 0;
+            if (!mine) continue;
+            info->commits++;
+            for (int t = 0; t < s->nt; t++) if (s->scanned[t]) v[s->col[t]] -= (s->Delta - s->d[t]);
+            int t = s->jend_slot;
+            for (int guard = 0; guard <= LAPM_TS; guard++) {
+                const int j = s->col[t], i = s->pred[t];
+                const int pj = colOfRow[i];
+                colOfRow[i] = j; matchK[i] = s->predk[t]; rowOfCol[j] = i;
+                if (i == s0) break;
+                for (t = 0; t < s->nt; t++) if (s->col[t] == pj) break;
+            }
+        }
+    }
+    int status = 0;
+    if (giveup) status = 1;
+    /* ---- stage 3 ---- */
+    int nedges = 0; int* ea = malloc(sizeof(int) * LAPM_EDGES); int* eb = malloc(sizeof(int) * LAPM_EDGES);
+    const int D = nR;
+    if (!status) {
+        double gamma = 0.0;
+        for (int i = 0; i < nR; i++) gamma += cv[i * K + matchK[i]] - cv[i * K];
+        const double n3 = (double)nC * nC * nC;
+        const double mag = cmax + gamma;
+        const double eps = (1e-15 * n3 > 1e-9 ? 1e-15 * n3 : 1e-9) * mag, tol = 1e-12 * mag;
+        info->eps = eps; info->gamma = gamma;
+        for (int i = 0; i < nR && !status; i++) {
+            const int m = colOfRow[i];
+            const double ui = c[i + (size_t)nR * m] - v[m];
+            for (int j = 0; j < nC; j++) {
+                if (j == m) continue;
+                const double r = (c[i + (size_t)nR * j] - v[j]) - ui;
+                if (!(r >= -tol)) { status = 2; break; }
+                if (r < eps) { if (nedges == LAPM_EDGES) { status = 3; break; } ea[nedges] = i; eb[nedges] = rowOfCol[j] >= 0 ? rowOfCol[j] : D; nedges++; }
+            }
+        }
+        for (int j = 0; j < nC && !status; j++) {
+            if (v[j] > 0.0 || (rowOfCol[j] < 0 && v[j] != 0.0)) status = 2;
+            else if (rowOfCol[j] >= 0 && nC > nR && -v[j] < eps) { if (nedges == LAPM_EDGES) status = 3; else { ea[nedges] = D; eb[nedges] = rowOfCol[j]; nedges++; } }
+        }
+    }
+    info->nedges = nedges;
+    /* ---- stage 4 ---- */
+    if (!status) {
+        unsigned char* alive = malloc((size_t)nR + 1), *hasout = malloc((size_t)nR + 1);
+        memset(alive, 1, (size_t)nR + 1);
+        for (int changed = 1; changed;) {
+            changed = 0; memset(hasout, 0, (size_t)nR + 1);
+            for (int e = 0; e < nedges; e++) if (alive[ea[e]] && alive[eb[e]]) hasout[ea[e]] = 1;
+            for (int i = 0; i <= nR; i++) if (alive[i] && !hasout[i]) { alive[i] = 0; changed = 1; }
+        }
+        int ncyc = 0; for (int i = 0; i <= nR; i++) ncyc += alive[i];
+        info->ncyclic = ncyc;
+        if (ncyc) status = 4;
+        free(alive); free(hasout);
+    }
+    if (!status) for (int i = 0; i < nR; i++) assignment[i] = colOfRow[i];
+    info->status = status;
+    free(cj); free(cv); free(v); free(rowOfCol); free(colOfRow); free(matchK); free(sr); free(flist); free(lock); free(ea); free(eb);
+    return status;
+}
