@@ -176,6 +176,13 @@ int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long lon
  * in 10 ns ticks: init, step 3 + 4, -, step 5, total; [13] shader MHz; [14] uncovered columns at the first step 5;
  * [15] 0, or which helper hand-off timed out */
 int mot_get_assoc_stats(mot_ctx* ctx, int* out16);
+/* assignment fast path in front of the Munkres emulation (exact sparse solver + uniqueness certificate; the reference's
+ * assignmentoptimal, hungarian.cpp:29-368, returns the unique optimum whenever there is one):
+ * [0..15] most recent launch: [0] 0 = certified (emulation skipped), 1 = solver gave up / not applicable, 2 = dual check
+ *   failed, 3 = too many near-tight edges, 4 = tied optima (order-exact emulation ran); [1] solver rounds [2] free rows after
+ *   the greedy start [3] searches [4] commits [5] near-tight edges [6] nodes on cycles [7] solver time in 10 ns ticks
+ * [16..20] cumulative launch counts of this context by outcome 0..4 */
+int mot_get_lap_stats(mot_ctx* ctx, int* out32);
 /* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
 int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);
 /* crop + gray + resize only (top/td.cpp:348-364) on the bound frame. */

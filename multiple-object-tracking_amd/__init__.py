@@ -289,6 +289,13 @@ class MotContext:
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
         return out
 
+    def lap_stats(self) -> np.ndarray:
+        """assignment fast path: [0..7] most recent launch (outcome, rounds, free rows, searches, commits, near-tight
+        edges, cyclic nodes, solver ticks), [16..20] cumulative launches by outcome (0 = certified, 4 = tied optima)"""
+        out = np.zeros(32, np.int32)
+        self._chk(self.lib.mot_get_lap_stats(self._h, _vp(out)))
+        return out
+
     def fhog_extract(self, patch: np.ndarray, h: int, w: int, windowed=False) -> np.ndarray:
         p = np.ascontiguousarray(patch, np.float32).ravel()
         assert p.size == h * w

@@ -17,6 +17,7 @@
 //     as self-tagged 8-byte granules (mk_helper_loop, assoc_common.h);
 //   * below 65 lines the Munkres workgroup computes costs, minima and bitmaps itself (mk_fused_cost).
 #include "assoc_common.h"
+#include "lap_certify.h"
 #include "dl_lifecycle.h"
 #include <stdlib.h>
 
@@ -87,6 +88,7 @@ __global__ void __launch_bounds__(256) assoc_sub_kernel(AssocArgs a)
 // the sequential state machine, one workgroup
 // ---------------------------------------------------------------------------
 #define MK_HELP_MIN 512
+#define MK_LAP_MIN_LINES 96          /* default smallest problem for the fast path (lap_kernels.hip) */
 #define MK_XCDS 8                /* MI355X: 8 XCDs, workgroup i of a launch goes to XCD i % 8 */
 #define MK_SPIN_LIMIT 4000000   /* bounded spins: a lost partner ends the wait after seconds instead of hanging the GPU */
 struct MkShared {
@@ -359,8 +361,10 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
 
 // HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
 // HELP = true : launched with 1 + MK_HELPERS workgroups; workgroups 1.. run mk_helper_loop.
+// lap_mode: the fast path (lap_kernels.hip) ran in front of this launch; if its certificate holds (lap_certify.h) the
+// solver's matching IS the reference's assignment and the emulation is skipped.
 template <bool HELP>
-__global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost, LifeArgs life)
+__global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost, LifeArgs life, int lap_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char mk_raw[];
     MkShared& S = *reinterpret_cast<MkShared*>(mk_raw);
@@ -383,6 +387,9 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     }
     if (!HELP && (want_cost & 2)) mk_fused_cost(a, S, nR, nC, rowsTrk);
     if (tid == 0) stat[15] = 0;                                        // set again only if a helper hand-off times out
+    bool certified = false;
+    if (lap_mode) certified = lap_certify(a.ws.lap, nR, nC, reinterpret_cast<unsigned*>(S.bm), S.flag);
+    __syncthreads();
     if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
@@ -395,12 +402,16 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
     if (tid == 0) S.flag[7] = 0;
     if (tid < 2 * MK_MAXW) { S.taken32[tid] = 0; S.cont32[tid] = 0; }
+    if (certified) {                                                   // the unique optimum: nothing to emulate
+        if (tid < nR) S.starColOfRow[tid] = a.ws.lap.colOfRow[tid];
+        __syncthreads();
+    }
     // ---- steps 1 + 2a: initial stars (hungarian.cpp:93-101 / :128-139) ----
     // lines (rows if perRow, else columns) are scanned in order; each takes its first zero whose cross line
     // is still free.  A line whose first zero sits in a cross line with exactly ONE zero ("clean") can be
     // starred out of order: no other line can ever claim that cross line.  Only the contested lines go
     // through the ordered scan (wave 0).
-    {
+    if (!certified) {
         const int nL = perRow ? nR : nC, nX = perRow ? nC : nR;
         const int W = perRow ? wordsC : wordsR, WX = perRow ? wordsR : wordsC;
         const u64* lineBm = perRow ? a.ws.zr : a.ws.zc;
@@ -460,7 +471,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     }
     int ncov = 0;
     for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
-    bool done = (ncov == minDim);                                      // step 2b (:216-237)
+    bool done = certified || (ncov == minDim);                         // step 2b (:216-237)
     if (!done) {
         __syncthreads();
         for (int i = tid; i < nC * wordsR; i += MK_THREADS) S.bm[(i / wordsR) * MK_MAXW + (i % wordsR)] = a.ws.zc[i];
@@ -801,7 +812,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         ctl_st(ctl + CTL_COV + lane, (u64)MK_TAG_EXIT << 32);
     }
     if (tid == 0) {
-        stat[0] = n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0; 
+        stat[0] = certified ? -1 : n_s4; stat[1] = n_s5; stat[2] = n_sw; stat[3] = n_cov5; stat[14] = ncu0; 
         // step-5 split (thread 0, 100 MHz ticks): helpers: publish / wait minimum / wait update / merge;  one workgroup: pass 1 / reduce / (a) / (b)
         stat[4] = (int)t_h0; stat[5] = (int)t_h1; stat[6] = (int)t_h2; stat[7] = (int)t_h3;
         stat[8] = (int)(t_init - t_begin); stat[9] = (int)t_s3; stat[11] = (int)t_s5; stat[12] = (int)(wall_clock64() - t_begin);
@@ -819,7 +830,10 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     // device-resident loop: the lifecycle step (td.cpp:472-644) runs here instead of in a launch of its own
     if (life.enabled) {
         __syncthreads();                                               // the assignment vector is complete (same workgroup wrote it)
-        dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, reinterpret_cast<int*>(S.bm) + 4096);
+        // a helper hand-off that timed out leaves a partial starring: never commit it to the tracker state -- the frame is
+        // dropped (live list and models untouched) and the context latches a device error that every read-back reports
+        if (S.flag[7]) { if (tid == 0) life.S.err[4] = stat[15]; }
+        else dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, reinterpret_cast<int*>(S.bm) + 4096);
     }
 }
 
@@ -842,6 +856,8 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
     return hipGetLastError();
 }
 
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s);   // lap_kernels.hip
+
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
                         const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid, const LifeArgs* life_in)
 {
@@ -858,23 +874,37 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     else { maxR = nT < nD ? nT : nD; maxC = nT < nD ? nD : nT; if (nT_dev) { maxR = nD < nT ? nD : nT; maxC = nD > nT ? nD : nT; } }
     if (maxR > MK_MAXN || maxC > MK_MAXN) return hipErrorInvalidValue;
     const int lines = maxR > maxC ? maxR : maxC;
+    // Assignment fast path (lap_kernels.hip): exact sparse solver + uniqueness certificate in front of the emulation; rows <=
+    // columns only (the only shape td.cpp:462-469 produces).  MOT_LAP_FAST=0 switches it off, MOT_LAP_MIN sets the smallest
+    // problem (lines) it is used for -- below that the emulation of a whole frame costs less than the three extra launches.
+    static int lap_min = -1;
+    if (lap_min < 0) {
+        const char* e0 = getenv("MOT_LAP_FAST"); const char* e1 = getenv("MOT_LAP_MIN");
+        lap_min = (e0 && atoi(e0) == 0) ? (1 << 30) : (e1 ? (atoi(e1) > 1 ? atoi(e1) : 1) : MK_LAP_MIN_LINES);
+    }
+    const bool lap = ws.lap.ccol && maxR > 0 && maxR <= maxC && lines >= lap_min;
     // small problems: the Munkres workgroup computes cost, minima and bitmaps itself (mk_fused_cost)
-    const bool fused = lines <= MK_FUSE_LINES;
+    const bool fused = lines <= MK_FUSE_LINES && !lap;
     hipError_t e = hipSuccess;
     if (!fused && maxR > 0 && maxC > 0) {
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
-        hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+        if (lap) { e = launch_lap_front(a, gR, gC, s); if (e != hipSuccess) return e; }
+        else {
+            hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+        }
     }
     if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }   // cost kernels submitted, the Munkres kernel comes next
-    static bool attr_set = false;
+    static int attr_dev = -1;                                          // hipFuncSetAttribute is per device
+    int cur_dev = 0; e = hipGetDevice(&cur_dev); if (e != hipSuccess) return e;
+    const bool attr_set = attr_dev == cur_dev;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_dev = cur_dev;
     }
     // Step-5 helper workgroups (16 more CUs stream the matrix; two cross-CU hand-offs per step 5) pay off only when
     // step 5 moves a lot of data: dense hard problems beyond ~512 lines.  MOT_MUNKRES_HELPERS=1 forces them on for
@@ -882,7 +912,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     static int helpers = -1;
     if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
     const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN));
-    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life);
-    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life);
+    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
+    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life, lap ? 1 : 0);
     return hipGetLastError();
 }

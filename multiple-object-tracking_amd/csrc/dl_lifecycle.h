@@ -14,7 +14,8 @@ struct DLState {
     int* upd_det;                 // [cap + max_dets] detection whose box an update item adopts (-1: the predicted box, td.cpp:540-560)
     bbox_t* pred;                 // [cap] predicted boxes in live order
     bbox_t* gather;               // [world*spr] all-gather buffer (own segment written by predict)
-    int* err;                     // [4]: spawns dropped for template-size mismatch, capacity drops, pool exhausted, -
+    int* err;                     // [8]: spawns dropped for template-size mismatch, capacity drops, pool exhausted, all-gather segment overflow,
+                                  //      [4] sticky: a Munkres helper hand-off timed out (frame dropped; read-backs return MOT_ERR_DEVICE)
     int cap, max_dets, rank, world, spr, rows, cols, kind;
 };
 
@@ -43,7 +44,8 @@ __device__ inline void dl_build_lists(const DLState& S, int n, int* wave_tot)
         const int pos = block_excl_scan_flag(r == rk, wave_tot, total);
         if (r == rk) {
             S.rankpos[t] = pos;
-            if (rk == S.rank) {
+            if (pos >= S.spr) atomicAdd(&S.err[3], 1);                 // cannot happen: a segment holds cap boxes (mot_ctx.hip)
+            else if (rk == S.rank) {
                 S.loc_slots[pos] = S.slot[t];
                 if (S.kind == MOT_TRACKER_KALMAN) S.gather[(size_t)S.rank * S.spr + pos] = S.bbox[t];   // predict is in/out (kalman.cpp:112-115)
             }

@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_ker
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
     float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;      // HBM-slab templates: region C + staging in LDS
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
     float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
     const Regions r = carve(p, base);
     bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
     features_prepare<false>(p, l, item, box, r, threadIdx.x, blockDim.x);
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_crop_kernel(const KcfPool
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)item * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
     const Regions r = carve(p, base);
     const int tid = threadIdx.x, nt = blockDim.x;
     phase_crop(p, l.frame, nullptr, l.boxes_in[item], r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
@@ -1033,13 +1033,14 @@ size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats
 template <typename K>
 static hipError_t set_lds_attr(K kern, size_t bytes)
 {
-    // once per kernel symbol: allow the full 160 KB of a gfx950 CU as dynamic LDS
-    static const void* done[16]; static int ndone = 0;
+    // once per kernel symbol AND device: allow the full 160 KB of a gfx950 CU as dynamic LDS
+    static const void* done[64]; static int done_dev[64]; static int ndone = 0;
     if (bytes <= 64 * 1024) return hipSuccess;
     const void* key = reinterpret_cast<const void*>(kern);
-    for (int i = 0; i < ndone; i++) if (done[i] == key) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, MOT_LDS_LIMIT);
-    if (e == hipSuccess && ndone < 16) done[ndone++] = key;
+    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+    for (int i = 0; i < ndone; i++) if (done[i] == key && done_dev[i] == dev) return hipSuccess;
+    e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, MOT_LDS_LIMIT);
+    if (e == hipSuccess && ndone < 64) { done[ndone] = key; done_dev[ndone++] = dev; }
     return e;
 }
 

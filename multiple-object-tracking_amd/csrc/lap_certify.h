@@ -1,0 +1,57 @@
+// lap_certify.h -- last stage of the assignment fast path (lap_kernels.hip), executed by the Munkres controller
+// workgroup before it would start the order-exact emulation.
+//
+// Input: the solver's matching M and duals, already checked entry by entry by lap_verify_kernel (LAP_H_VIOL), and the
+// list of near-tight edges  i -> i'  ("row i could take the column of row i' at a reduced cost below eps"; node nR
+// stands for all free columns).  Any other assignment M' differs from M along alternating cycles of that digraph's
+// complete version, and cost(M') - cost(M) = sum of the reduced costs on them >= (eps - n * tol) unless every edge of
+// a cycle is near-tight.  So: no directed cycle among the near-tight edges  =>  M is the unique optimum by more than
+// anything float64 rounding moves inside the reference (margin: lap_model.c (CPU model, test infrastructure))  =>  hungarian.cpp:29-368 returns M.
+#pragma once
+#include "assoc_common.h"
+
+namespace assoc {
+
+// scratch: >= LAP_EDGES unsigned + 2 * (MK_MAXN + 64) bytes of LDS.  Returns true (workgroup-uniform) iff certified.
+__device__ inline bool lap_certify(const LapWs& L, int nR, int nC, unsigned* scratch, int* flag2)
+{
+    const int tid = threadIdx.x;
+    unsigned* ed = scratch;
+    unsigned char* alive = reinterpret_cast<unsigned char*>(scratch + LAP_EDGES);
+    unsigned char* hasout = alive + MK_MAXN + 64;
+    const int solve = L.hdr[LAP_H_SOLVE], viol = L.hdr[LAP_H_VIOL], ne = L.hdr[LAP_H_NEDGES], bad = L.hdr[LAP_H_BAD];
+    int reason = 0;                                                     // 0 certified, 1 solver gave up / n.a., 2 infeasible dual, 3 too many near-tight edges, 4 tie
+    if (solve != 0 || bad) reason = 1; else if (viol) reason = 2; else if (ne > LAP_EDGES) reason = 3;
+    int ncyc = 0;
+    if (!reason) {
+        for (int e = tid; e < ne; e += MK_THREADS) ed[e] = L.edges[e];
+        for (int i = tid; i <= nR; i += MK_THREADS) alive[i] = 1;
+        __syncthreads();
+        // peel nodes without an edge into the still-alive set; what survives lies on or leads into a cycle
+        for (int it = 0; it <= nR + 1; it++) {
+            for (int i = tid; i <= nR; i += MK_THREADS) hasout[i] = 0;
+            if (tid == 0) flag2[0] = 0;
+            __syncthreads();
+            for (int e = tid; e < ne; e += MK_THREADS) { const unsigned x = ed[e]; const int s = x >> 16, d = x & 0xFFFF; if (alive[s] && alive[d]) hasout[s] = 1; }
+            __syncthreads();
+            for (int i = tid; i <= nR; i += MK_THREADS) if (alive[i] && !hasout[i]) { alive[i] = 0; flag2[0] = 1; }
+            __syncthreads();
+            const int changed = flag2[0];
+            __syncthreads();
+            if (!changed) break;
+        }
+        int mine = 0;
+        for (int i = tid; i <= nR; i += MK_THREADS) mine += alive[i];
+        ncyc = __syncthreads_count(mine != 0);                          // nodes = threads here (nR + 1 <= 1025: thread 0 may hold two)
+        if (ncyc) reason = 4;
+    }
+    if (tid == 0) {
+        L.hdr[LAP_H_LAST + 0] = reason; L.hdr[LAP_H_LAST + 5] = ne; L.hdr[LAP_H_LAST + 6] = ncyc;
+        L.hdr[LAP_H_CUM + reason] += 1;                                  // [32] certified, [33..36] handed to the order-exact Munkres, by reason
+        // re-arm for the next launch (this workgroup is the last reader)
+        L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; *L.cmaxkey = 0ull;
+    }
+    return reason == 0;
+}
+
+} // namespace assoc

@@ -61,7 +61,7 @@ struct mot_ctx {
     mot_impl::PinBuf<int> h_slots; mot_impl::PinBuf<bbox_t> h_boxes_a, h_boxes_b; mot_impl::PinBuf<int> h_assign; mot_impl::PinBuf<double> h_cost; mot_impl::PinBuf<float> h_patches;
     // association
     AssocWs assoc{}; mot_impl::DevBuf<double> a_dist; mot_impl::DevBuf<unsigned long long> a_zr, a_zc, a_linemin; mot_impl::DevBuf<int> a_assign, a_status; mot_impl::DevBuf<double> a_cost;
-    mot_impl::DevBuf<double> a_user; mot_impl::DevBuf<unsigned long long> a_ctl;
+    mot_impl::DevBuf<double> a_user; mot_impl::DevBuf<unsigned long long> a_ctl; mot_impl::DevBuf<unsigned char> a_lap;
     // frame loop (td.cpp:306-748), host-orchestrated mode
     std::vector<mot_impl::LiveInfo> live; unsigned next_tid = 0;
     mot_impl::DevBuf<bbox_t> d_gather; int slots_per_rank = 0; bool step_open = false;
@@ -75,4 +75,5 @@ struct mot_ctx {
 namespace mot_impl {
 int ensure_device(mot_ctx* c);
 int get_pool(mot_ctx* c, int rows, int cols, int* out_idx);
+int devloop_check(mot_ctx* c);   // mot_devloop.hip
 }

@@ -333,7 +333,21 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
     HIPCHK(c->a_ctl.alloc(MOT_ASSOC_CTL_WORDS)); HIPCHK(hipMemset(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n)); c->assoc.ctl = c->a_ctl.p;
-    c->slots_per_rank = (cfg->max_tracks + cfg->world - 1) / cfg->world;
+    {   // assignment fast path workspace (lap_kernels.hip): one block, carved here
+        size_t off = 0; auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_cost = carve(sizeof(double) * 1024 * LAP_K), o_col = carve(sizeof(unsigned short) * 1024 * LAP_K), o_v = carve(sizeof(double) * 1024),
+                     o_u = carve(sizeof(double) * 1024), o_cr = carve(sizeof(short) * 1024), o_rc = carve(sizeof(short) * 1024),
+                     o_e = carve(sizeof(unsigned) * LAP_EDGES), o_h = carve(sizeof(int) * 64), o_d = carve(sizeof(double) * 8), o_k = carve(8);
+        HIPCHK(c->a_lap.alloc(off)); HIPCHK(hipMemset(c->a_lap.p, 0, off));
+        unsigned char* b = c->a_lap.p; LapWs& L = c->assoc.lap;
+        L.ccost = (double*)(b + o_cost); L.ccol = (unsigned short*)(b + o_col); L.v = (double*)(b + o_v); L.u = (double*)(b + o_u);
+        L.colOfRow = (short*)(b + o_cr); L.rowOfCol = (short*)(b + o_rc); L.edges = (unsigned*)(b + o_e); L.hdr = (int*)(b + o_h);
+        L.dhdr = (double*)(b + o_d); L.cmaxkey = (unsigned long long*)(b + o_k);
+    }
+    // all-gather segment of one rank.  Ownership is tid % world (round-robin by creation id), which drifts under track churn:
+    // a rank can own up to max_tracks of the live tracks, so every segment is sized for that (24 KB per rank at 1024 tracks:
+    // still a latency-bound message); the predict / update grids are bounded by device-side counts, not by the segment size.
+    c->slots_per_rank = cfg->max_tracks;
     HIPCHK(c->d_gather.alloc((size_t)c->slots_per_rank * cfg->world));
     HIPCHK(hipMemset(c->d_gather.p, 0, sizeof(bbox_t) * c->d_gather.n));
     *out = c.release();
@@ -353,7 +367,7 @@ int mot_ctx_destroy(mot_ctx* c)
 }
 
 void* mot_ctx_stream(mot_ctx* c) { return c ? (void*)c->stream : nullptr; }
-int mot_ctx_sync(mot_ctx* c) { if (!c) return fail(MOT_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return MOT_OK; }
+int mot_ctx_sync(mot_ctx* c) { if (!c) return fail(MOT_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return devloop_check(c); }
 
 int mot_frame_upload(mot_ctx* c, const uint8_t* host_bgr)
 {
@@ -667,6 +681,14 @@ int mot_get_assoc_stats(mot_ctx* c, int* out16)
     if (!c || !out16) return fail(MOT_ERR_ARG, "null argument");
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out16, c->assoc.status, sizeof(int) * 16, hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_get_lap_stats(mot_ctx* c, int* out32)
+{
+    if (!c || !out32) return fail(MOT_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out32, c->assoc.lap.hdr + LAP_H_LAST, sizeof(int) * 32, hipMemcpyDeviceToHost));
     return MOT_OK;
 }
 

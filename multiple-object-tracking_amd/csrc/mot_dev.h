@@ -71,6 +71,7 @@ struct KcfLaunch {
     float2* spec_out;         // feature-only launch: [n][31][nbins] spectra of boxes_in[item] are written here, no model update
     const float2* det_spec;   // blend launch: spectra written by a feature-only launch ...
     const int* det_index;     // ... and [n] the detection whose spectrum item uses (-1: compute from boxes_in[item] as usual)
+    int slab_base;            // HBM-slab templates: item i works in slab (slab_base + i) -- a launch that may run beside another KCF launch gets slabs of its own
 };
 
 struct KalmanPool {
@@ -79,6 +80,28 @@ struct KalmanPool {
 };
 
 // ---- association workspace -------------------------------------------------
+// assignment fast path (lap_kernels.hip): sparse exact LAP solver + uniqueness certificate
+#define LAP_K 8               // candidate columns per row (the K smallest costs)
+#define LAP_TS 32             // columns one search may touch
+#define LAP_S 128             // concurrent searches per round
+#define LAP_EDGES 8192        // near-tight edges the certificate accepts
+struct LapWs {
+    unsigned short* ccol;     // [1024][LAP_K] candidate columns of every row, ascending cost (0xFFFF: none)
+    double* ccost;            // [1024][LAP_K] their costs
+    double* v;                // [1024] column prices (<= 0; 0 on unmatched columns)
+    double* u;                // [1024] row duals u_i = c[i][M(i)] - v[M(i)]
+    short* colOfRow;          // [1024] the solver's matching
+    short* rowOfCol;          // [1024]
+    unsigned* edges;          // [LAP_EDGES] near-tight edges (row << 16) | (row that owns the column, or nR = "a free column")
+    int* hdr;                 // [64] LAP_H_*
+    double* dhdr;             // [8]  eps, tol, gamma, cmax
+    unsigned long long* cmaxkey;  // order-preserving key of the largest cost (atomicMax)
+};
+enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 5 not applicable (negative / non-finite costs)
+       LAP_H_NEDGES = 1, LAP_H_VIOL = 2, LAP_H_BAD = 3,
+       LAP_H_LAST = 16,       // [16..31] statistics of the most recent launch: status, rounds, free rows, searches, commits, edges, cyclic nodes, device time (10 ns)
+       LAP_H_CUM = 32 };      // [32..] cumulative: launches certified, launches handed to the order-exact Munkres (by reason)
+
 struct AssocWs {
     double* dist;             // [1024*1024] working matrix, column-major
     unsigned long long* zr;   // row-major zero bitmap  [nR][wordsC]
@@ -88,6 +111,7 @@ struct AssocWs {
     double* cost;             // [1]
     int* status;              // [16]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow, timers
     unsigned long long* ctl;  // control block + result buffers of the step-5 helper workgroups (MOT_ASSOC_CTL_WORDS u64)
+    LapWs lap;                // fast-path workspace (lap.ccol == nullptr: not available)
 };
 
 // host-side launchers implemented in the .hip files

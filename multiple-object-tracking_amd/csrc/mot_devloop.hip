@@ -42,7 +42,7 @@ struct DevLoop {
     hipEvent_t ev[8]{}; bool ev_ok = false;
     // split update (KCF): the spectra of all detection boxes are computed on a second, low-priority stream while the
     // association runs; the per-track update then only blends them into the model
-    DevBuf<float2> det_spec; hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr; bool split = false;
+    DevBuf<float2> det_spec; hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
 };
 
@@ -53,6 +53,7 @@ void devloop_destroy(DevLoop* d)
     if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
     if (d->ev_feat) (void)hipEventDestroy(d->ev_feat);
     if (d->ev_upd) (void)hipEventDestroy(d->ev_upd);
+    if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->side) (void)hipStreamDestroy(d->side);
     delete d;
 }
@@ -100,6 +101,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             HIPCHK(hipEventCreateWithFlags(&d->ev_mid, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&d->ev_feat, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&d->ev_upd, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
             HIPCHK(hipEventRecord(d->ev_upd, c->stream));
             HIPCHK(d->det_spec.alloc((size_t)md * MOT_NCHAN * kp.nbins));
             d->split = true;
@@ -123,8 +125,11 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     if (d->split && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= MOT_SPLIT_EARLY_MAX) {
         // small frames leave most CUs idle during the predict: the detection features run beside it (they only need the
         // frame and the boxes); the spectra buffer is free once the previous frame's update has finished
-        HIPCHK(hipStreamWaitEvent(d->side, d->ev_upd, 0));
-        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = d->det_spec.p;
+        // the side stream is ordered behind everything the caller has enqueued on the context stream so far (frame upload,
+        // detector output): in-order execution makes this event subsume the previous frame's update (ev_upd) as well
+        HIPCHK(hipEventRecord(d->ev_in, c->stream));
+        HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = d->det_spec.p; lf.slab_base = S.cap;
         HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
         HIPCHK(hipEventRecord(d->ev_feat, d->side));
         d->feat_early = true;
@@ -157,7 +162,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
         // features of every detection box, on the side stream, from the moment the Munkres kernel has been handed to the
         // dispatcher (so its 17 workgroups are placed first); the frame and the boxes are inputs of this call
         HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
-        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->frame; lf.boxes_in = dets; lf.spec_out = d->det_spec.p;
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->frame; lf.boxes_in = dets; lf.spec_out = d->det_spec.p; lf.slab_base = S.cap;
         HIPCHK(launch_kcf_update(kp, lf, nD, d->side));
         HIPCHK(hipEventRecord(d->ev_feat, d->side));
     }
@@ -175,6 +180,19 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
 }
 
 } // namespace
+
+namespace mot_impl {
+// sticky device-side errors of the device-resident loop (the stream must be idle)
+int devloop_check(mot_ctx* c)
+{
+    if (!c->devloop) return MOT_OK;
+    int err[8];
+    HIPCHK(hipMemcpy(err, c->devloop->S.err, sizeof err, hipMemcpyDeviceToHost));
+    if (err[4]) return fail(MOT_ERR_DEVICE, "Munkres helper workgroups timed out (hand-off %d); the frame was dropped", err[4]);
+    if (err[3]) return fail(MOT_ERR_DEVICE, "all-gather segment overflow (%d)", err[3]);
+    return MOT_OK;
+}
+} // namespace mot_impl
 
 extern "C" {
 
@@ -230,6 +248,7 @@ int mot_live_count(mot_ctx* c, int* n_live)
     if (!c || !n_live) return fail(MOT_ERR_ARG, "null argument");
     if (!c->devloop) { *n_live = (int)c->live.size(); return MOT_OK; }
     HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = devloop_check(c); if (rc) return rc;
     HIPCHK(hipMemcpy(n_live, c->devloop->S.nlive, sizeof(int), hipMemcpyDeviceToHost));
     return MOT_OK;
 }
@@ -245,6 +264,7 @@ int mot_live_tracks(mot_ctx* c, bbox_t* boxes, unsigned* tids, int* ages, int* n
     const DLState& S = c->devloop->S;
     int n = 0;
     HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = devloop_check(c); if (rc) return rc;
     HIPCHK(hipMemcpy(&n, S.nlive, sizeof(int), hipMemcpyDeviceToHost));
     if (n_live) *n_live = n;
     if (n > 0) {

@@ -4,8 +4,9 @@ replicated association + lifecycle on every rank.
 
 The collective is a plain ``torch.distributed.all_gather_into_tensor`` (backend
 "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).  The message is
-24 B x ceil(max_tracks / world) per rank -- latency-bound, so there is exactly one
-collective per frame and nothing else on the data path.
+24 B x max_tracks per rank (ownership tid % world drifts under track churn, so a
+segment must hold up to max_tracks boxes) -- 24 KB at 1024 tracks, latency-bound, so
+there is exactly one collective per frame and nothing else on the data path.
 """
 from __future__ import annotations
 
@@ -15,7 +16,7 @@ BBOX_BYTES = 24
 
 
 def slots_per_rank(max_tracks: int, world: int) -> int:
-    return (max_tracks + world - 1) // world
+    return max_tracks
 
 
 def owner_of(tid: int, world: int) -> int:

@@ -427,15 +427,25 @@ for nr, nc in ((700, 400), (400, 700)):
     a, cost = c.assignment_optimal(d, nr, nc)
     ra, rc = orc.assignment_optimal(lib, d, nr, nc)
     assert np.array_equal(a, ra) and cost == rc, ("rect", nr, nc)
-print("VARIANT_OK", c.assoc_stats()[:3].tolist())
+# random matrix families incl. tie-heavy ones (the fast path must hand every tie to the order-exact emulation)
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from test_lap_model import mm
+for trial in range(120):
+    nr = int(rng.integers(1, 140)); nc = int(rng.integers(nr, 150))
+    d = mm(rng, nr, nc, trial % 9)
+    a, cost = c.assignment_optimal(d, nr, nc)
+    ra, rc = orc.assignment_optimal(lib, d, nr, nc)
+    assert np.array_equal(a, ra) and cost == rc, ("family", trial % 9, nr, nc)
+print("VARIANT_OK", c.assoc_stats()[:3].tolist(), "LAP", c.lap_stats()[16:21].tolist())
 '''
 
 
 def _run_variant(env_extra):
     import subprocess, sys
     env = dict(os.environ, **env_extra)
-    out = subprocess.run([sys.executable, "-c", _VARIANT_CODE], cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _VARIANT_CODE], cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert "VARIANT_OK" in out.stdout, out.stdout + out.stderr
+    return eval(out.stdout.split("LAP")[-1].strip())
 
 
 @pytest.mark.parametrize("helpers", ["0", "1"])
@@ -443,3 +453,42 @@ def test_munkres_helper_workgroups_subprocess(helpers):
     """step-5 helper workgroups (munkres_kernel<true>, 1 + 16 workgroups, cross-CU control block) forced on for every
     problem above 256 lines ("1") and forced off ("0"): identical assignments and cost either way."""
     _run_variant({"MOT_MUNKRES_HELPERS": helpers})
+
+
+@pytest.mark.parametrize("mode", ["all_sizes", "off"])
+def test_lap_fast_path_subprocess(mode):
+    """assignment fast path (lap_kernels.hip: exact sparse solver + uniqueness certificate) forced on for EVERY problem size
+    (MOT_LAP_MIN=1) and switched off (MOT_LAP_FAST=0): bit-identical assignments and cost either way, and with it on both
+    outcomes must occur -- certified launches (emulation skipped) and tied optima (order-exact emulation ran)."""
+    cum = _run_variant({"MOT_LAP_MIN": "1"} if mode == "all_sizes" else {"MOT_LAP_FAST": "0"})
+    if mode == "off":
+        assert sum(cum) == 0, cum
+    else:
+        assert cum[0] > 20 and cum[4] > 20 and cum[2] == 0, cum     # certified, ties; the dual check must never fail
+
+
+def test_lap_fast_path_counters(mot, oracle):
+    """default configuration: a crowded 1024 x 1024 tracking problem with a unique optimum is certified (no emulation:
+    step counters stay at their 'skipped' mark), the same problem with two tracks on one centroid is a tie and goes through
+    the emulation; both equal the oracle"""
+    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    rng = np.random.default_rng(12)
+    n = 1024
+    while True:
+        cx = rng.permutation(1200 * 640)[:n]
+        px, py = cx % 1200, cx // 1200                                # distinct centroids
+        trk = [(int(px[i]) - 40, int(py[i]) - 40, int(py[i]) + 39, int(px[i]) + 39, i % 3, 0.9) for i in range(n)]
+        det = [(int(px[i] + rng.integers(-3, 4)) - 40, int(py[i] + rng.integers(-3, 4)) - 40, int(py[i]) + 39, int(px[i]) + 39, int(i % 3), 0.9) for i in rng.permutation(n)]
+        at, ad, cost = c.assign(trk, det)
+        ra, rc = orc.assignment_optimal(oracle, orc.cost_matrix(oracle, trk, det), n, n)
+        assert np.array_equal(ad, ra) and cost == rc
+        if c.lap_stats()[0] == 0:
+            break                                                     # (a random scene may contain a symmetric tie: draw again)
+    assert c.assoc_stats()[0] == -1 and c.assoc_stats()[1] == 0       # certified: no step 4 / step 5 ran
+    trk[7] = trk[3][:4] + (trk[7][4], 0.9); trk[7] = trk[3]           # two tracks, one centroid and class: tied optima
+    at, ad, cost = c.assign(trk, det)
+    ra, rc = orc.assignment_optimal(oracle, orc.cost_matrix(oracle, trk, det), n, n)
+    assert np.array_equal(ad, ra) and cost == rc
+    st = c.lap_stats()
+    assert st[0] == 4 and st[6] >= 2 and c.assoc_stats()[0] >= 0, st[:8]
+    c.close()

@@ -18,7 +18,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 class Info(C.Structure):
     _fields_ = [("status", C.c_int), ("rounds", C.c_int), ("free0", C.c_int), ("searches", C.c_int), ("commits", C.c_int),
-                ("nedges", C.c_int), ("ncyclic", C.c_int), ("eps", C.c_double), ("gamma", C.c_double), ("cmax", C.c_double)]
+                ("nedges", C.c_int), ("ncyclic", C.c_int), ("hard", C.c_int), ("hard_scans", C.c_int), ("eps", C.c_double), ("gamma", C.c_double), ("cmax", C.c_double)]
 
 
 @pytest.fixture(scope="module")
