@@ -180,8 +180,11 @@ int mot_get_assoc_stats(mot_ctx* ctx, int* out16);
  * assignmentoptimal, hungarian.cpp:29-368, returns the unique optimum whenever there is one):
  * [0..15] most recent launch: [0] 0 = certified (emulation skipped), 1 = solver gave up / not applicable, 2 = dual check
  *   failed, 3 = too many near-tight edges, 4 = tied optima (order-exact emulation ran); [1] solver rounds [2] free rows after
- *   the greedy start [3] searches [4] commits [5] near-tight edges [6] nodes on cycles [7] solver time in 10 ns ticks
- * [16..20] cumulative launch counts of this context by outcome 0..4 */
+ *   the greedy start [3] searches [4] commits [5] near-tight edges [6] nodes on cycles [7] solver time in 10 ns ticks;
+ *   sparse order-exact emulation (runs when not certified): [8] 0 ok / 1 minimum outside the candidate lists / 2 n.a.,
+ *   [9] augmentations [10] step-5 passes [11] step-3 events [12..14] 10 ns ticks: steps 3+4, step 5, total;
+ *   [15] what decided this launch: 0 certificate, 1 sparse emulation (accepted by its after-the-fact check), 2 dense emulation
+ * [16..20] cumulative launch counts of this context by certificate outcome 0..4; [24] sparse emulation accepted, [25] refused */
 int mot_get_lap_stats(mot_ctx* ctx, int* out32);
 /* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
 int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);

@@ -17,7 +17,6 @@
 //     as self-tagged 8-byte granules (mk_helper_loop, assoc_common.h);
 //   * below 65 lines the Munkres workgroup computes costs, minima and bitmaps itself (mk_fused_cost).
 #include "assoc_common.h"
-#include "lap_certify.h"
 #include "dl_lifecycle.h"
 #include <stdlib.h>
 
@@ -387,9 +386,23 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     }
     if (!HELP && (want_cost & 2)) mk_fused_cost(a, S, nR, nC, rowsTrk);
     if (tid == 0) stat[15] = 0;                                        // set again only if a helper hand-off times out
-    bool certified = false;
-    if (lap_mode) certified = lap_certify(a.ws.lap, nR, nC, reinterpret_cast<unsigned*>(S.bm), S.flag);
-    __syncthreads();
+    // lap_mode: mk_sparse_kernel left its verdict: 0 = certified unique optimum, 1 = the sparse order-exact emulation ran and
+    // mk_postcheck_kernel found no entry outside the candidate lists that could have mattered -- in both cases the assignment
+    // is the reference's and the dense emulation below is skipped
+    bool certified = false; const short* given = nullptr;
+    if (lap_mode) {
+        const LapWs& L = a.ws.lap;
+        const int mode = L.hdr[LAP_H_MODE], spviol = L.hdr[LAP_H_SPVIOL];
+        if (mode == 0) { certified = true; given = L.colOfRow; }
+        else if (mode == 1 && !spviol) { certified = true; given = L.spAssign; }
+        __syncthreads();
+        if (tid == 0) {
+            L.hdr[LAP_H_LAST + 15] = mode == 0 ? 0 : (certified ? 1 : 2);   // what this frame used: 0 certificate, 1 sparse emulation, 2 dense emulation
+            if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
+            // re-arm for the next launch (this workgroup is the last reader)
+            L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2; *L.cmaxkey = 0ull;
+        }
+    }
     if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     const bool perRow = nR <= nC;
@@ -403,7 +416,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     if (tid == 0) S.flag[7] = 0;
     if (tid < 2 * MK_MAXW) { S.taken32[tid] = 0; S.cont32[tid] = 0; }
     if (certified) {                                                   // the unique optimum: nothing to emulate
-        if (tid < nR) S.starColOfRow[tid] = a.ws.lap.colOfRow[tid];
+        if (tid < nR) S.starColOfRow[tid] = given[tid];
         __syncthreads();
     }
     // ---- steps 1 + 2a: initial stars (hungarian.cpp:93-101 / :128-139) ----
@@ -857,6 +870,7 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
 }
 
 hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s);   // lap_kernels.hip
+hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s);   // mk_sparse.hip
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
                         const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid, const LifeArgs* life_in)
@@ -889,7 +903,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     if (!fused && maxR > 0 && maxC > 0) {
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
-        if (lap) { e = launch_lap_front(a, gR, gC, s); if (e != hipSuccess) return e; }
+        if (lap) { e = launch_lap_front(a, gR, gC, s); if (e != hipSuccess) return e; e = launch_mk_sparse(a, gR, gC, s); if (e != hipSuccess) return e; }
         else {
             hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
             hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);

@@ -1,5 +1,5 @@
-// lap_certify.h -- last stage of the assignment fast path (lap_kernels.hip), executed by the Munkres controller
-// workgroup before it would start the order-exact emulation.
+// lap_certify.h -- last stage of the assignment fast path (lap_kernels.hip), executed by the workgroup of
+// mk_sparse_kernel (mk_sparse.hip) before it would start the order-exact emulation.
 //
 // Input: the solver's matching M and duals, already checked entry by entry by lap_verify_kernel (LAP_H_VIOL), and the
 // list of near-tight edges  i -> i'  ("row i could take the column of row i' at a reduced cost below eps"; node nR
@@ -12,8 +12,9 @@
 
 namespace assoc {
 
-// scratch: >= LAP_EDGES unsigned + 2 * (MK_MAXN + 64) bytes of LDS.  Returns true (workgroup-uniform) iff certified.
-__device__ inline bool lap_certify(const LapWs& L, int nR, int nC, unsigned* scratch, int* flag2)
+// scratch: >= LAP_EDGES unsigned + 2 * (MK_MAXN + 64) bytes of LDS.  Returns 0 (workgroup-uniform) iff certified, else the
+// reason: 1 solver gave up / not applicable, 2 infeasible dual, 3 too many near-tight edges, 4 tied optima.
+__device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scratch, int* flag2)
 {
     const int tid = threadIdx.x;
     unsigned* ed = scratch;
@@ -47,11 +48,9 @@ __device__ inline bool lap_certify(const LapWs& L, int nR, int nC, unsigned* scr
     }
     if (tid == 0) {
         L.hdr[LAP_H_LAST + 0] = reason; L.hdr[LAP_H_LAST + 5] = ne; L.hdr[LAP_H_LAST + 6] = ncyc;
-        L.hdr[LAP_H_CUM + reason] += 1;                                  // [32] certified, [33..36] handed to the order-exact Munkres, by reason
-        // re-arm for the next launch (this workgroup is the last reader)
-        L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; *L.cmaxkey = 0ull;
+        L.hdr[LAP_H_CUM + reason] += 1;                                  // [32] certified, [33..36] not certified, by reason
     }
-    return reason == 0;
+    return reason;
 }
 
 } // namespace assoc

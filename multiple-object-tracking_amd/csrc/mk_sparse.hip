@@ -1,0 +1,340 @@
+// mk_sparse.hip -- SPARSE order-exact emulation of the reference's Munkres (trackers/hungarian/hungarian.cpp:29-368)
+// and its after-the-fact validity check.
+//
+// The dense emulation (assoc_kernels.hip) moves an n x n float64 matrix through every step 5.  Here every row keeps only
+// its LAP_K smallest entries (the candidate lists lap_rowscan_kernel produced) and the reference's state machine runs on
+// them, in LDS, with the reference's scan orders (step 1 :93-101, step 3 :249-275: columns ascending, rows ascending,
+// one hit per column and sweep), element arithmetic (:355-364: +h on covered rows first, then -h on uncovered columns)
+// and zero test fabs(x) < DBL_EPSILON.  An entry OUTSIDE the lists has, at any time,
+//        value = c[i][j] - rowmin_i + A_i(t) - S_j(t)  >=  c[i][j] - rowmin_i - S_j(final)
+// (A_i / S_j: what step 5 has added to row i / subtracted from column j so far; both only grow).  mk_postcheck_kernel
+// tests that bound against a margin for every such entry, with the S_j this run ended with: if it holds, no outside
+// entry was ever zero or the minimum of a step 5 (its value after that step is still positive, so it was above h),
+// so the dense run and this run are step by step the same run and the assignment is the reference's, ties included.
+// If it fails (dense / adversarial matrices, false-positive detections whose partner is far away) the final kernel
+// runs the dense emulation as before.  CPU model: mk_sparse_model.c (test infrastructure).
+//
+// One 1024-thread workgroup.  Thread = row for step 5 and the set-up; steps 3 / 4 / 2a / 2b run in wavefront 0:
+//   * zeros of a row: bit mask over its candidates; zeros of a column: the transposed candidate lists (rows ascending);
+//   * cnt[c] = zeros of column c in UNCOVERED rows (kept for every column), hz = {c : cnt[c] > 0} as a bit mask, so "the
+//     next uncovered column with an uncovered zero" is one masked find-first-bit, and covering a row costs one LDS atomic
+//     per zero of that row; after an augmentation (all rows uncovered, :324-330) cnt = tot, the per-column totals.
+#include "assoc_common.h"
+#include "lap_certify.h"
+
+using namespace assoc;
+
+namespace {
+
+#define SPK LAP_K
+#define SP_TLMAX 128            /* longest transposed list the set-up sorts; longer: not applicable */
+
+struct SpShared {
+    double d[SPK * MK_MAXN];                 // working values of the candidate entries, [k][row]
+    double Scol[MK_MAXN];                    // S_j
+    double red[MK_THREADS / 64];
+    u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
+    int cnt[MK_MAXN], tot[MK_MAXN];
+    unsigned short cj[SPK * MK_MAXN];        // candidate columns, [k][row] (0xFFFF: none)
+    unsigned short tl[SPK * MK_MAXN];        // transposed lists: (row << 4) | k, rows ascending inside a column
+    unsigned short tptr[MK_MAXN + 2];
+    unsigned short zmask[MK_MAXN];
+    short starColOfRow[MK_MAXN], starRowOfCol[MK_MAXN], primeColOfRow[MK_MAXN];
+    unsigned short clist[MK_MAXN];
+    int wave_tot[MK_THREADS / 64];
+    int flag[8];
+};
+static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
+static_assert(SPK <= 16, "candidate index is packed into 4 bits");
+
+__device__ __forceinline__ bool bit_of(const u64* m, int i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
+__device__ __forceinline__ void lds_and64(u64* p, u64 m) { unsigned* q = reinterpret_cast<unsigned*>(p); if ((unsigned)m != 0xFFFFFFFFu) atomicAnd(q, (unsigned)m); if ((unsigned)(m >> 32) != 0xFFFFFFFFu) atomicAnd(q + 1, (unsigned)(m >> 32)); }
+
+__global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_raw[];
+    SpShared& S = *reinterpret_cast<SpShared*>(sp_raw);
+    int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
+    const LapWs& L = a.ws.lap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t_begin = wall_clock64();
+    if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }
+    // ---- the fast path's verdict first: a certified unique optimum needs no emulation at all ----
+    const int bad = L.hdr[LAP_H_BAD];
+    const int reason = lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(S.d), S.flag);
+    __syncthreads();
+    if (reason == 0) { if (tid == 0) L.hdr[LAP_H_MODE] = 0; return; }
+    if (bad) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }          // negative / non-finite costs: dense emulation
+    // ---- set-up: candidate entries, d = c - row minimum (hungarian.cpp:83-89), zero masks, per-column totals ----
+    const int r = tid;
+    const int wordsC = (nC + 63) >> 6;
+    if (tid < 8) S.flag[tid] = 0;
+    S.cnt[tid] = 0; S.tot[tid] = 0; S.Scol[tid] = 0.0;
+    S.starColOfRow[tid] = -1; S.starRowOfCol[tid] = -1; S.primeColOfRow[tid] = -1;
+    if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
+    __syncthreads();
+    unsigned zm = 0;
+    if (r < nR) {
+        const double rmin = L.ccost[(size_t)r * SPK];
+#pragma unroll
+        for (int k = 0; k < SPK; k++) {
+            const unsigned short c = L.ccol[(size_t)r * SPK + k];
+            double x = DBL_MAX;
+            if (c != 0xFFFF) { x = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[c], 1); if (fabs(x) < DBL_EPSILON) { zm |= 1u << k; atomicAdd(&S.tot[c], 1); } }
+            S.d[k * MK_MAXN + r] = x; S.cj[k * MK_MAXN + r] = c;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SPK; k++) { S.d[k * MK_MAXN + r] = DBL_MAX; S.cj[k * MK_MAXN + r] = 0xFFFF; }
+    }
+    S.zmask[r] = (unsigned short)zm;
+    __syncthreads();
+    // transposed lists: exclusive scan of the per-column candidate counts, fill, sort each list by row
+    {
+        const int mycnt = tid < nC ? S.cnt[tid] : 0;
+        int incl = mycnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) S.wave_tot[wave] = incl;
+        if (mycnt > SP_TLMAX) S.flag[0] = 1;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += S.wave_tot[w];
+        const int excl = base + incl - mycnt;
+        S.tptr[tid] = (unsigned short)excl;
+        if (tid == MK_THREADS - 1) { S.tptr[MK_MAXN] = (unsigned short)(excl + mycnt); }
+        S.cnt[tid] = excl;                                             // fill cursor
+        __syncthreads();
+        if (S.flag[0]) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }
+        if (r < nR) {
+#pragma unroll
+            for (int k = 0; k < SPK; k++) { const unsigned short c = S.cj[k * MK_MAXN + r]; if (c != 0xFFFF) { const int p = atomicAdd(&S.cnt[c], 1); S.tl[p] = (unsigned short)((r << 4) | k); } }
+        }
+        __syncthreads();
+        if (tid < nC) {                                                // insertion sort (lists are short; rows sit in the high bits)
+            const int p0 = S.tptr[tid], p1 = p0 + mycnt;
+            for (int i = p0 + 1; i < p1; i++) { const unsigned short x = S.tl[i]; int j = i - 1; while (j >= p0 && S.tl[j] > x) { S.tl[j + 1] = S.tl[j]; j--; } S.tl[j + 1] = x; }
+        }
+        __syncthreads();
+    }
+    // ---- step 1 (:93-101): rows ascending, each stars its first zero BY COLUMN INDEX whose column is still free.  A row whose
+    // first zero lies in a column with a single zero can be starred out of order; the others go through an ordered pass ----
+    bool contested = false;
+    if (r < nR && zm) {
+        int fz = 0xFFFF;
+#pragma unroll
+        for (int k = 0; k < SPK; k++) if ((zm >> k) & 1) fz = min(fz, (int)S.cj[k * MK_MAXN + r]);
+        if (S.tot[fz] == 1) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; }
+        else contested = true;
+    }
+    {
+        const u64 bal = __ballot(contested);
+        if (lane == 0) S.wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, ncont = 0;
+        for (int w = 0; w < MK_THREADS / 64; w++) { const int t = S.wave_tot[w]; if (w < wave) off += t; ncont += t; }
+        if (contested) S.clist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
+        __syncthreads();
+        if (wave == 0) {                                               // ordered pass: lane = candidate slot of the row in turn
+            for (int q = 0; q < ncont; q++) {
+                const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
+                unsigned key = 0xFFFFu;
+                if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (S.starRowOfCol[c] < 0) key = (unsigned)c; }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) { const unsigned o = __shfl_xor(key, off); if (o < key) key = o; }
+                if (lane == 0 && key != 0xFFFFu) { S.starColOfRow[rr] = (short)key; S.starRowOfCol[key] = (short)rr; }
+            }
+        }
+        __syncthreads();
+    }
+    {   // step 2a: covered columns = starred columns
+        const bool has = tid < nC && S.starRowOfCol[tid] >= 0;
+        const u64 bal = __ballot(has);
+        if (lane == 0) S.covC[wave] = bal;
+        // cnt = tot (all rows uncovered), hz = hzAll
+        S.cnt[tid] = S.tot[tid];
+        const u64 hb = __ballot(S.tot[tid] > 0);
+        if (lane == 0) { S.hz[wave] = hb; S.hzAll[wave] = hb; }
+    }
+    __syncthreads();
+    int ncov = 0;
+    for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
+    bool done = ncov == nR;
+    int n_prime = 0, n_s5 = 0, n_aug = 0; long long t_s3 = 0, t_s5 = 0;
+    const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
+    u64 cC = (lane < MK_MAXW) ? S.covC[lane] : 0, cR = 0, phaseUnc = 0;   // wave 0: lane w holds word w
+    int status = 0;
+    while (!done) {
+        const long long t_a = wall_clock64();
+        // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
+        if (wave == 0) {
+            int action = 0; int from = 0; bool found = false;
+            while (action == 0) {
+                if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
+                u64 cand = (lane < MK_MAXW) ? (S.hz[lane] & ~cC & vC) : 0;
+                const int fw = from >> 6;
+                if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
+                const int col = wave_first_bit(cand, lane, MK_MAXW);
+                if (col < 0) { if (found) { found = false; from = 0; continue; } action = 2; break; }
+                // first uncovered row holding a zero in this column
+                const int p0 = S.tptr[col], p1 = S.tptr[col + 1];
+                int row = -1;
+                for (int base = p0; base < p1; base += 64) {
+                    const int e = (base + lane < p1) ? (int)S.tl[base + lane] : -1;
+                    bool hit = false;
+                    if (e >= 0) { const int rr = e >> 4, k = e & 15; hit = ((S.zmask[rr] >> k) & 1) && !bit_of(S.covR, rr); }
+                    const u64 b = __ballot(hit);
+                    if (b) { row = __builtin_amdgcn_readlane(e, __ffsll((long long)b) - 1) >> 4; break; }
+                }
+                if (row < 0) { action = 4; break; }                   // cnt / hz out of step with the masks: cannot happen
+                const int sc = S.starColOfRow[row];
+                if (lane == 0) S.primeColOfRow[row] = (short)col;      // :255
+                if (sc < 0) {
+                    // ---------- step 4 (:283-334) ----------
+                    n_aug++;
+                    int last = col;
+                    if (lane == 0) {
+                        int cr = row, cc = col;
+                        for (int it = 0; it <= nR + nC; it++) {
+                            const int old_r = S.starRowOfCol[cc];
+                            S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr;
+                            if (old_r < 0) break;
+                            cc = S.primeColOfRow[old_r]; cr = old_r;
+                            if (cc < 0) break;
+                        }
+                        last = cc;
+                    }
+                    last = __builtin_amdgcn_readfirstlane(last);
+                    if (lane < MK_MAXW) { u64 t = cR; while (t) { const int r2 = lane * 64 + __ffsll((long long)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
+                    if (lane == 0) S.primeColOfRow[row] = -1;
+                    cR = 0;
+                    cC |= phaseUnc; if (last >= 0 && lane == (last >> 6)) cC |= 1ull << (last & 63);
+                    phaseUnc = 0;
+                    if (lane < MK_MAXW) { S.covR[lane] = 0; S.hz[lane] = S.hzAll[lane]; }
+                    for (int i = lane; i < nC; i += 64) S.cnt[i] = S.tot[i];
+                    int total = 0;
+                    for (int w = 0; w < wordsC; w++) total += __popcll(readlane64(cC, w));
+                    if (total == nR) { action = 3; break; }
+                    from = 0; found = false;
+                    continue;
+                }
+                // cover the row (:270), uncover its star's column (:271)
+                if (lane == (row >> 6)) { cR |= 1ull << (row & 63); S.covR[lane] = cR; }
+                {
+                    const unsigned m = S.zmask[row];
+                    if (lane < SPK && ((m >> lane) & 1)) {
+                        const int c2 = S.cj[lane * MK_MAXN + row];
+                        if (atomicSub(&S.cnt[c2], 1) == 1) lds_and64(&S.hz[c2 >> 6], ~(1ull << (c2 & 63)));
+                    }
+                }
+                if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); }
+                found = true; from = col + 1;                          // :273
+            }
+            if (lane < MK_MAXW) S.covC[lane] = cC;
+            if (lane == 0) S.flag[1] = action;
+        }
+        __syncthreads();
+        const int action = S.flag[1];
+        const long long t_b = wall_clock64();
+        t_s3 += t_b - t_a;
+        if (action == 3) { done = true; break; }
+        if (action == 4) { status = 2; break; }
+        // ================= step 5 (:337-368) on the candidate entries: thread = row =================
+        n_s5++;
+        const bool rc = bit_of(S.covR, r);
+        double v[SPK]; bool unc[SPK];
+        double h = DBL_MAX;
+#pragma unroll
+        for (int k = 0; k < SPK; k++) {
+            const unsigned short c = S.cj[k * MK_MAXN + r];
+            v[k] = S.d[k * MK_MAXN + r];
+            unc[k] = c != 0xFFFF && !bit_of(S.covC, c);
+            if (!rc && unc[k] && v[k] < h) h = v[k];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(h, off); if (o < h) h = o; }
+        if (lane == 0) S.red[wave] = h;
+        S.cnt[tid] = 0; S.tot[tid] = 0;
+        __syncthreads();
+        h = S.red[0];
+#pragma unroll
+        for (int w = 1; w < MK_THREADS / 64; w++) { const double o = S.red[w]; if (o < h) h = o; }
+        if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
+        unsigned nm = 0;
+#pragma unroll
+        for (int k = 0; k < SPK; k++) {
+            const unsigned short c = S.cj[k * MK_MAXN + r];
+            if (c != 0xFFFF) {
+                double x = v[k];
+                if (rc) x += h;                                        // :355-358
+                if (unc[k]) x -= h;                                    // :361-364
+                S.d[k * MK_MAXN + r] = x;
+                if (fabs(x) < DBL_EPSILON) { nm |= 1u << k; atomicAdd(&S.tot[c], 1); if (!rc) atomicAdd(&S.cnt[c], 1); }
+            }
+        }
+        S.zmask[r] = (unsigned short)nm;
+        if (tid < nC && !bit_of(S.covC, tid)) S.Scol[tid] += h;
+        __syncthreads();
+        {
+            const u64 hb = __ballot(S.cnt[tid] > 0), ha = __ballot(S.tot[tid] > 0);
+            if (lane == 0) { S.hz[wave] = hb; S.hzAll[wave] = ha; }
+        }
+        __syncthreads();
+        t_s5 += wall_clock64() - t_b;
+    }
+    __syncthreads();
+    if (tid < nR) L.spAssign[tid] = S.starColOfRow[tid];
+    L.spS[tid] = S.Scol[tid];
+    if (tid == 0) {
+        L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
+        L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
+        L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
+    }
+}
+
+// every entry outside the candidate lists against the final S_j (see the header); grid of 64 x 64 tiles
+__global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
+{
+    int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
+    const LapWs& L = a.ws.lap;
+    if (L.hdr[LAP_H_MODE] != 1) return;                                // certified, or dense emulation anyway
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
+    if (blockIdx.x * 64 >= nR || c0 >= nC) return;
+    bool viol = false;
+    if (r < nR) {
+        const unsigned short lj = L.ccol[(size_t)r * SPK + SPK - 1];
+        if (lj != 0xFFFF) {                                            // (a row with fewer than LAP_K columns has every entry in its list)
+            const double rmin = L.ccost[(size_t)r * SPK], lc = L.ccost[(size_t)r * SPK + SPK - 1];
+            const double margin = 1e-9 * (1.0 + L.dhdr[3]);            // 1e-9 * (1 + largest cost): far above the reference's accumulated rounding
+            bbox_t rb = {};
+            if (!a.user) rb = rowsTrk ? a.trk[r] : a.det[r];
+            for (int cc = wave; cc < 64; cc += 4) {
+                const int c = c0 + cc;
+                if (c >= nC) break;
+                double cst;
+                if (a.user) cst = a.user[(size_t)r + (size_t)nR * c];
+                else cst = rowsTrk ? pair_cost(rb, a.det[c]) : pair_cost(a.trk[c], rb);
+                const bool outside = cst > lc || (cst == lc && c > (int)lj);
+                if (outside && !(cst - rmin - L.spS[c] > margin)) viol = true;
+            }
+        }
+    }
+    if (__syncthreads_or(viol) && threadIdx.x == 0) atomicOr(&L.hdr[LAP_H_SPVIOL], 1);
+}
+
+} // namespace
+
+hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s)
+{
+    static int attr_dev = -1;
+    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+    if (attr_dev != dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mk_sparse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SpShared));
+        if (e != hipSuccess) return e;
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(mk_sparse_kernel, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a);
+    hipLaunchKernelGGL(mk_postcheck_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

@@ -337,12 +337,13 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
         size_t off = 0; auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_cost = carve(sizeof(double) * 1024 * LAP_K), o_col = carve(sizeof(unsigned short) * 1024 * LAP_K), o_v = carve(sizeof(double) * 1024),
                      o_u = carve(sizeof(double) * 1024), o_cr = carve(sizeof(short) * 1024), o_rc = carve(sizeof(short) * 1024),
-                     o_e = carve(sizeof(unsigned) * LAP_EDGES), o_h = carve(sizeof(int) * 64), o_d = carve(sizeof(double) * 8), o_k = carve(8);
+                     o_e = carve(sizeof(unsigned) * LAP_EDGES), o_h = carve(sizeof(int) * 64), o_d = carve(sizeof(double) * 8), o_k = carve(8),
+                     o_sa = carve(sizeof(short) * 1024), o_ss = carve(sizeof(double) * 1024);
         HIPCHK(c->a_lap.alloc(off)); HIPCHK(hipMemset(c->a_lap.p, 0, off));
         unsigned char* b = c->a_lap.p; LapWs& L = c->assoc.lap;
         L.ccost = (double*)(b + o_cost); L.ccol = (unsigned short*)(b + o_col); L.v = (double*)(b + o_v); L.u = (double*)(b + o_u);
         L.colOfRow = (short*)(b + o_cr); L.rowOfCol = (short*)(b + o_rc); L.edges = (unsigned*)(b + o_e); L.hdr = (int*)(b + o_h);
-        L.dhdr = (double*)(b + o_d); L.cmaxkey = (unsigned long long*)(b + o_k);
+        L.dhdr = (double*)(b + o_d); L.cmaxkey = (unsigned long long*)(b + o_k); L.spAssign = (short*)(b + o_sa); L.spS = (double*)(b + o_ss);
     }
     // all-gather segment of one rank.  Ownership is tid % world (round-robin by creation id), which drifts under track churn:
     // a rank can own up to max_tracks of the live tracks, so every segment is sized for that (24 KB per rank at 1024 tracks:

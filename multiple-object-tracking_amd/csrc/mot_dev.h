@@ -96,11 +96,16 @@ struct LapWs {
     int* hdr;                 // [64] LAP_H_*
     double* dhdr;             // [8]  eps, tol, gamma, cmax
     unsigned long long* cmaxkey;  // order-preserving key of the largest cost (atomicMax)
+    short* spAssign;          // [1024] assignment found by the sparse order-exact emulation (mk_sparse.hip)
+    double* spS;              // [1024] S_j: what its step 5 passes subtracted from column j in total
 };
 enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 5 not applicable (negative / non-finite costs)
        LAP_H_NEDGES = 1, LAP_H_VIOL = 2, LAP_H_BAD = 3,
+       LAP_H_MODE = 4,        // verdict for the final kernel: 0 certified unique optimum (lap.colOfRow), 1 sparse emulation ran (lap.spAssign, valid
+                              // iff LAP_H_SPVIOL == 0), 2 run the dense order-exact emulation
+       LAP_H_SPVIOL = 5,      // mk_postcheck_kernel: an entry outside the candidate lists could have mattered
        LAP_H_LAST = 16,       // [16..31] statistics of the most recent launch: status, rounds, free rows, searches, commits, edges, cyclic nodes, device time (10 ns)
-       LAP_H_CUM = 32 };      // [32..] cumulative: launches certified, launches handed to the order-exact Munkres (by reason)
+       LAP_H_CUM = 32 };      // [32..36] cumulative certificate outcomes (0 certified, 1..4 reasons), [40] sparse emulation accepted, [41] refused -> dense
 
 struct AssocWs {
     double* dist;             // [1024*1024] working matrix, column-major

@@ -436,7 +436,7 @@ for trial in range(120):
     a, cost = c.assignment_optimal(d, nr, nc)
     ra, rc = orc.assignment_optimal(lib, d, nr, nc)
     assert np.array_equal(a, ra) and cost == rc, ("family", trial % 9, nr, nc)
-print("VARIANT_OK", c.assoc_stats()[:3].tolist(), "LAP", c.lap_stats()[16:21].tolist())
+print("VARIANT_OK", c.assoc_stats()[:3].tolist(), "LAP", c.lap_stats()[16:28].tolist())
 '''
 
 
@@ -464,13 +464,15 @@ def test_lap_fast_path_subprocess(mode):
     if mode == "off":
         assert sum(cum) == 0, cum
     else:
-        assert cum[0] > 20 and cum[4] > 20 and cum[2] == 0, cum     # certified, ties; the dual check must never fail
+        assert cum[0] > 20 and cum[4] > 20, cum                     # certified launches and tied optima both occurred
+        assert cum[2] <= 5, cum                                     # dense random matrices can defeat the sparse solver's duals (then the emulation decides); rare
+        assert cum[8] > 20 and cum[9] > 20, cum                     # uncertified problems: sparse emulation accepted / refused (dense emulation ran)
 
 
 def test_lap_fast_path_counters(mot, oracle):
     """default configuration: a crowded 1024 x 1024 tracking problem with a unique optimum is certified (no emulation:
     step counters stay at their 'skipped' mark), the same problem with two tracks on one centroid is a tie and goes through
-    the emulation; both equal the oracle"""
+    the sparse order-exact emulation, a dense random matrix through the dense one; all equal the oracle"""
     c = mot.MotContext(max_tracks=1024, max_dets=1024)
     rng = np.random.default_rng(12)
     n = 1024
@@ -490,5 +492,12 @@ def test_lap_fast_path_counters(mot, oracle):
     ra, rc = orc.assignment_optimal(oracle, orc.cost_matrix(oracle, trk, det), n, n)
     assert np.array_equal(ad, ra) and cost == rc
     st = c.lap_stats()
-    assert st[0] == 4 and st[6] >= 2 and c.assoc_stats()[0] >= 0, st[:8]
+    assert st[0] == 4 and st[6] >= 2, st[:8]                           # the certificate refused: tied optima ...
+    assert st[15] == 1 and st[8] == 0 and st[9] > 0, st[8:16]          # ... and the sparse order-exact emulation decided the tie
+    # a dense random matrix defeats the candidate lists: the sparse run is refused after the fact, the dense emulation decides
+    d = rng.uniform(0, 1, size=300 * 300)
+    a, cost = c.assignment_optimal(d, 300, 300)
+    ra, rc = orc.assignment_optimal(oracle, d, 300, 300)
+    assert np.array_equal(a, ra) and cost == rc
+    assert c.lap_stats()[15] == 2 and c.assoc_stats()[0] >= 0
     c.close()
