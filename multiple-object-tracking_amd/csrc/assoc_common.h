@@ -100,6 +100,48 @@ __device__ __forceinline__ u64 readlane64(u64 v, int src)          // src must b
     return ((u64)hi << 32) | lo;
 }
 
+// ---- wave reductions on the DPP path (hipcc lowers __shfl_xor to ds_bpermute: an LDS round trip per step and half) ----
+// four v_mov_dpp steps reduce inside every row of 16 lanes (all 16 lanes end up with the row's result), the four row results are
+// combined through v_readlane: the result is wave-uniform
+template <int CTRL> __device__ __forceinline__ unsigned dpp_mov32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ u64 dpp_mov64(u64 v) { return ((u64)dpp_mov32<CTRL>((unsigned)(v >> 32)) << 32) | dpp_mov32<CTRL>((unsigned)v); }
+#define DPP_QUAD_XOR1 0xB1      /* quad_perm [1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E      /* quad_perm [2,3,0,1] */
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+__device__ __forceinline__ u64 row16_min_u64(u64 v)
+{
+    u64 o;
+    o = dpp_mov64<DPP_QUAD_XOR1>(v); v = o < v ? o : v;
+    o = dpp_mov64<DPP_QUAD_XOR2>(v); v = o < v ? o : v;
+    o = dpp_mov64<DPP_ROW_HALF_MIRROR>(v); v = o < v ? o : v;
+    o = dpp_mov64<DPP_ROW_MIRROR>(v); v = o < v ? o : v;
+    return v;
+}
+__device__ __forceinline__ u64 wave_min_u64_dpp(u64 v)
+{
+    v = row16_min_u64(v);
+    const u64 a = readlane64(v, 0), b = readlane64(v, 16), c = readlane64(v, 32), d = readlane64(v, 48);
+    const u64 ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ u64 wave_max_u64_dpp(u64 v) { return ~wave_min_u64_dpp(~v); }
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)
+{
+    unsigned o;
+    o = dpp_mov32<DPP_QUAD_XOR1>(v); v = o < v ? o : v;
+    o = dpp_mov32<DPP_QUAD_XOR2>(v); v = o < v ? o : v;
+    o = dpp_mov32<DPP_ROW_HALF_MIRROR>(v); v = o < v ? o : v;
+    o = dpp_mov32<DPP_ROW_MIRROR>(v); v = o < v ? o : v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// minimum of doubles (any sign, no NaNs): through the order-preserving key
+__device__ __forceinline__ double wave_min_f64_dpp(double x) { return dunkey(wave_min_u64_dpp(dkey(x))); }
+__device__ __forceinline__ double row16_min_f64(double x) { return dunkey(row16_min_u64(dkey(x))); }
+
 __device__ __forceinline__ int wave_first_bit(u64 m, int lane, int nwords)
 {   // lanes < nwords hold words of a line; returns index of the first set bit, or -1 (wave-uniform)
     const u64 bal = __ballot(lane < nwords && m != 0);

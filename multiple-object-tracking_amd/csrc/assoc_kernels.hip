@@ -52,10 +52,12 @@ __global__ void __launch_bounds__(256) assoc_min_kernel(AssocArgs a)
     if (perRow && r < nR && best != ~0ull) atomicMin(&a.linemin[r], best);
 }
 
-// pass 2: working matrix d = cost - linemin, zero bitmaps in both orientations
-__global__ void __launch_bounds__(256) assoc_sub_kernel(AssocArgs a)
+// pass 2: working matrix d = cost - linemin, zero bitmaps in both orientations.  lazy: behind the fast path (lap_kernels.hip,
+// mk_sparse.hip) this is only needed when the dense emulation has to run -- every workgroup checks the verdict and leaves
+__global__ void __launch_bounds__(256) assoc_sub_kernel(AssocArgs a, int lazy)
 {
     __shared__ unsigned int zr_lo[64], zr_hi[64];
+    if (lazy) { const int mode = a.ws.lap.hdr[LAP_H_MODE]; if (mode == 0 || (mode == 1 && !a.ws.lap.hdr[LAP_H_SPVIOL])) return; }
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
@@ -869,7 +871,7 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
     return hipGetLastError();
 }
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s);   // lap_kernels.hip
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid);   // lap_kernels.hip
 hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s);   // mk_sparse.hip
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
@@ -903,10 +905,15 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     if (!fused && maxR > 0 && maxC > 0) {
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
-        if (lap) { e = launch_lap_front(a, gR, gC, s); if (e != hipSuccess) return e; e = launch_mk_sparse(a, gR, gC, s); if (e != hipSuccess) return e; }
+        if (lap) {
+            e = launch_lap_front(a, gR, gC, s, ev_mid); if (e != hipSuccess) return e;
+            ev_mid = nullptr;
+            e = launch_mk_sparse(a, gR, gC, s); if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a, 1);   // working matrix + bitmaps, only if the dense emulation must run
+        }
         else {
             hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a, 0);
         }
     }
     if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }   // cost kernels submitted, the Munkres kernel comes next
@@ -925,7 +932,9 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // every problem above 256 lines, =0 off; default: above MK_HELP_MIN lines.
     static int helpers = -1;
     if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
-    const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN));
+    // behind the fast path the dense emulation is the rare last resort: one workgroup, not the 1 + 128 workgroup helper grid
+    // (whose launch alone costs more than the common case's whole final kernel)
+    const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && !lap));
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life, lap ? 1 : 0);
     return hipGetLastError();

@@ -12,8 +12,7 @@
 //                       column it scanned and of its end column, which makes concurrent dual updates commute (proof
 //                       sketch in DESIGN.md 4.3).  Row duals are implicit (u_i = c[i][M(i)] - v[M(i)]), so matched
 //                       edges are tight by construction.  The solver is UNTRUSTED: whatever it returns is checked by
-//   lap_verify_kernel   the dense pass (it also produces what the Munkres kernel needs if it has to run: working
-//                       matrix d = cost - row minimum and the zero bitmaps, i.e. assoc_sub_kernel's work): reduced
+//   lap_verify_kernel   the dense pass: reduced
 //                       cost r = c - u_i - v_j of EVERY entry must be >= -tol, prices <= 0 and exactly 0 on free
 //                       columns (dual feasibility + complementary slackness => optimal), and every entry with r < eps
 //                       that is not matched is recorded as an edge "row i could take the column of row i'".
@@ -26,25 +25,6 @@
 using namespace assoc;
 
 namespace {
-
-__device__ __forceinline__ u64 wave_min_u64(u64 v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(v, off); if (o < v) v = o; }
-    return v;
-}
-__device__ __forceinline__ u64 wave_max_u64(u64 v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(v, off); if (o > v) v = o; }
-    return v;
-}
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(v, off); if (o < v) v = o; }
-    return v;
-}
 
 // ---- stage 1 ----------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
@@ -79,9 +59,9 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
         u64 lk = ~0ull; int lt = 0;
 #pragma unroll
         for (int t = 0; t < MK_MAXN / 64; t++) if (key[t] < lk) { lk = key[t]; lt = t; }
-        const u64 wm = wave_min_u64(lk);
+        const u64 wm = wave_min_u64_dpp(lk);
         const unsigned mycol = (lk == wm && lk != ~0ull) ? (unsigned)(lt * 64 + lane) : 0xFFFFFFFFu;
-        const unsigned wc = wave_min_u32(mycol);                      // equal cost: the lowest column
+        const unsigned wc = wave_min_u32_dpp(mycol);                      // equal cost: the lowest column
         if (lane == 0) {
             L.ccol[(size_t)r * LAP_K + k] = wc == 0xFFFFFFFFu ? (unsigned short)0xFFFF : (unsigned short)wc;
             L.ccost[(size_t)r * LAP_K + k] = wc == 0xFFFFFFFFu ? DBL_MAX : dunkey(wm);
@@ -92,32 +72,48 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
             for (int t = 0; t < MK_MAXN / 64; t++) if (t == lt) key[t] = ~0ull;
         }
     }
-    mx = wave_max_u64(mx);
+    mx = wave_max_u64_dpp(mx);
     if (lane == 0) atomicMax(L.cmaxkey, mx);
     if (__ballot(bad) && lane == 0) atomicOr(&L.hdr[LAP_H_BAD], 1);
 }
 
 // ---- stage 2 ----------------------------------------------------------------------------------------------------
+// One search = one WAVEFRONT: the touched columns of the search live in the registers of lanes 0..LAP_TS-1 (column,
+// tentative distance, predecessor), the minimum is a wave reduction, and relaxing a candidate is a ballot over the touched
+// columns -- no LDS traffic besides the candidate list of the row being scanned.  Sixteen searches run at a time; every
+// wavefront works through its share of the round's free rows on the SAME snapshot (nothing is written to prices or matching
+// until the round's barrier), leaves a record (scanned columns with their price decrements, the augmenting path) in LDS,
+// and takes locks; after the barrier the searches that hold all their locks commit.
+#define LAP_SR 64                          /* searches per round (4 per wavefront) */
+struct LapRec {
+    double dec[LAP_TS];                  // scanned slots: Delta - d (what the column's price drops by)
+    unsigned short col[LAP_TS];          // touched columns
+    unsigned short prow[LAP_TS], pcol[LAP_TS];   // augmenting path: row prow[n] takes column pcol[n] ...
+    unsigned char pk[LAP_TS];            // ... which is its pk[n]-th candidate
+    unsigned char flag[LAP_TS];          // 1 scanned, 2 end column
+    int nt, plen, ok, pad;
+};
 struct LapShared {
     double cc[MK_MAXN * LAP_K];          // candidate costs, [row][k]
     double v[MK_MAXN];                   // column prices
-    double sd[LAP_S * LAP_TS];           // per search: tentative distance of every touched column
-    double sdelta[LAP_S];
+    double mcost[MK_MAXN];               // cost of the row's matched edge
     double red[MK_THREADS / 64];
+    LapRec rec[LAP_SR];
     unsigned lock[MK_MAXN];
     unsigned short cj[MK_MAXN * LAP_K];  // candidate columns
-    unsigned short scol[LAP_S * LAP_TS];
-    short spred[LAP_S * LAP_TS];         // row that reached the column ...
-    unsigned char spk[LAP_S * LAP_TS];   // ... through its k-th candidate
-    unsigned char sscan[LAP_S * LAP_TS];
     short rowOfCol[MK_MAXN], colOfRow[MK_MAXN];
     unsigned short flist[MK_MAXN];
-    unsigned char matchK[MK_MAXN];
-    short snt[LAP_S], send[LAP_S];
     int wave_tot[MK_THREADS / 64];
     int flag[8];
 };
 static_assert(sizeof(LapShared) <= MOT_LDS_LIMIT, "lap_solve_kernel LDS");
+static_assert(LAP_TS <= 32 && LAP_K <= 16, "search state: one touched column per lane, candidates in the low lanes");
+
+__device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-uniform
+{
+    const u64 b = (u64)__double_as_longlong(x);
+    return __longlong_as_double((long long)readlane64(b, src));
+}
 
 __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
 {
@@ -136,7 +132,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     // greedy start: every row asks for its cheapest column, the lowest row wins
     if (tid < nR) atomicMin(&S.lock[S.cj[tid * LAP_K]], (unsigned)tid);
     __syncthreads();
-    if (tid < nR) { const int j = S.cj[tid * LAP_K]; if (S.lock[j] == (unsigned)tid) { S.rowOfCol[j] = (short)tid; S.colOfRow[tid] = (short)j; S.matchK[tid] = 0; } }
+    if (tid < nR) { const int j = S.cj[tid * LAP_K]; if (S.lock[j] == (unsigned)tid) { S.rowOfCol[j] = (short)tid; S.colOfRow[tid] = (short)j; S.mcost[tid] = S.cc[tid * LAP_K]; } }
     __syncthreads();
     int rounds = 0, free0 = -1, searches = 0, commits = 0;
     for (;;) {
@@ -151,73 +147,84 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
         if (isfree) S.flist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)tid;
         if (free0 < 0) free0 = nf;
         if (nf == 0) break;
-        if (++rounds > 4 * MK_MAXN) { if (tid == 0) S.flag[0] = 1; __syncthreads(); break; }
+        if (++rounds > 8 * MK_MAXN) { if (tid == 0) S.flag[0] = 1; __syncthreads(); break; }
         __syncthreads();
-        const int ns = min(nf, LAP_S);
+        const int ns = min(nf, LAP_SR);
         searches += ns;
-        // searcher q runs on lane q / 16 of wave q % 16: eight lanes per wavefront, sixteen wavefronts in flight
-        const int q = lane * (MK_THREADS / 64) + wave;
-        const bool searcher = lane < LAP_S / (MK_THREADS / 64) && q < ns;
-        double* sd = S.sd + q * LAP_TS; unsigned short* scol = S.scol + q * LAP_TS; short* spred = S.spred + q * LAP_TS;
-        unsigned char* spk = S.spk + q * LAP_TS; unsigned char* sscan = S.sscan + q * LAP_TS;
-        int nt = 0, jend = -1; double Delta = 0.0; bool ok = false;
-        if (searcher) {
+        for (int q = wave; q < ns; q += MK_THREADS / 64) {
+            LapRec& R = S.rec[q];
             const int s0 = S.flist[q];
-            double us = DBL_MAX;
-            for (int k = 0; k < LAP_K; k++) { const int j = S.cj[s0 * LAP_K + k]; if (j == 0xFFFF) break; const double x = S.cc[s0 * LAP_K + k] - S.v[j]; if (x < us) us = x; }
-            for (int k = 0; k < LAP_K; k++) {
-                const int j = S.cj[s0 * LAP_K + k]; if (j == 0xFFFF) break;
-                scol[nt] = (unsigned short)j; sd[nt] = (S.cc[s0 * LAP_K + k] - S.v[j]) - us; spred[nt] = (short)s0; spk[nt] = (unsigned char)k; sscan[nt] = 0; nt++;
-            }
-            bool fail = false;
+            // the start row's candidates seed the touched list (slot = candidate index)
+            int tcol = -1, tpred = s0, tpk = lane; double td = DBL_MAX; bool tscan = false;
+            double x0 = DBL_MAX;
+            if (lane < LAP_K) { const int j = S.cj[s0 * LAP_K + lane]; if (j != 0xFFFF) { tcol = j; x0 = S.cc[s0 * LAP_K + lane] - S.v[j]; } }
+            const double us = row16_min_f64(x0);                       // candidates sit in lanes 0..15
+            if (tcol >= 0) td = x0 - us;
+            int nt = __popcll(__ballot(tcol >= 0));                    // valid candidates are a prefix of the list
+            double Delta = 0.0; int jend = -1; bool fail = false;
             for (;;) {
-                int b = -1; double best = DBL_MAX;
-                for (int t = 0; t < nt; t++) if (!sscan[t] && sd[t] < best) { best = sd[t]; b = t; }
-                if (b < 0) { fail = true; break; }                    // no augmenting path inside the candidate graph
+                // closest touched column that is not scanned yet; equal distance: the earlier slot
+                const double best = wave_min_f64_dpp((lane < nt && !tscan) ? td : DBL_MAX);
+                const u64 bm = __ballot(lane < nt && !tscan && td == best);
+                if (!bm || !(best < DBL_MAX)) { fail = true; break; }  // no augmenting path inside the candidate graph
+                const int b = __ffsll((long long)bm) - 1;
                 Delta = best;
-                const int j = scol[b];
+                const int j = __builtin_amdgcn_readlane(tcol, b);
                 const int i = S.rowOfCol[j];
                 if (i < 0) { jend = b; break; }
-                sscan[b] = 1;
-                const double ui = S.cc[i * LAP_K + S.matchK[i]] - S.v[j];
+                if (lane == b) tscan = true;
+                const double ui = S.mcost[i] - S.v[j];
+                int cj2 = 0xFFFF; double nd = DBL_MAX;
+                if (lane < LAP_K) { cj2 = S.cj[i * LAP_K + lane]; if (cj2 != 0xFFFF) nd = best + ((S.cc[i * LAP_K + lane] - S.v[cj2]) - ui); }
+#pragma unroll
                 for (int k = 0; k < LAP_K; k++) {
-                    const int j2 = S.cj[i * LAP_K + k];
+                    const int j2 = __builtin_amdgcn_readlane(cj2, k);
                     if (j2 == 0xFFFF) break;
                     if (j2 == j) continue;
-                    const double nd = best + ((S.cc[i * LAP_K + k] - S.v[j2]) - ui);
-                    int t = 0; while (t < nt && scol[t] != j2) t++;
-                    if (t < nt) { if (!sscan[t] && nd < sd[t]) { sd[t] = nd; spred[t] = (short)i; spk[t] = (unsigned char)k; } }
+                    const double ndk = readlane_f64(nd, k);
+                    const u64 m = __ballot(lane < nt && tcol == j2);
+                    if (m) { if (((m >> lane) & 1) && !tscan && ndk < td) { td = ndk; tpred = i; tpk = k; } }
                     else if (nt == LAP_TS) { fail = true; break; }
-                    else { scol[t] = (unsigned short)j2; sd[t] = nd; spred[t] = (short)i; spk[t] = (unsigned char)k; sscan[t] = 0; nt++; }
+                    else { if (lane == nt) { tcol = j2; td = ndk; tpred = i; tpk = k; tscan = false; } nt++; }
                 }
                 if (fail) break;
             }
-            ok = !fail;
-            if (fail) S.flag[0] = 1;
-            else for (int t = 0; t < nt; t++) if (sscan[t] || t == jend) atomicMin(&S.lock[scol[t]], (unsigned)q);
+            if (fail) { if (lane == 0) { R.ok = 0; S.flag[0] = 1; } continue; }
+            // record: touched columns, price decrements of the scanned ones, locks
+            const bool need = lane < nt && (tscan || lane == jend);
+            if (lane < nt) { R.col[lane] = (unsigned short)tcol; R.dec[lane] = Delta - td; R.flag[lane] = (unsigned char)((tscan ? 1 : 0) | (lane == jend ? 2 : 0)); }
+            if (need) atomicMin(&S.lock[tcol], (unsigned)q);
+            // the augmenting path, end column first
+            int plen = 0, t = jend;
+            for (int guard = 0; guard <= LAP_TS; guard++) {
+                const int pi = __builtin_amdgcn_readlane(tpred, t), pkk = __builtin_amdgcn_readlane(tpk, t), pc = __builtin_amdgcn_readlane(tcol, t);
+                if (lane == 0) { R.prow[plen] = (unsigned short)pi; R.pcol[plen] = (unsigned short)pc; R.pk[plen] = (unsigned char)pkk; }
+                plen++;
+                if (pi == s0) break;
+                const int pj = S.colOfRow[pi];                         // a tree row's column is a scanned column of this search
+                const u64 m = __ballot(lane < nt && tcol == pj);
+                if (!m) { plen = -1; break; }
+                t = __ffsll((long long)m) - 1;
+            }
+            if (lane == 0) { R.nt = nt; R.plen = plen; R.ok = plen > 0; if (plen <= 0) S.flag[0] = 2; }
         }
         __syncthreads();
         if (S.flag[0]) break;
-        if (searcher && ok) {
-            bool mine = true;
-            for (int t = 0; t < nt; t++) if ((sscan[t] || t == jend) && S.lock[scol[t]] != (unsigned)q) mine = false;
-            if (mine) {
-                const int s0 = S.flist[q];
-                commits++;
-                for (int t = 0; t < nt; t++) if (sscan[t]) S.v[scol[t]] -= (Delta - sd[t]);
-                int t = jend;
-                for (int guard = 0; guard <= LAP_TS; guard++) {
-                    const int j = scol[t], i = spred[t];
-                    const int pj = S.colOfRow[i];
-                    S.colOfRow[i] = (short)j; S.matchK[i] = spk[t]; S.rowOfCol[j] = (short)i;
-                    if (i == s0) break;
-                    t = 0; while (t < nt && scol[t] != pj) t++;
-                    if (t >= nt) { S.flag[0] = 2; break; }           // cannot happen: a tree row's column is a scanned column
-                }
+        // commits: a search that holds the lock of every column it scanned and of its end column
+        for (int q = wave; q < ns; q += MK_THREADS / 64) {
+            const LapRec& R = S.rec[q];
+            const int nt = R.nt;
+            const bool need = lane < nt && R.flag[lane] != 0;
+            const bool lost = need && S.lock[R.col[lane]] != (unsigned)q;
+            if (__ballot(lost)) continue;
+            commits++;
+            if (lane < nt && (R.flag[lane] & 1)) S.v[R.col[lane]] -= R.dec[lane];
+            if (lane < R.plen) {
+                const int pi = R.prow[lane], pc = R.pcol[lane];
+                S.colOfRow[pi] = (short)pc; S.rowOfCol[pc] = (short)pi; S.mcost[pi] = S.cc[pi * LAP_K + R.pk[lane]];
             }
         }
         __syncthreads();
-        if (S.flag[0]) break;
     }
     __syncthreads();
     const int status = S.flag[0] ? 1 : 0;
@@ -225,7 +232,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     double g = 0.0;
     if (!status && tid < nR) {
         const int j = S.colOfRow[tid];
-        const double cm = S.cc[tid * LAP_K + S.matchK[tid]];
+        const double cm = S.mcost[tid];
         L.u[tid] = cm - S.v[j];
         g = cm - S.cc[tid * LAP_K];
     }
@@ -233,12 +240,8 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     for (int off2 = 32; off2 > 0; off2 >>= 1) g += __shfl_xor(g, off2);
     if (lane == 0) S.red[wave] = g;
     L.v[tid] = S.v[tid]; L.colOfRow[tid] = S.colOfRow[tid]; L.rowOfCol[tid] = S.rowOfCol[tid];
-    // commits per thread are only statistics: sum them
-    int cs = commits;
-#pragma unroll
-    for (int off2 = 32; off2 > 0; off2 >>= 1) cs += __shfl_xor(cs, off2);
     __syncthreads();
-    if (lane == 0) S.wave_tot[wave] = cs;
+    if (lane == 0) S.wave_tot[wave] = commits;                         // (wave-uniform counter)
     __syncthreads();
     if (tid == 0) {
         double gamma = 0.0; int ctot = 0;
@@ -256,56 +259,52 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
 }
 
 // ---- stage 3 ----------------------------------------------------------------------------------------------------
-// assoc_sub_kernel (working matrix + zero bitmaps for the Munkres kernel) + the dense dual check + near-tight edges
+// the dense dual check + near-tight edges, 64 x 64 tiles; a tile's column data (boxes, prices, owners) are staged in LDS
+// once so that the sqrt chain of an element does not wait on global loads
 __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a)
 {
-    __shared__ unsigned int zr_lo[64], zr_hi[64];
+    __shared__ bbox_t colb[64]; __shared__ double colv[64]; __shared__ int colo[64];
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const LapWs& L = a.ws.lap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
-    const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
-    if (threadIdx.x < 64) { zr_lo[threadIdx.x] = 0; zr_hi[threadIdx.x] = 0; }
-    __syncthreads();
-    const bool solved = L.hdr[LAP_H_SOLVE] == 0;
+    if (L.hdr[LAP_H_SOLVE] != 0) return;                               // nothing to check: the solver gave up / was not applicable
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
+        const int c = c0 + threadIdx.x;
+        if (!a.user) colb[threadIdx.x] = rowsTrk ? a.det[c] : a.trk[c];
+        colv[threadIdx.x] = L.v[c]; colo[threadIdx.x] = L.rowOfCol[c];
+    }
     const double eps = L.dhdr[0], tol = L.dhdr[1];
-    const double rmin = r < nR ? dunkey(a.linemin[r]) : 0.0;
-    const double ur = (solved && r < nR) ? L.u[r] : 0.0;
-    const int mr = (solved && r < nR) ? (int)L.colOfRow[r] : -1;
+    const double ur = r < nR ? L.u[r] : 0.0;
+    const int mr = r < nR ? (int)L.colOfRow[r] : -1;
     bbox_t rb = {};
     if (!a.user && r < nR) rb = rowsTrk ? a.trk[r] : a.det[r];
+    __syncthreads();
     bool viol = false;
-    for (int cc = wave; cc < 64; cc += 4) {
-        const int c = c0 + cc;
-        if (c >= nC) break;
-        bool z = false;
-        if (r < nR) {
+    if (r < nR) {
+#pragma unroll 4
+        for (int cc = wave; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            if (c >= nC) break;
             double cst;
             if (a.user) cst = a.user[(size_t)r + (size_t)nR * c];
-            else cst = rowsTrk ? pair_cost(rb, a.det[c]) : pair_cost(a.trk[c], rb);
-            const double d = cst - rmin;
-            a.ws.dist[(size_t)r + (size_t)nR * c] = d;
-            z = fabs(d) < DBL_EPSILON;
-            if (solved && c != mr) {
-                const double red = (cst - L.v[c]) - ur;
+            else cst = rowsTrk ? pair_cost(rb, colb[cc]) : pair_cost(colb[cc], rb);
+            if (c != mr) {
+                const double red = (cst - colv[cc]) - ur;
                 if (!(red >= -tol)) viol = true;
                 else if (red < eps) {
                     const int e = atomicAdd(&L.hdr[LAP_H_NEDGES], 1);
-                    const int owner = L.rowOfCol[c];
+                    const int owner = colo[cc];
                     if (e < LAP_EDGES) L.edges[e] = ((unsigned)r << 16) | (unsigned)(owner >= 0 ? owner : nR);
                 }
             }
         }
-        const u64 bal = __ballot(z);
-        if (lane == 0) a.ws.zc[(size_t)c * wordsR + blockIdx.x] = bal;
-        if (z) { if (cc < 32) atomicOr(&zr_lo[lane], 1u << cc); else atomicOr(&zr_hi[lane], 1u << (cc - 32)); }
     }
     // per column (first row tile only): prices <= 0, exactly 0 on free columns; "a free column could take this column's row"
-    if (solved && blockIdx.x == 0 && threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
-        const int c = c0 + threadIdx.x;
-        const double vc = L.v[c];
-        const int owner = L.rowOfCol[c];
+    if (blockIdx.x == 0 && threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
+        const double vc = colv[threadIdx.x];
+        const int owner = colo[threadIdx.x];
         if (!(vc <= 0.0) || (owner < 0 && vc != 0.0)) viol = true;
         else if (owner >= 0 && nC > nR && -vc < eps) {
             const int e = atomicAdd(&L.hdr[LAP_H_NEDGES], 1);
@@ -313,12 +312,11 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a)
         }
     }
     if (__syncthreads_or(viol) && threadIdx.x == 0) atomicOr(&L.hdr[LAP_H_VIOL], 1);
-    if (threadIdx.x < 64 && r < nR) a.ws.zr[(size_t)r * wordsC + blockIdx.y] = ((u64)zr_hi[threadIdx.x] << 32) | zr_lo[threadIdx.x];
 }
 
 } // namespace
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s)
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid)
 {
     static int attr_dev = -1;                                          // per-device function attribute
     int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
@@ -328,6 +326,9 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s)
         attr_dev = dev;
     }
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
+    // device loop: from here on the chip is mostly idle (one-workgroup solver, short dense passes) -- the detection features of the
+    // split update start now on the side stream
+    if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a);
     hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -16,9 +16,10 @@
 //
 // One 1024-thread workgroup.  Thread = row for step 5 and the set-up; steps 3 / 4 / 2a / 2b run in wavefront 0:
 //   * zeros of a row: bit mask over its candidates; zeros of a column: the transposed candidate lists (rows ascending);
-//   * cnt[c] = zeros of column c in UNCOVERED rows (kept for every column), hz = {c : cnt[c] > 0} as a bit mask, so "the
-//     next uncovered column with an uncovered zero" is one masked find-first-bit, and covering a row costs one LDS atomic
-//     per zero of that row; after an augmentation (all rows uncovered, :324-330) cnt = tot, the per-column totals.
+//   * per column two slot masks over its transposed list: tzero (slots holding a zero) and tlive (... in an UNCOVERED row),
+//     and hz = {c : tlive[c] != 0} as a bit mask: "the next uncovered column with an uncovered zero" is one masked
+//     find-first-bit, "its first uncovered zero row" one LDS round trip, and covering a row one LDS atomic per zero of
+//     that row; after an augmentation (all rows uncovered, :324-330) tlive = tzero.
 #include "assoc_common.h"
 #include "lap_certify.h"
 
@@ -27,28 +28,30 @@ using namespace assoc;
 namespace {
 
 #define SPK LAP_K
-#define SP_TLMAX 128            /* longest transposed list the set-up sorts; longer: not applicable */
+#define SP_TLS 32               /* slots per column in the transposed lists; a column wanted by more rows: not applicable */
 
 struct SpShared {
-    double d[SPK * MK_MAXN];                 // working values of the candidate entries, [k][row]
     double Scol[MK_MAXN];                    // S_j
     double red[MK_THREADS / 64];
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
-    int cnt[MK_MAXN], tot[MK_MAXN];
+    unsigned tzero[MK_MAXN];                 // per column: which of its slots hold a zero
+    unsigned tlive[MK_MAXN];                 // ... a zero in an UNCOVERED row
+    unsigned short tl[SP_TLS * MK_MAXN];     // transposed lists, [column][slot]: (row << 4) | k, rows ascending
     unsigned short cj[SPK * MK_MAXN];        // candidate columns, [k][row] (0xFFFF: none)
-    unsigned short tl[SPK * MK_MAXN];        // transposed lists: (row << 4) | k, rows ascending inside a column
-    unsigned short tptr[MK_MAXN + 2];
-    unsigned short zmask[MK_MAXN];
+    unsigned char pos[SPK * MK_MAXN];        // slot of (row, k) in its column's list
+    unsigned short zmask[MK_MAXN];           // zeros of a row as a mask over its candidates
     short starColOfRow[MK_MAXN], starRowOfCol[MK_MAXN], primeColOfRow[MK_MAXN];
     unsigned short clist[MK_MAXN];
+    int cnt[MK_MAXN];                        // set-up only: fill cursors
     int wave_tot[MK_THREADS / 64];
     int flag[8];
 };
 static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
 static_assert(SPK <= 16, "candidate index is packed into 4 bits");
+static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certify scratch");
 
 __device__ __forceinline__ bool bit_of(const u64* m, int i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
-__device__ __forceinline__ void lds_and64(u64* p, u64 m) { unsigned* q = reinterpret_cast<unsigned*>(p); if ((unsigned)m != 0xFFFFFFFFu) atomicAnd(q, (unsigned)m); if ((unsigned)(m >> 32) != 0xFFFFFFFFu) atomicAnd(q + 1, (unsigned)(m >> 32)); }
+__device__ __forceinline__ void lds_clear_bit64(u64* words, int i) { atomicAnd(reinterpret_cast<unsigned*>(words) + (i >> 5), ~(1u << (i & 31))); }
 
 __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
 {
@@ -61,60 +64,55 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }
     // ---- the fast path's verdict first: a certified unique optimum needs no emulation at all ----
     const int bad = L.hdr[LAP_H_BAD];
-    const int reason = lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(S.d), S.flag);
+    const int reason = lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(sp_raw), S.flag);
     __syncthreads();
     if (reason == 0) { if (tid == 0) L.hdr[LAP_H_MODE] = 0; return; }
     if (bad) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }          // negative / non-finite costs: dense emulation
-    // ---- set-up: candidate entries, d = c - row minimum (hungarian.cpp:83-89), zero masks, per-column totals ----
+    // ---- set-up: candidate entries (values in registers: only the row's own thread ever touches them), d = c - row minimum
+    // (hungarian.cpp:83-89), zero masks, transposed lists ----
     const int r = tid;
     const int wordsC = (nC + 63) >> 6;
     if (tid < 8) S.flag[tid] = 0;
-    S.cnt[tid] = 0; S.tot[tid] = 0; S.Scol[tid] = 0.0;
+    S.cnt[tid] = 0; S.tzero[tid] = 0; S.Scol[tid] = 0.0;
     S.starColOfRow[tid] = -1; S.starRowOfCol[tid] = -1; S.primeColOfRow[tid] = -1;
     if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
     __syncthreads();
+    double dv[SPK]; unsigned short myc[SPK];
     unsigned zm = 0;
+#pragma unroll
+    for (int k = 0; k < SPK; k++) { dv[k] = DBL_MAX; myc[k] = 0xFFFF; }
     if (r < nR) {
         const double rmin = L.ccost[(size_t)r * SPK];
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
-            const unsigned short c = L.ccol[(size_t)r * SPK + k];
-            double x = DBL_MAX;
-            if (c != 0xFFFF) { x = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[c], 1); if (fabs(x) < DBL_EPSILON) { zm |= 1u << k; atomicAdd(&S.tot[c], 1); } }
-            S.d[k * MK_MAXN + r] = x; S.cj[k * MK_MAXN + r] = c;
+            myc[k] = L.ccol[(size_t)r * SPK + k];
+            if (myc[k] != 0xFFFF) { dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < SPK; k++) { S.d[k * MK_MAXN + r] = DBL_MAX; S.cj[k * MK_MAXN + r] = 0xFFFF; }
     }
+#pragma unroll
+    for (int k = 0; k < SPK; k++) S.cj[k * MK_MAXN + r] = myc[k];
     S.zmask[r] = (unsigned short)zm;
     __syncthreads();
-    // transposed lists: exclusive scan of the per-column candidate counts, fill, sort each list by row
-    {
+    {   // transposed lists: fill (any order), then sort each column's list by row (rows sit in the high bits)
         const int mycnt = tid < nC ? S.cnt[tid] : 0;
-        int incl = mycnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        if (lane == 63) S.wave_tot[wave] = incl;
-        if (mycnt > SP_TLMAX) S.flag[0] = 1;
+        if (mycnt > SP_TLS) S.flag[0] = 1;
         __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; w++) base += S.wave_tot[w];
-        const int excl = base + incl - mycnt;
-        S.tptr[tid] = (unsigned short)excl;
-        if (tid == MK_THREADS - 1) { S.tptr[MK_MAXN] = (unsigned short)(excl + mycnt); }
-        S.cnt[tid] = excl;                                             // fill cursor
+        if (S.flag[0]) { if (tid == 0) { L.hdr[LAP_H_MODE] = 2; L.hdr[LAP_H_LAST + 8] = 2; } return; }
+        S.cnt[tid] = 0;
         __syncthreads();
-        if (S.flag[0]) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }
         if (r < nR) {
 #pragma unroll
-            for (int k = 0; k < SPK; k++) { const unsigned short c = S.cj[k * MK_MAXN + r]; if (c != 0xFFFF) { const int p = atomicAdd(&S.cnt[c], 1); S.tl[p] = (unsigned short)((r << 4) | k); } }
+            for (int k = 0; k < SPK; k++) if (myc[k] != 0xFFFF) { const int p = atomicAdd(&S.cnt[myc[k]], 1); S.tl[myc[k] * SP_TLS + p] = (unsigned short)((r << 4) | k); }
         }
         __syncthreads();
-        if (tid < nC) {                                                // insertion sort (lists are short; rows sit in the high bits)
-            const int p0 = S.tptr[tid], p1 = p0 + mycnt;
-            for (int i = p0 + 1; i < p1; i++) { const unsigned short x = S.tl[i]; int j = i - 1; while (j >= p0 && S.tl[j] > x) { S.tl[j + 1] = S.tl[j]; j--; } S.tl[j + 1] = x; }
-        }
+        if (tid < nC) {
+            unsigned short* t = S.tl + tid * SP_TLS;
+            for (int i = 1; i < mycnt; i++) { const unsigned short x = t[i]; int j = i - 1; while (j >= 0 && t[j] > x) { t[j + 1] = t[j]; j--; } t[j + 1] = x; }
+            unsigned zb = 0;
+            for (int i = 0; i < mycnt; i++) { const int e = t[i]; S.pos[(e & 15) * MK_MAXN + (e >> 4)] = (unsigned char)i; if ((S.zmask[e >> 4] >> (e & 15)) & 1) zb |= 1u << i; }
+            for (int i = mycnt; i < SP_TLS; i++) t[i] = 0xFFFF;
+            S.tzero[tid] = zb; S.tlive[tid] = zb;                      // all rows uncovered
+        } else S.tlive[tid] = 0;
         __syncthreads();
     }
     // ---- step 1 (:93-101): rows ascending, each stars its first zero BY COLUMN INDEX whose column is still free.  A row whose
@@ -123,8 +121,8 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     if (r < nR && zm) {
         int fz = 0xFFFF;
 #pragma unroll
-        for (int k = 0; k < SPK; k++) if ((zm >> k) & 1) fz = min(fz, (int)S.cj[k * MK_MAXN + r]);
-        if (S.tot[fz] == 1) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; }
+        for (int k = 0; k < SPK; k++) if ((zm >> k) & 1) fz = min(fz, (int)myc[k]);
+        if (__popc(S.tzero[fz]) == 1) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; }
         else contested = true;
     }
     {
@@ -140,27 +138,24 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
                 unsigned key = 0xFFFFu;
                 if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (S.starRowOfCol[c] < 0) key = (unsigned)c; }
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) { const unsigned o = __shfl_xor(key, off); if (o < key) key = o; }
+                key = wave_min_u32_dpp(key);
                 if (lane == 0 && key != 0xFFFFu) { S.starColOfRow[rr] = (short)key; S.starRowOfCol[key] = (short)rr; }
             }
         }
         __syncthreads();
     }
-    {   // step 2a: covered columns = starred columns
+    {   // step 2a: covered columns = starred columns; hz = hzAll = columns that hold a zero
         const bool has = tid < nC && S.starRowOfCol[tid] >= 0;
         const u64 bal = __ballot(has);
-        if (lane == 0) S.covC[wave] = bal;
-        // cnt = tot (all rows uncovered), hz = hzAll
-        S.cnt[tid] = S.tot[tid];
-        const u64 hb = __ballot(S.tot[tid] > 0);
-        if (lane == 0) { S.hz[wave] = hb; S.hzAll[wave] = hb; }
+        const u64 hb = __ballot(S.tzero[tid] != 0);
+        if (lane == 0) { S.covC[wave] = bal; S.hz[wave] = hb; S.hzAll[wave] = hb; }
     }
     __syncthreads();
     int ncov = 0;
     for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
     bool done = ncov == nR;
     int n_prime = 0, n_s5 = 0, n_aug = 0; long long t_s3 = 0, t_s5 = 0;
+    const long long t_setup = wall_clock64() - t_begin;
     const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
     u64 cC = (lane < MK_MAXW) ? S.covC[lane] : 0, cR = 0, phaseUnc = 0;   // wave 0: lane w holds word w
     int status = 0;
@@ -176,18 +171,17 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
                 const int col = wave_first_bit(cand, lane, MK_MAXW);
                 if (col < 0) { if (found) { found = false; from = 0; continue; } action = 2; break; }
-                // first uncovered row holding a zero in this column
-                const int p0 = S.tptr[col], p1 = S.tptr[col + 1];
-                int row = -1;
-                for (int base = p0; base < p1; base += 64) {
-                    const int e = (base + lane < p1) ? (int)S.tl[base + lane] : -1;
-                    bool hit = false;
-                    if (e >= 0) { const int rr = e >> 4, k = e & 15; hit = ((S.zmask[rr] >> k) & 1) && !bit_of(S.covR, rr); }
-                    const u64 b = __ballot(hit);
-                    if (b) { row = __builtin_amdgcn_readlane(e, __ffsll((long long)b) - 1) >> 4; break; }
-                }
-                if (row < 0) { action = 4; break; }                   // cnt / hz out of step with the masks: cannot happen
+                // first uncovered row holding a zero in this column: one LDS round trip (slots in lanes 0..31, the live mask in lane 32)
+                const unsigned ld = lane < SP_TLS ? (unsigned)S.tl[col * SP_TLS + lane] : S.tlive[col];
+                const unsigned lv = (unsigned)__builtin_amdgcn_readlane((int)ld, SP_TLS);
+                if (lv == 0) { action = 4; break; }                    // hz out of step with the masks: cannot happen
+                const int slot = __ffs((int)lv) - 1;
+                const int row = __builtin_amdgcn_readlane((int)ld, slot) >> 4;
+                // the row's star, its zeros and where they sit in their columns' lists: one more round trip
                 const int sc = S.starColOfRow[row];
+                const unsigned m = S.zmask[row];
+                int c2 = 0, ps = 0;
+                if (lane < SPK) { c2 = S.cj[lane * MK_MAXN + row]; ps = S.pos[lane * MK_MAXN + row]; }
                 if (lane == 0) S.primeColOfRow[row] = (short)col;      // :255
                 if (sc < 0) {
                     // ---------- step 4 (:283-334) ----------
@@ -211,21 +205,18 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                     cC |= phaseUnc; if (last >= 0 && lane == (last >> 6)) cC |= 1ull << (last & 63);
                     phaseUnc = 0;
                     if (lane < MK_MAXW) { S.covR[lane] = 0; S.hz[lane] = S.hzAll[lane]; }
-                    for (int i = lane; i < nC; i += 64) S.cnt[i] = S.tot[i];
+                    for (int i = lane; i < nC; i += 64) S.tlive[i] = S.tzero[i];      // all rows uncovered again (:324-330)
                     int total = 0;
                     for (int w = 0; w < wordsC; w++) total += __popcll(readlane64(cC, w));
                     if (total == nR) { action = 3; break; }
                     from = 0; found = false;
                     continue;
                 }
-                // cover the row (:270), uncover its star's column (:271)
+                // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
                 if (lane == (row >> 6)) { cR |= 1ull << (row & 63); S.covR[lane] = cR; }
-                {
-                    const unsigned m = S.zmask[row];
-                    if (lane < SPK && ((m >> lane) & 1)) {
-                        const int c2 = S.cj[lane * MK_MAXN + row];
-                        if (atomicSub(&S.cnt[c2], 1) == 1) lds_and64(&S.hz[c2 >> 6], ~(1ull << (c2 & 63)));
-                    }
+                if (lane < SPK && ((m >> lane) & 1)) {
+                    const unsigned bitv = 1u << ps;
+                    if (atomicAnd(&S.tlive[c2], ~bitv) == bitv) lds_clear_bit64(S.hz, c2);
                 }
                 if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); }
                 found = true; from = col + 1;                          // :273
@@ -242,19 +233,15 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         // ================= step 5 (:337-368) on the candidate entries: thread = row =================
         n_s5++;
         const bool rc = bit_of(S.covR, r);
-        double v[SPK]; bool unc[SPK];
+        bool unc[SPK];
         double h = DBL_MAX;
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
-            const unsigned short c = S.cj[k * MK_MAXN + r];
-            v[k] = S.d[k * MK_MAXN + r];
-            unc[k] = c != 0xFFFF && !bit_of(S.covC, c);
-            if (!rc && unc[k] && v[k] < h) h = v[k];
+            unc[k] = myc[k] != 0xFFFF && !bit_of(S.covC, myc[k]);
+            if (!rc && unc[k] && dv[k] < h) h = dv[k];
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(h, off); if (o < h) h = o; }
+        h = wave_min_f64_dpp(h);
         if (lane == 0) S.red[wave] = h;
-        S.cnt[tid] = 0; S.tot[tid] = 0;
         __syncthreads();
         h = S.red[0];
 #pragma unroll
@@ -263,20 +250,29 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         unsigned nm = 0;
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
-            const unsigned short c = S.cj[k * MK_MAXN + r];
-            if (c != 0xFFFF) {
-                double x = v[k];
+            if (myc[k] != 0xFFFF) {
+                double x = dv[k];
                 if (rc) x += h;                                        // :355-358
                 if (unc[k]) x -= h;                                    // :361-364
-                S.d[k * MK_MAXN + r] = x;
-                if (fabs(x) < DBL_EPSILON) { nm |= 1u << k; atomicAdd(&S.tot[c], 1); if (!rc) atomicAdd(&S.cnt[c], 1); }
+                dv[k] = x;
+                if (fabs(x) < DBL_EPSILON) nm |= 1u << k;
             }
         }
-        S.zmask[r] = (unsigned short)nm;
+        if (nm != zm) {                                                // zero bits that changed: the column-side masks follow
+#pragma unroll
+            for (int k = 0; k < SPK; k++) {
+                if (((nm ^ zm) >> k) & 1) {
+                    const unsigned bitv = 1u << S.pos[k * MK_MAXN + r];
+                    if ((nm >> k) & 1) { atomicOr(&S.tzero[myc[k]], bitv); if (!rc) atomicOr(&S.tlive[myc[k]], bitv); }
+                    else { atomicAnd(&S.tzero[myc[k]], ~bitv); if (!rc) atomicAnd(&S.tlive[myc[k]], ~bitv); }
+                }
+            }
+            zm = nm; S.zmask[r] = (unsigned short)nm;
+        }
         if (tid < nC && !bit_of(S.covC, tid)) S.Scol[tid] += h;
         __syncthreads();
         {
-            const u64 hb = __ballot(S.cnt[tid] > 0), ha = __ballot(S.tot[tid] > 0);
+            const u64 hb = __ballot(S.tlive[tid] != 0), ha = __ballot(S.tzero[tid] != 0);
             if (lane == 0) { S.hz[wave] = hb; S.hzAll[wave] = ha; }
         }
         __syncthreads();
@@ -289,35 +285,44 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
         L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
         L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
+        L.hdr[48] = (int)t_setup;                                      // (debug: set-up ticks)
     }
 }
 
 // every entry outside the candidate lists against the final S_j (see the header); grid of 64 x 64 tiles
 __global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
 {
+    __shared__ bbox_t colb[64]; __shared__ double colS[64];
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const LapWs& L = a.ws.lap;
     if (L.hdr[LAP_H_MODE] != 1) return;                                // certified, or dense emulation anyway
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
+        const int c = c0 + threadIdx.x;
+        if (!a.user) colb[threadIdx.x] = rowsTrk ? a.det[c] : a.trk[c];
+        colS[threadIdx.x] = L.spS[c];
+    }
     bool viol = false;
+    unsigned short lj = 0xFFFF; double rmin = 0.0, lc = 0.0; bbox_t rb = {};
     if (r < nR) {
-        const unsigned short lj = L.ccol[(size_t)r * SPK + SPK - 1];
-        if (lj != 0xFFFF) {                                            // (a row with fewer than LAP_K columns has every entry in its list)
-            const double rmin = L.ccost[(size_t)r * SPK], lc = L.ccost[(size_t)r * SPK + SPK - 1];
-            const double margin = 1e-9 * (1.0 + L.dhdr[3]);            // 1e-9 * (1 + largest cost): far above the reference's accumulated rounding
-            bbox_t rb = {};
-            if (!a.user) rb = rowsTrk ? a.trk[r] : a.det[r];
-            for (int cc = wave; cc < 64; cc += 4) {
-                const int c = c0 + cc;
-                if (c >= nC) break;
-                double cst;
-                if (a.user) cst = a.user[(size_t)r + (size_t)nR * c];
-                else cst = rowsTrk ? pair_cost(rb, a.det[c]) : pair_cost(a.trk[c], rb);
-                const bool outside = cst > lc || (cst == lc && c > (int)lj);
-                if (outside && !(cst - rmin - L.spS[c] > margin)) viol = true;
-            }
+        lj = L.ccol[(size_t)r * SPK + SPK - 1];
+        rmin = L.ccost[(size_t)r * SPK]; lc = L.ccost[(size_t)r * SPK + SPK - 1];
+        if (!a.user) rb = rowsTrk ? a.trk[r] : a.det[r];
+    }
+    const double margin = 1e-9 * (1.0 + L.dhdr[3]);                    // 1e-9 * (1 + largest cost): far above the reference's accumulated rounding
+    __syncthreads();
+    if (r < nR && lj != 0xFFFF) {                                      // (a row with fewer than LAP_K columns has every entry in its list)
+#pragma unroll 4
+        for (int cc = wave; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            if (c >= nC) break;
+            double cst;
+            if (a.user) cst = a.user[(size_t)r + (size_t)nR * c];
+            else cst = rowsTrk ? pair_cost(rb, colb[cc]) : pair_cost(colb[cc], rb);
+            const bool outside = cst > lc || (cst == lc && c > (int)lj);
+            if (outside && !(cst - rmin - colS[cc] > margin)) viol = true;
         }
     }
     if (__syncthreads_or(viol) && threadIdx.x == 0) atomicOr(&L.hdr[LAP_H_SPVIOL], 1);

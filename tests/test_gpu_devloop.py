@@ -44,19 +44,20 @@ def test_device_loop_vs_oracle(mot, oracle, kind, n, size, nframes):
     m.close(); c.close()
 
 
-@pytest.mark.parametrize("n,nframes", [(600, 7), (1024, 7)])
-def test_device_loop_large_vs_oracle(mot, oracle, n, nframes):
-    """the BENCHED configuration against the oracle: above 512 lines the frame runs the assignment fast path, the Munkres
-    kernel with its 16 helper workgroups and the lifecycle tail, and the split update; misses and false positives make
-    tracks die and spawn every frame (td.cpp:585-644)"""
+@pytest.mark.parametrize("n,nframes,miss,fp", [(600, 7, 4, 3), (1024, 7, 4, 3), (1024, 9, 0, 0)])
+def test_device_loop_large_vs_oracle(mot, oracle, n, nframes, miss, fp):
+    """the BENCHED configuration against the oracle: assignment fast path (certificate), sparse order-exact emulation, dense
+    emulation as the last resort, lifecycle tail and split update.  With misses and false positives tracks die and spawn every
+    frame (td.cpp:585-644) and a false positive's partner is a far-away free track: the candidate lists cannot decide those
+    frames and the dense emulation runs; without them (the bench stream itself) the first two always suffice."""
     from multiple_object_tracking_amd import synth
-    scene = synth.Scene(n, 80, stream_id=5, miss_pct=4, fp_pct=3)
+    scene = synth.Scene(n, 80, stream_id=5 if miss else 0, miss_pct=miss, fp_pct=fp)
     items = list(scene.frames(nframes))
     frames = [f for f, _ in items]; dets = [d[:1024] for _, d in items]
     fd, dd, da = _dev(frames, dets, mot)
     c = mot.MotContext(max_tracks=1024, max_dets=1024)
     m = orc.OracleMot(oracle, 0, 0, 1024)
-    outcomes = set()
+    used = set()
     for f in range(nframes):
         c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
         ref = m.step(frames[f], dets[f])
@@ -64,8 +65,9 @@ def test_device_loop_large_vs_oracle(mot, oracle, n, nframes):
         assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
         assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
         if f:
-            outcomes.add(int(c.lap_stats()[0]))
-    assert outcomes <= {0, 4}, outcomes                               # certified or a genuine tie, never a solver / dual failure
+            used.add(int(c.lap_stats()[15]))                          # 0 certificate, 1 sparse emulation, 2 dense emulation
+    if not miss:
+        assert used == {0, 1}, used                                   # the bench stream: certified frames and tie frames, never the dense emulation
     m.close(); c.close()
 
 

@@ -480,14 +480,21 @@ def test_lap_fast_path_counters(mot, oracle):
         cx = rng.permutation(1200 * 640)[:n]
         px, py = cx % 1200, cx // 1200                                # distinct centroids
         trk = [(int(px[i]) - 40, int(py[i]) - 40, int(py[i]) + 39, int(px[i]) + 39, i % 3, 0.9) for i in range(n)]
-        det = [(int(px[i] + rng.integers(-3, 4)) - 40, int(py[i] + rng.integers(-3, 4)) - 40, int(py[i]) + 39, int(px[i]) + 39, int(i % 3), 0.9) for i in rng.permutation(n)]
+        dobj = [(int(px[i] + rng.integers(-3, 4)) - 40, int(py[i] + rng.integers(-3, 4)) - 40, int(py[i]) + 39, int(px[i]) + 39, int(i % 3), 0.9) for i in range(n)]
+        perm = rng.permutation(n)
+        det = [dobj[i] for i in perm]
         at, ad, cost = c.assign(trk, det)
         ra, rc = orc.assignment_optimal(oracle, orc.cost_matrix(oracle, trk, det), n, n)
         assert np.array_equal(ad, ra) and cost == rc
         if c.lap_stats()[0] == 0:
             break                                                     # (a random scene may contain a symmetric tie: draw again)
     assert c.assoc_stats()[0] == -1 and c.assoc_stats()[1] == 0       # certified: no step 4 / step 5 ran
-    trk[7] = trk[3][:4] + (trk[7][4], 0.9); trk[7] = trk[3]           # two tracks, one centroid and class: tied optima
+    # object 7 moves onto object 3: two tracks on ONE centroid and class (identical cost columns), their two detections next to
+    # each other -> two optimal assignments; which one the reference returns is decided by its scan order
+    trk[7] = trk[3]
+    d3 = dobj[3]
+    dobj[7] = (d3[0] + 1, d3[1], d3[2], d3[3] + 1, d3[4], 0.9)
+    det = [dobj[i] for i in perm]
     at, ad, cost = c.assign(trk, det)
     ra, rc = orc.assignment_optimal(oracle, orc.cost_matrix(oracle, trk, det), n, n)
     assert np.array_equal(ad, ra) and cost == rc
