@@ -70,6 +70,30 @@ __device__ __forceinline__ double pair_cost(const bbox_t a, const bbox_t d)
     return dist;
 }
 
+// The same cost from the integer squared centroid distance d2 and the class flag (what pair_cost evaluates: 0.0 + sqrt(d2) * (1/1280),
+// then + 1.0 on a class mismatch), and a float estimate of it whose absolute error stays below PAIR_COST_F32_ERR (d2 < 2^24 is
+// exact in float, sqrtf and the product round to 1 ulp each, values < 2.2): dense passes use the estimate to discard the entries
+// that are far from any threshold and evaluate the float64 form only for the few that are close.
+#define PAIR_COST_F32_ERR 1e-6
+__device__ __forceinline__ void pair_d2(const bbox_t a, const bbox_t d, int& d2, bool& pen)
+{
+    const int cxi = (a.l + a.r) >> 1, cyi = (a.t + a.b) >> 1;
+    const int cxj = (d.l + d.r) >> 1, cyj = (d.t + d.b) >> 1;
+    d2 = (cxi - cxj) * (cxi - cxj) + (cyi - cyj) * (cyi - cyj);
+    pen = a.type != d.type;
+}
+__device__ __forceinline__ double cost_of_d2(int d2, bool pen)
+{
+    double dist = 0.0;
+    dist += sqrt((double)d2) * (1.0 / ((double)MOT_FRAME_W));
+    if (pen) dist += 1.0;
+    return dist;
+}
+__device__ __forceinline__ float cost_of_d2_f32(int d2, bool pen) { return sqrtf((float)d2) * (1.0f / (float)MOT_FRAME_W) + (pen ? 1.0f : 0.0f); }
+// the estimate needs d2 < 2^24 (exact in float): centroids within +-1400 of the origin give |dx|, |dy| <= 2800.  Tracker boxes are
+// clamped to the 1280 x 720 frame (td.cpp:378-381) and detections lie in it; anything else takes the float64 form throughout.
+__device__ __forceinline__ bool box_small(const bbox_t b) { return (unsigned)(b.l + 1400) <= 2800u && (unsigned)(b.r + 1400) <= 2800u && (unsigned)(b.t + 1400) <= 2800u && (unsigned)(b.b + 1400) <= 2800u; }
+
 struct AssocArgs {
     const bbox_t* trk; const bbox_t* det; const int* nT_dev; int nT; int nD;
     const double* user; int userR, userC;

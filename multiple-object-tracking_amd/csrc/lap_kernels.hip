@@ -40,6 +40,58 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
     const LapWs& L = a.ws.lap;
     bbox_t rb = {};
     if (!a.user) rb = rowsTrk ? a.trk[r] : a.det[r];
+    // ---- box costs: order by the integer key (class flag, squared centroid distance) and evaluate the float64 cost only for the
+    // entries that are kept.  Exact whenever the LAP_K smallest keys are same-class entries closer than 1280 px: their costs are
+    // < 1.0 <= every cross-class cost, and inside a class the cost grows strictly with the squared distance. ----
+    if (!a.user) {
+        unsigned ik[MK_MAXN / 64];
+        bool small = box_small(rb);
+        unsigned mx0 = 0, mx1 = 0; bool any1 = false;
+#pragma unroll
+        for (int t = 0; t < MK_MAXN / 64; t++) {
+            const int j = t * 64 + lane;
+            ik[t] = 0xFFFFFFFFu;
+            if (j < nC) {
+                const bbox_t cb = rowsTrk ? a.det[j] : a.trk[j];
+                small &= box_small(cb);
+                int d2; bool pen; if (rowsTrk) pair_d2(rb, cb, d2, pen); else pair_d2(cb, rb, d2, pen);
+                ik[t] = (pen ? 0x80000000u : 0u) | (unsigned)d2;
+                if (pen) { any1 = true; if ((unsigned)d2 > mx1) mx1 = (unsigned)d2; } else if ((unsigned)d2 > mx0) mx0 = (unsigned)d2;
+            }
+        }
+        if (!__ballot(!small)) {
+            unsigned selk = 0xFFFFFFFFu, selc = 0xFFFFu;              // lane k keeps the k-th smallest
+            for (int k = 0; k < LAP_K; k++) {
+                unsigned lk = 0xFFFFFFFFu; int lt = 0;
+#pragma unroll
+                for (int t = 0; t < MK_MAXN / 64; t++) if (ik[t] < lk) { lk = ik[t]; lt = t; }
+                const unsigned wm = wave_min_u32_dpp(lk);
+                const unsigned mycol = (lk == wm && lk != 0xFFFFFFFFu) ? (unsigned)(lt * 64 + lane) : 0xFFFFFFFFu;
+                const unsigned wc = wave_min_u32_dpp(mycol);          // equal cost: the lowest column
+                if (lane == k) { selk = wm; selc = wc == 0xFFFFFFFFu ? 0xFFFFu : wc; }
+                if (mycol == wc && wc != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int t = 0; t < MK_MAXN / 64; t++) if (t == lt) ik[t] = 0xFFFFFFFFu;
+                }
+            }
+            const bool near = lane >= LAP_K || selc == 0xFFFFu || selk < (unsigned)MOT_FRAME_W * MOT_FRAME_W;   // same class, closer than 1280 px
+            if (!__ballot(!near)) {
+                if (lane < LAP_K) {
+                    const bool has = selc != 0xFFFFu;
+                    const double cst = has ? cost_of_d2((int)(selk & 0x7FFFFFFFu), (selk >> 31) != 0) : DBL_MAX;
+                    L.ccol[(size_t)r * LAP_K + lane] = (unsigned short)selc;
+                    L.ccost[(size_t)r * LAP_K + lane] = cst;
+                    if (lane == 0) a.linemin[r] = dkey(cst);           // hungarian.cpp:69-81
+                }
+                // largest cost of the row: the farthest entry of each class
+                mx0 = ~wave_min_u32_dpp(~mx0); mx1 = ~wave_min_u32_dpp(~mx1);
+                const bool w1 = __ballot(any1) != 0;
+                if (lane == 0) { double m = cost_of_d2((int)mx0, false); if (w1) { const double m1 = cost_of_d2((int)mx1, true); if (m1 > m) m = m1; } L.u[r] = m; }   // row maximum (L.u is free until the solver writes the duals)
+                return;
+            }
+        }
+    }
+    // ---- general form: caller-supplied matrix, or boxes the integer ordering does not cover ----
     u64 key[MK_MAXN / 64];
     u64 mx = 0; bool bad = false;
 #pragma unroll
@@ -61,7 +113,7 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
         for (int t = 0; t < MK_MAXN / 64; t++) if (key[t] < lk) { lk = key[t]; lt = t; }
         const u64 wm = wave_min_u64_dpp(lk);
         const unsigned mycol = (lk == wm && lk != ~0ull) ? (unsigned)(lt * 64 + lane) : 0xFFFFFFFFu;
-        const unsigned wc = wave_min_u32_dpp(mycol);                      // equal cost: the lowest column
+        const unsigned wc = wave_min_u32_dpp(mycol);                  // equal cost: the lowest column
         if (lane == 0) {
             L.ccol[(size_t)r * LAP_K + k] = wc == 0xFFFFFFFFu ? (unsigned short)0xFFFF : (unsigned short)wc;
             L.ccost[(size_t)r * LAP_K + k] = wc == 0xFFFFFFFFu ? DBL_MAX : dunkey(wm);
@@ -73,7 +125,7 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
         }
     }
     mx = wave_max_u64_dpp(mx);
-    if (lane == 0) atomicMax(L.cmaxkey, mx);
+    if (lane == 0) L.u[r] = dunkey(mx);                                // row maximum: reduced by the solver (no same-address atomics)
     if (__ballot(bad) && lane == 0) atomicOr(&L.hdr[LAP_H_BAD], 1);
 }
 
@@ -126,9 +178,15 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return; }
     if (L.hdr[LAP_H_BAD]) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return; }
     for (int i = tid; i < nR * LAP_K; i += MK_THREADS) { S.cc[i] = L.ccost[i]; S.cj[i] = L.ccol[i]; }
+    {   // largest cost of the matrix from the row maxima the row scan left in L.u
+        const double rm = wave_min_f64_dpp(tid < nR ? -L.u[tid] : 0.0);
+        if (lane == 0) S.red[wave] = -rm;
+    }
     S.v[tid] = 0.0; S.rowOfCol[tid] = -1; S.colOfRow[tid] = -1; S.lock[tid] = 0xFFFFFFFFu;
     if (tid < 8) S.flag[tid] = 0;
     __syncthreads();
+    double cmax_all = S.red[0];
+    for (int w = 1; w < MK_THREADS / 64; w++) cmax_all = fmax(cmax_all, S.red[w]);
     // greedy start: every row asks for its cheapest column, the lowest row wins
     if (tid < nR) atomicMin(&S.lock[S.cj[tid * LAP_K]], (unsigned)tid);
     __syncthreads();
@@ -246,7 +304,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     if (tid == 0) {
         double gamma = 0.0; int ctot = 0;
         for (int w = 0; w < MK_THREADS / 64; w++) { gamma += S.red[w]; ctot += S.wave_tot[w]; }
-        const double cmax = dunkey(*L.cmaxkey);
+        const double cmax = cmax_all;
         const double mag = cmax + gamma;
         const double n3 = (double)nC * (double)nC * (double)nC;
         L.dhdr[0] = fmax(1e-9, 1e-15 * n3) * mag;                      // eps: see the header of lap_model.c (CPU model, test infrastructure)
@@ -263,16 +321,18 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
 // once so that the sqrt chain of an element does not wait on global loads
 __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a)
 {
-    __shared__ bbox_t colb[64]; __shared__ double colv[64]; __shared__ int colo[64];
+    __shared__ bbox_t colb[64]; __shared__ double colv[64]; __shared__ int colo[64]; __shared__ int big;
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const LapWs& L = a.ws.lap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
     if (L.hdr[LAP_H_SOLVE] != 0) return;                               // nothing to check: the solver gave up / was not applicable
+    if (threadIdx.x == 0) big = 0;
+    __syncthreads();
     if (threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
         const int c = c0 + threadIdx.x;
-        if (!a.user) colb[threadIdx.x] = rowsTrk ? a.det[c] : a.trk[c];
+        if (!a.user) { const bbox_t cb = rowsTrk ? a.det[c] : a.trk[c]; colb[threadIdx.x] = cb; if (!box_small(cb)) big = 1; }
         colv[threadIdx.x] = L.v[c]; colo[threadIdx.x] = L.rowOfCol[c];
     }
     const double eps = L.dhdr[0], tol = L.dhdr[1];
@@ -281,23 +341,29 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a)
     bbox_t rb = {};
     if (!a.user && r < nR) rb = rowsTrk ? a.trk[r] : a.det[r];
     __syncthreads();
+    const bool est_ok = !a.user && !big && box_small(rb);              // float estimate of the cost usable (assoc_common.h)
+    const double far = eps + 4.0 * PAIR_COST_F32_ERR;
     bool viol = false;
     if (r < nR) {
 #pragma unroll 4
         for (int cc = wave; cc < 64; cc += 4) {
             const int c = c0 + cc;
             if (c >= nC) break;
+            if (c == mr) continue;
             double cst;
             if (a.user) cst = a.user[(size_t)r + (size_t)nR * c];
-            else cst = rowsTrk ? pair_cost(rb, colb[cc]) : pair_cost(colb[cc], rb);
-            if (c != mr) {
-                const double red = (cst - colv[cc]) - ur;
-                if (!(red >= -tol)) viol = true;
-                else if (red < eps) {
-                    const int e = atomicAdd(&L.hdr[LAP_H_NEDGES], 1);
-                    const int owner = colo[cc];
-                    if (e < LAP_EDGES) L.edges[e] = ((unsigned)r << 16) | (unsigned)(owner >= 0 ? owner : nR);
-                }
+            else {
+                int d2; bool pen; if (rowsTrk) pair_d2(rb, colb[cc], d2, pen); else pair_d2(colb[cc], rb, d2, pen);
+                // an entry whose estimated reduced cost is far above eps is feasible and not near-tight: nothing to record
+                if (est_ok && ((double)cost_of_d2_f32(d2, pen) - colv[cc]) - ur > far) continue;
+                cst = rowsTrk ? pair_cost(rb, colb[cc]) : pair_cost(colb[cc], rb);
+            }
+            const double red = (cst - colv[cc]) - ur;
+            if (!(red >= -tol)) viol = true;
+            else if (red < eps) {
+                const int e = atomicAdd(&L.hdr[LAP_H_NEDGES], 1);
+                const int owner = colo[cc];
+                if (e < LAP_EDGES) L.edges[e] = ((unsigned)r << 16) | (unsigned)(owner >= 0 ? owner : nR);
             }
         }
     }

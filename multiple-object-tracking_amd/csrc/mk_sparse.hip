@@ -158,15 +158,26 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     const long long t_setup = wall_clock64() - t_begin;
     const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
     u64 cC = (lane < MK_MAXW) ? S.covC[lane] : 0, cR = 0, phaseUnc = 0;   // wave 0: lane w holds word w
+    u64 hzr = (lane < MK_MAXW) ? S.hz[lane] : 0, hzAllr = hzr;            // wave 0: columns with a live zero / with any zero
+    bool hz_dirty = false;                                                // step 5 changed the masks: wave 0 rebuilds hzr / hzAllr
     int status = 0;
     while (!done) {
         const long long t_a = wall_clock64();
         // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
         if (wave == 0) {
             int action = 0; int from = 0; bool found = false;
+            if (hz_dirty) {                                            // after a step 5: one pass over the column masks
+                u64 nl = 0, na = 0;
+#pragma unroll
+                for (int w = 0; w < MK_MAXW; w++) {
+                    const u64 bl = __ballot(S.tlive[w * 64 + lane] != 0), ba = __ballot(S.tzero[w * 64 + lane] != 0);
+                    if (lane == w) { nl = bl; na = ba; }
+                }
+                hzr = nl; hzAllr = na; hz_dirty = false;
+            }
             while (action == 0) {
                 if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
-                u64 cand = (lane < MK_MAXW) ? (S.hz[lane] & ~cC & vC) : 0;
+                u64 cand = hzr & ~cC & vC;
                 const int fw = from >> 6;
                 if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
                 const int col = wave_first_bit(cand, lane, MK_MAXW);
@@ -204,7 +215,8 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                     cR = 0;
                     cC |= phaseUnc; if (last >= 0 && lane == (last >> 6)) cC |= 1ull << (last & 63);
                     phaseUnc = 0;
-                    if (lane < MK_MAXW) { S.covR[lane] = 0; S.hz[lane] = S.hzAll[lane]; }
+                    if (lane < MK_MAXW) S.covR[lane] = 0;
+                    hzr = hzAllr;
                     for (int i = lane; i < nC; i += 64) S.tlive[i] = S.tzero[i];      // all rows uncovered again (:324-330)
                     int total = 0;
                     for (int w = 0; w < wordsC; w++) total += __popcll(readlane64(cC, w));
@@ -214,9 +226,11 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 }
                 // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
                 if (lane == (row >> 6)) { cR |= 1ull << (row & 63); S.covR[lane] = cR; }
-                if (lane < SPK && ((m >> lane) & 1)) {
-                    const unsigned bitv = 1u << ps;
-                    if (atomicAnd(&S.tlive[c2], ~bitv) == bitv) lds_clear_bit64(S.hz, c2);
+                bool emptied = false;
+                if (lane < SPK && ((m >> lane) & 1)) { const unsigned bitv = 1u << ps; emptied = atomicAnd(&S.tlive[c2], ~bitv) == bitv; }
+                for (u64 eb = __ballot(emptied); eb; eb &= eb - 1) {   // columns that lost their last live zero (usually none or one)
+                    const int ce = __builtin_amdgcn_readlane(c2, __ffsll((long long)eb) - 1);
+                    if (lane == (ce >> 6)) hzr &= ~(1ull << (ce & 63));
                 }
                 if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); }
                 found = true; from = col + 1;                          // :273
@@ -270,11 +284,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
             zm = nm; S.zmask[r] = (unsigned short)nm;
         }
         if (tid < nC && !bit_of(S.covC, tid)) S.Scol[tid] += h;
-        __syncthreads();
-        {
-            const u64 hb = __ballot(S.tlive[tid] != 0), ha = __ballot(S.tzero[tid] != 0);
-            if (lane == 0) { S.hz[wave] = hb; S.hzAll[wave] = ha; }
-        }
+        hz_dirty = true;
         __syncthreads();
         t_s5 += wall_clock64() - t_b;
     }
@@ -292,16 +302,18 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
 // every entry outside the candidate lists against the final S_j (see the header); grid of 64 x 64 tiles
 __global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
 {
-    __shared__ bbox_t colb[64]; __shared__ double colS[64];
+    __shared__ bbox_t colb[64]; __shared__ double colS[64]; __shared__ int big;
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const LapWs& L = a.ws.lap;
     if (L.hdr[LAP_H_MODE] != 1) return;                                // certified, or dense emulation anyway
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
+    if (threadIdx.x == 0) big = 0;
+    __syncthreads();
     if (threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
         const int c = c0 + threadIdx.x;
-        if (!a.user) colb[threadIdx.x] = rowsTrk ? a.det[c] : a.trk[c];
+        if (!a.user) { const bbox_t cb = rowsTrk ? a.det[c] : a.trk[c]; colb[threadIdx.x] = cb; if (!box_small(cb)) big = 1; }
         colS[threadIdx.x] = L.spS[c];
     }
     bool viol = false;
@@ -313,6 +325,7 @@ __global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
     }
     const double margin = 1e-9 * (1.0 + L.dhdr[3]);                    // 1e-9 * (1 + largest cost): far above the reference's accumulated rounding
     __syncthreads();
+    const bool est_ok = !a.user && !big && box_small(rb);              // float estimate of the cost usable (assoc_common.h)
     if (r < nR && lj != 0xFFFF) {                                      // (a row with fewer than LAP_K columns has every entry in its list)
 #pragma unroll 4
         for (int cc = wave; cc < 64; cc += 4) {
@@ -320,7 +333,15 @@ __global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
             if (c >= nC) break;
             double cst;
             if (a.user) cst = a.user[(size_t)r + (size_t)nR * c];
-            else cst = rowsTrk ? pair_cost(rb, colb[cc]) : pair_cost(colb[cc], rb);
+            else {
+                int d2; bool pen; if (rowsTrk) pair_d2(rb, colb[cc], d2, pen); else pair_d2(colb[cc], rb, d2, pen);
+                if (est_ok) {                                          // clearly outside the list AND clearly above the bound, or clearly inside the list: done
+                    const double e = (double)cost_of_d2_f32(d2, pen);
+                    if (e < lc - 2.0 * PAIR_COST_F32_ERR) continue;
+                    if (e > lc + 2.0 * PAIR_COST_F32_ERR && e - rmin - colS[cc] > margin + 2.0 * PAIR_COST_F32_ERR) continue;
+                }
+                cst = rowsTrk ? pair_cost(rb, colb[cc]) : pair_cost(colb[cc], rb);
+            }
             const bool outside = cst > lc || (cst == lc && c > (int)lj);
             if (outside && !(cst - rmin - colS[cc] > margin)) viol = true;
         }

@@ -97,7 +97,16 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             const KcfPool& kp = c->pools[d->pool]->dev;
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // lo = numerically largest = lowest priority
-            HIPCHK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
+            // MOT_SIDE_RESERVE=N: instead of a low-priority stream, a stream whose kernels may not use N of the chip's CUs, so the
+            // one-workgroup kernels of the association chain on the main stream never queue behind detection-feature workgroups
+            const char* rs = getenv("MOT_SIDE_RESERVE");
+            const int reserve = rs ? atoi(rs) : 0;
+            if (reserve > 0 && reserve < 256) {
+                uint32_t mask[8];
+                for (int w = 0; w < 8; w++) mask[w] = 0xFFFFFFFFu;
+                for (int b = 0; b < reserve; b++) mask[b >> 5] &= ~(1u << (b & 31));
+                HIPCHK(hipExtStreamCreateWithCUMask(&d->side, 8, mask));
+            } else HIPCHK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
             HIPCHK(hipEventCreateWithFlags(&d->ev_mid, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&d->ev_feat, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&d->ev_upd, hipEventDisableTiming));
