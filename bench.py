@@ -56,55 +56,76 @@ def gen_stream(n_tracks, size, n_frames, stream_id=0):
     return frames, dets
 
 
-def cpu_baseline(n_tracks, size, budget_s=15.0):
-    """the reference's own code (oracle/_ref) -- or the oracle port if that is absent -- on one host core,
-    on the first frames of the same synthetic workload (full track count, all stages incl. Munkres)."""
+def _cpu_worker(args):
+    """one host core: an independent stream of `n` KCF tracks through the oracle's frame loop; returns (updates, seconds)"""
+    n, size, sid, frames_cap, budget = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     import mot_amd  # noqa: F401
     from multiple_object_tracking_amd import synth
-    kind = "port"
+    lib = orc.load_oracle()
+    scene = synth.Scene(n, size, stream_id=sid)
+    gen = scene.frames(10 ** 6)
+    m = orc.OracleMot(lib, 0, 0, max(n, 1))
+    frame, dets = next(gen); m.step(frame, dets)                     # frame 0 spawns the tracks (not steady state)
+    t0 = time.perf_counter(); done = 0
+    while done < frames_cap and time.perf_counter() - t0 < budget:
+        frame, dets = next(gen); m.step(frame, dets); done += 1
+    dt = time.perf_counter() - t0
+    m.close()
+    return n * done, dt, done
+
+
+def cpu_baseline(n_tracks, size, budget_s=12.0):
+    """CPU baseline on the host cores of this box (rank 0, N = 1 only), bounded samples of the same synthetic workload:
+      * value / kind "reference": the reference's own code (oracle/_ref, when present), ONE core (the reference's tracker thread is
+        single-threaded, top/td.cpp:306), full track count, all stages incl. its Munkres;
+      * port_1core: the oracle port on one core, same frames -> port_over_reference = calibration ratio (SURVEY 8d);
+      * all_cores: the port on every host core, tracks split into one independent stream per core (n / cores tracks each, each with
+        its own cost matrix + Munkres) -- an upper bound for a multi-threaded CPU build, count stated."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    import mot_amd  # noqa: F401
+    from multiple_object_tracking_amd import synth
+    out = {}
     libs = None
     if orc.ref_available():
         try:
             libs = tuple(orc.load_ref(n) for n in ["kcf", "kalman", "hungarian", "drawlib"])
-            kind = "reference"
         except OSError:
             libs = None
-    scene = synth.Scene(n_tracks, size, stream_id=0)
-    gen = scene.frames(10 ** 6)
-    updates, t_used, frames_done = 0, 0.0, 0
-    if kind == "reference":
+    # oracle port, one core, the first steady frames of the bench stream
+    upd_p, t_p, nf_p = _cpu_worker((n_tracks, size, 0, 3, budget_s * 0.4))
+    port = upd_p / t_p
+    if libs is not None:
         class Feed:
             def __init__(self, items): self.items = items
             def frames(self, n): return iter(self.items[:n])
-        # frame 0 only spawns the tracks (tracker_new + first update: not steady state); frames 1.. are timed individually
-        est = n_tracks * 0.5e-3 + 0.04 * (n_tracks / 1024.0) ** 2
-        nf = int(max(2, min(40, budget_s / est)))
+        scene = synth.Scene(n_tracks, size, stream_id=0)
+        gen = scene.frames(10 ** 6)
+        nf = max(1, nf_p)
         frames = [next(gen) for _ in range(nf + 1)]
         timing = []
         orc.ref_frame_loop(0, Feed(frames), nf + 1, libs, timing)
-        t_used = sum(t for t, _ in timing[1:])
-        updates = sum(n for _, n in timing[1:])
-        frames_done = nf
+        t_used = sum(t for t, _ in timing[1:]); updates = sum(n for _, n in timing[1:])
+        out.update({"value": updates / t_used, "unit": "tracker-updates/s", "cores": 1, "kind": "reference",
+                    "sample": f"{n_tracks} KCF tracks x {nf} frames after the spawn frame of the bench stream (crop+resize, predict, cost, Munkres, update), 1 thread",
+                    "port_1core": port, "port_over_reference": port / (updates / t_used)})
     else:
-        lib = orc.load_oracle()
-        m = orc.OracleMot(lib, 0, 0, n_tracks)
-        frame, dets = next(gen)
-        m.step(frame, dets)
-        t0 = time.perf_counter()
-        frame, dets = next(gen); m.step(frame, dets)
-        per_frame = time.perf_counter() - t0
-        nf = int(max(1, min(40, budget_s / per_frame)))
-        t0 = time.perf_counter()
-        for _ in range(nf):
-            frame, dets = next(gen); m.step(frame, dets)
-        t_used = time.perf_counter() - t0
-        frames_done = nf
-        updates = n_tracks * frames_done
-        m.close()
-    return {"value": updates / t_used, "unit": "tracker-updates/s", "cores": 1, "kind": kind,
-            "sample": f"{n_tracks} KCF tracks x {frames_done} steady-state frames of the bench stream (crop+resize, predict, cost, Munkres, update), 1 thread"}
+        out.update({"value": port, "unit": "tracker-updates/s", "cores": 1, "kind": "port",
+                    "sample": f"{n_tracks} KCF tracks x {nf_p} frames after the spawn frame of the bench stream, oracle port, 1 thread"})
+    # all host cores: one independent stream of n / cores tracks per core
+    try:
+        import multiprocessing as mp
+        cores = os.cpu_count() or 1
+        per = max(n_tracks // cores, 1)
+        with mp.get_context("spawn").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(per, size, 100 + i, 10 ** 6, budget_s * 0.4) for i in range(cores)])
+        out["all_cores"] = {"value": sum(u for u, _, _ in res) / max(t for _, t, _ in res), "cores": cores, "kind": "port",
+                            "sample": f"{cores} independent streams of {per} KCF tracks (one per core), {min(f for _, _, f in res)}-{max(f for _, _, f in res)} frames each"}
+    except Exception as e:                                            # never fail the bench line over the optional leg
+        out["all_cores"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():
@@ -122,6 +143,7 @@ def main():
                          "value = all K streams. Informative (small track counts leave most CUs idle); the default 1 is the measured config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=20)
+    ap.add_argument("--steady", type=int, default=40, help="frames of a second timed window right behind the first (reported as steady_state; 0 = off)")
     ap.add_argument("--debug-assoc", action="store_true", help="print Munkres step counters / phase times per profiled frame to stderr")
     args = ap.parse_args()
 
@@ -155,7 +177,7 @@ def main():
     streams = args.mode == "streams" and world > 1
     mot_rank, mot_world = (0, 1) if streams else (rank, world)
     n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
-    n_frames = 1 + args.warmup + args.steps + n_prof
+    n_frames = 1 + args.warmup + args.steps + args.steady + n_prof
     frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0)
     frames_d = torch.from_numpy(frames_h).cuda()
     dets_d = torch.from_numpy(dets_h.view(np.uint8).reshape(n_frames, -1)).cuda()
@@ -222,14 +244,38 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             n_live = int(t.item())
 
+        # second timed window right behind the first (same loop, no events): the stream has left its start-up transient
+        steady = None
+        if args.steady > 0:
+            stream.synchronize(); torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            ts0 = time.perf_counter()
+            for _ in range(args.steady):
+                step(f); f += 1
+            stream.synchronize(); torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            ts = time.perf_counter() - ts0
+            if world > 1:
+                t = torch.tensor([ts], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ts = float(t.item())
+            steady = {"value": n_live * args.steady / ts, "ms_per_step": ts / args.steady * 1e3, "frames": args.steady,
+                      "first_frame": 1 + args.warmup + args.steps}
+
         # per-kernel device time, HIP events on the launch stream (world == 1 only)
         stage = None
+        assoc_ms, used_by = [], [0, 0, 0]
         if n_prof:
             acc = np.zeros(5)
             for _ in range(n_prof):
                 fp = frames_d.data_ptr() + f * frame_bytes
                 dp = dets_d.data_ptr() + f * det_bytes
-                acc += ctx.profile_frame_device(fp, dp, n_tracks)
+                st5 = ctx.profile_frame_device(fp, dp, n_tracks)
+                acc += st5
+                assoc_ms.append(float(st5[1] + st5[3]))
+                used_by[int(ctx.lap_stats()[15]) % 3] += 1
                 if args.debug_assoc:
                     print("assoc", ctx.assoc_stats().tolist(), file=sys.stderr)
                     pa, ub = ctx.debug_kcf_phases(True)
@@ -256,32 +302,44 @@ def main():
                        "parallelism": (f"{world} replicas, no collective" if streams else f"track-shard x{world}, 1 all-gather/frame") if world > 1 else "single GPU"},
         }
         ab = alg_bytes(size)
+        if steady is not None:
+            out["steady_state"] = steady
         if stage is not None:
-            # the lifecycle step is the tail of the Munkres kernel; stage[3] is only the gap between two event records
-            kern = {"kcf_predict": stage[0], "assoc_min+sub+munkres+lifecycle": stage[1] + stage[3], "kcf_update": stage[4]}
-            dom = "kcf_update" if stage[4] >= stage[0] else "kcf_predict"
-            per_launch = ab["update" if dom == "kcf_update" else "predict"] * n_live
-            dur_s = kern[dom] * 1e-3
-            achieved = per_launch / dur_s / 1e9
+            # the lifecycle step is the tail of the final association kernel; stage[3] is only the gap between two event records
+            kern = {"kcf_predict": stage[0], "association (row scan, LAP solver, dual check, sparse / dense Munkres, lifecycle)": stage[1] + stage[3], "kcf_update": stage[4]}
+            split = os.environ.get("MOT_SPLIT_UPDATE", "1") != "0"
+            # roofline: the HBM-bound kernel with the largest device time.  With the split update the update stage on the main stream is
+            # the blend launch (its feature half runs beside the association on the side stream)
+            cands = {"kcf_predict": (stage[0], ab["predict"]), ("kcf_update (blend launch)" if split else "kcf_update"): (stage[4], ab["blend"] if split else ab["update"])}
+            dom = max(cands, key=lambda k: cands[k][0])
+            per_launch = cands[dom][1] * n_live
+            achieved = per_launch / (cands[dom][0] * 1e-3) / 1e9
             traffic = None; tj = {}
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    traffic = tj.get(f"{dom}_bytes_per_launch_n{n_tracks}")
-                except Exception:
-                    traffic = None
+            for cand_file in ("r02_traffic.json", "r01_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", cand_file)
+                if os.path.exists(tpath):
+                    try:
+                        tj = json.load(open(tpath))
+                        traffic = tj.get(("kcf_predict" if dom == "kcf_predict" else "kcf_update_blend" if split else "kcf_update") + f"_bytes_per_launch_n{n_tracks}")
+                    except Exception:
+                        traffic = None
+                    break
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "alg_bytes_per_launch": per_launch, "avg_launch_ms": kern[dom]}
-            if os.environ.get("MOT_SPLIT_UPDATE", "1") != "0":
-                # the update stage is the HBM-bound blend of the split update (its feature half runs beside the association)
-                bb = ab["blend"] * n_live
-                out["roofline_blend"] = {"bound": "hbm", "kernel": "kcf_update (blend launch)", "achieved": bb / (kern["kcf_update"] * 1e-3) / 1e9,
-                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bb / (kern["kcf_update"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         "traffic": (tj.get(f"kcf_update_blend_bytes_per_launch_n{n_tracks}") if traffic is not None else None),
-                                         "alg_bytes_per_launch": bb, "avg_launch_ms": kern["kcf_update"],
-                                         "note": "stage time between HIP events incl. the dispatch gap; the kernel alone is shorter (profiles/)"}
+                               "alg_bytes_per_launch": per_launch, "avg_launch_ms": cands[dom][0],
+                               "note": "stage time between HIP events on the launch stream incl. the dispatch gap"}
+            other = [k for k in cands if k != dom][0]
+            ob = cands[other][1] * n_live
+            out["roofline_other"] = {"bound": "hbm", "kernel": other, "achieved": ob / (cands[other][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ob / (cands[other][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": ob, "avg_launch_ms": cands[other][0]}
+            # the association stage moves almost no data: it is reported as latency-bound with its share of the frame, not against a roofline
+            tot = stage[0] + stage[1] + stage[3] + stage[4]
+            am = np.array(assoc_ms)
+            out["latency_bound"] = {"kernel": "association chain (lap_rowscan, lap_solve, lap_verify, mk_sparse, mk_postcheck, munkres/lifecycle)",
+                                    "share_of_frame": float((stage[1] + stage[3]) / tot), "ms_mean": float(am.mean()), "ms_p50": float(np.percentile(am, 50)),
+                                    "ms_p90": float(np.percentile(am, 90)), "ms_max": float(am.max()),
+                                    "decided_by": {"certificate": used_by[0], "sparse_emulation": used_by[1], "dense_emulation": used_by[2]},
+                                    "frames": len(assoc_ms), "first_frame": 1 + args.warmup + args.steps + args.steady}
             out["kernel_ms"] = {k: float(v) for k, v in kern.items()}
             out["hbm_frac_whole_frame"] = (ab["predict"] + ab["update"]) * n_live / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:

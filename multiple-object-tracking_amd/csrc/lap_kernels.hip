@@ -159,7 +159,7 @@ struct LapShared {
     int flag[8];
 };
 static_assert(sizeof(LapShared) <= MOT_LDS_LIMIT, "lap_solve_kernel LDS");
-static_assert(LAP_TS <= 32 && LAP_K <= 16, "search state: one touched column per lane, candidates in the low lanes");
+static_assert(LAP_TS <= 32 && LAP_K <= 16 && (LAP_K & (LAP_K - 1)) == 0, "search state: one touched column per lane, candidates in the low lanes");
 
 __device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-uniform
 {
@@ -212,10 +212,11 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
         for (int q = wave; q < ns; q += MK_THREADS / 64) {
             LapRec& R = S.rec[q];
             const int s0 = S.flist[q];
-            // the start row's candidates seed the touched list (slot = candidate index)
-            int tcol = -1, tpred = s0, tpk = lane; double td = DBL_MAX; bool tscan = false;
+            // the start row's candidates seed the touched list (slot = candidate index).  Every touched column carries the row that owns
+            // it (snapshot), loaded when the column is touched, so scanning a column starts without a dependent LDS read
+            int tcol = -1, tpred = s0, tpk = lane, trow = -1; double td = DBL_MAX; bool tscan = false;
             double x0 = DBL_MAX;
-            if (lane < LAP_K) { const int j = S.cj[s0 * LAP_K + lane]; if (j != 0xFFFF) { tcol = j; x0 = S.cc[s0 * LAP_K + lane] - S.v[j]; } }
+            if (lane < LAP_K) { const int j = S.cj[s0 * LAP_K + lane]; if (j != 0xFFFF) { tcol = j; x0 = S.cc[s0 * LAP_K + lane] - S.v[j]; trow = S.rowOfCol[j]; } }
             const double us = row16_min_f64(x0);                       // candidates sit in lanes 0..15
             if (tcol >= 0) td = x0 - us;
             int nt = __popcll(__ballot(tcol >= 0));                    // valid candidates are a prefix of the list
@@ -228,12 +229,21 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
                 const int b = __ffsll((long long)bm) - 1;
                 Delta = best;
                 const int j = __builtin_amdgcn_readlane(tcol, b);
-                const int i = S.rowOfCol[j];
+                const int i = __builtin_amdgcn_readlane(trow, b);
                 if (i < 0) { jend = b; break; }
                 if (lane == b) tscan = true;
-                const double ui = S.mcost[i] - S.v[j];
-                int cj2 = 0xFFFF; double nd = DBL_MAX;
-                if (lane < LAP_K) { cj2 = S.cj[i * LAP_K + lane]; if (cj2 != 0xFFFF) nd = best + ((S.cc[i * LAP_K + lane] - S.v[cj2]) - ui); }
+                // one round trip: the owner's matched cost, the column's price, the owner's candidate list
+                const int kk = lane & (LAP_K - 1);
+                const double mc = S.mcost[i], vj = S.v[j];
+                const int cj2v = S.cj[i * LAP_K + kk];
+                const double ccv = S.cc[i * LAP_K + kk];
+                const double ui = mc - vj;
+                // second round trip: price and owner of every candidate
+                const int cjc = cj2v == 0xFFFF ? 0 : cj2v;
+                const double v2 = S.v[cjc];
+                const int ow2 = S.rowOfCol[cjc];
+                const int cj2 = lane < LAP_K ? cj2v : 0xFFFF;
+                const double nd = (lane < LAP_K && cj2v != 0xFFFF) ? best + ((ccv - v2) - ui) : DBL_MAX;
 #pragma unroll
                 for (int k = 0; k < LAP_K; k++) {
                     const int j2 = __builtin_amdgcn_readlane(cj2, k);
@@ -243,7 +253,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
                     const u64 m = __ballot(lane < nt && tcol == j2);
                     if (m) { if (((m >> lane) & 1) && !tscan && ndk < td) { td = ndk; tpred = i; tpk = k; } }
                     else if (nt == LAP_TS) { fail = true; break; }
-                    else { if (lane == nt) { tcol = j2; td = ndk; tpred = i; tpk = k; tscan = false; } nt++; }
+                    else { const int o2 = __builtin_amdgcn_readlane(ow2, k); if (lane == nt) { tcol = j2; td = ndk; tpred = i; tpk = k; tscan = false; trow = o2; } nt++; }
                 }
                 if (fail) break;
             }

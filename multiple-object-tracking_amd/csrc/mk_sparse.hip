@@ -47,7 +47,7 @@ struct SpShared {
     int flag[8];
 };
 static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
-static_assert(SPK <= 16, "candidate index is packed into 4 bits");
+static_assert(SPK <= 16 && (SPK & (SPK - 1)) == 0 && (SP_TLS & (SP_TLS - 1)) == 0, "candidate index is packed into 4 bits; lane masks");
 static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certify scratch");
 
 __device__ __forceinline__ bool bit_of(const u64* m, int i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
@@ -182,17 +182,21 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
                 const int col = wave_first_bit(cand, lane, MK_MAXW);
                 if (col < 0) { if (found) { found = false; from = 0; continue; } action = 2; break; }
-                // first uncovered row holding a zero in this column: one LDS round trip (slots in lanes 0..31, the live mask in lane 32)
-                const unsigned ld = lane < SP_TLS ? (unsigned)S.tl[col * SP_TLS + lane] : S.tlive[col];
-                const unsigned lv = (unsigned)__builtin_amdgcn_readlane((int)ld, SP_TLS);
+                // first uncovered row holding a zero in this column: ONE LDS round trip (every lane issues both loads, no branch between them)
+                const unsigned tlv = S.tlive[col];
+                const unsigned tle = S.tl[col * SP_TLS + (lane & (SP_TLS - 1))];
+                const unsigned lv = (unsigned)__builtin_amdgcn_readfirstlane((int)tlv);
                 if (lv == 0) { action = 4; break; }                    // hz out of step with the masks: cannot happen
                 const int slot = __ffs((int)lv) - 1;
-                const int row = __builtin_amdgcn_readlane((int)ld, slot) >> 4;
-                // the row's star, its zeros and where they sit in their columns' lists: one more round trip
-                const int sc = S.starColOfRow[row];
-                const unsigned m = S.zmask[row];
-                int c2 = 0, ps = 0;
-                if (lane < SPK) { c2 = S.cj[lane * MK_MAXN + row]; ps = S.pos[lane * MK_MAXN + row]; }
+                const int row = __builtin_amdgcn_readlane((int)tle, slot) >> 4;
+                // the row's star, its zeros and where they sit in their columns' lists: one more round trip, all loads issued together
+                const int kk = lane & (SPK - 1);
+                const int sc_v = S.starColOfRow[row];
+                const unsigned m_v = S.zmask[row];
+                const int c2 = S.cj[kk * MK_MAXN + row];
+                const int ps = S.pos[kk * MK_MAXN + row];
+                const int sc = __builtin_amdgcn_readfirstlane(sc_v);
+                const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)m_v);
                 if (lane == 0) S.primeColOfRow[row] = (short)col;      // :255
                 if (sc < 0) {
                     // ---------- step 4 (:283-334) ----------
