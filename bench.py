@@ -44,10 +44,10 @@ def alg_bytes(size):
             "blend": 3 * 31 * nb * 8 + 3 * nb * 4 + 24}
 
 
-def gen_stream(n_tracks, size, n_frames, stream_id=0):
+def gen_stream(n_tracks, size, n_frames, stream_id=0, det_sizes=None):
     import mot_amd
     from multiple_object_tracking_amd import synth
-    scene = synth.Scene(n_tracks, size, stream_id=stream_id)
+    scene = synth.Scene(n_tracks, size, stream_id=stream_id, det_sizes=det_sizes, first_frame_exact=det_sizes is not None)
     frames = np.empty((n_frames, 720, 1280, 3), np.uint8)
     dets = np.zeros((n_frames, n_tracks), mot_amd.BBOX_DTYPE)
     for f, (frame, d) in enumerate(scene.frames(n_frames)):
@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tracks", type=int, default=1024, help="total concurrent KCF tracks (all GPUs)")
     ap.add_argument("--size", type=int, default=80, help="square template / object size in pixels")
+    ap.add_argument("--det-sizes", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="multi-scale detections (BASELINE configs[4]): tracks are spawned with the --size template from frame 0, "
+                         "from frame 1 on every detection is a random square of LO..HI px that the tracker resizes to its template")
     ap.add_argument("--mode", choices=["sharded", "streams"], default="sharded",
                     help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded tid %% N, one all-gather per frame (BASELINE configs[3], strong scaling); "
                          "streams = N independent camera streams of --tracks tracks each, one per GPU, no collective (BASELINE configs[4], weak scaling)")
@@ -178,7 +181,7 @@ def main():
     mot_rank, mot_world = (0, 1) if streams else (rank, world)
     n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
     n_frames = 1 + args.warmup + args.steps + args.steady + n_prof
-    frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0)
+    frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0, det_sizes=tuple(args.det_sizes) if args.det_sizes else None)
     frames_d = torch.from_numpy(frames_h).cuda()
     dets_d = torch.from_numpy(dets_h.view(np.uint8).reshape(n_frames, -1)).cuda()
     frame_bytes = 720 * 1280 * 3
@@ -289,6 +292,7 @@ def main():
         out = {
             "metric": "tracker-updates/sec (KCF, 80x80 patch)", "value": value, "unit": "tracker-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            **({"rccl_ranks": world, "collective": "1 x all_gather_into_tensor(bbox_t[max_tracks]) per frame" if not streams else "none"} if world > 1 and backend != "gloo" else {}),
             **({"smoke_backend": "gloo (not a measurement)"} if backend == "gloo" and world > 1 else {}),
             "higher_is_better": True, "scaling": "weak" if streams else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{world} independent camera streams (one per GPU, no collective), each {n_tracks} concurrent {size}x{size} KCF tracks, "
@@ -298,7 +302,7 @@ def main():
                                     f"BASELINE configs[{2 if n_tracks == 1024 else 1}]" + ("/[3]" if world > 1 else "")),
                        **({"streams_per_gpu": args.streams_per_gpu, "note": "K independent contexts on K HIP streams of one GPU; value = all streams"} if extra else {}),
                        "tracks_total": n_tracks * (world if streams else 1) * (1 + len(extra)), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
-                       "live_tracks_end": n_live, "patch": size,
+                       "live_tracks_end": n_live, "patch": size, **({"det_sizes": args.det_sizes} if args.det_sizes else {}),
                        "parallelism": (f"{world} replicas, no collective" if streams else f"track-shard x{world}, 1 all-gather/frame") if world > 1 else "single GPU"},
         }
         ab = alg_bytes(size)

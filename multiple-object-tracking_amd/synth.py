@@ -44,9 +44,13 @@ def _int_sine(period: int, amp: int) -> np.ndarray:
 
 class Scene:
     def __init__(self, n_objects: int, size: int = 80, stream_id: int = 0, det_sizes: tuple[int, int] | None = None,
-                 miss_pct: int = 0, fp_pct: int = 0):
+                 miss_pct: int = 0, fp_pct: int = 0, first_frame_exact: bool = False):
         self.n, self.size = n_objects, size
         self.det_sizes = det_sizes  # (lo, hi): detection boxes get a random square size in [lo, hi] around the object centre
+        # first_frame_exact: frame 0's detections have exactly `size` (every track is spawned with the size x size template,
+        # td.cpp:626-627 freezes it), the random sizes start with frame 1 -> BASELINE configs[4]: one template size, multi-scale
+        # detections resized to it (td.cpp:528-537)
+        self.first_frame_exact = first_frame_exact
         self.miss_pct, self.fp_pct = miss_pct, fp_pct
         seed = 0x5EED0000 + stream_id
         self.seed = seed
@@ -98,7 +102,7 @@ class Scene:
                 continue
             jx, jy = rng.randint(-2, 2), rng.randint(-2, 2)
             ds = s
-            if self.det_sizes:
+            if self.det_sizes and not (self.first_frame_exact and self.t == 0):
                 ds = rng.randint(self.det_sizes[0], self.det_sizes[1])
             cx, cy = int(self.pos[k, 0]) + s // 2 + jx, int(self.pos[k, 1]) + s // 2 + jy
             l = min(max(cx - ds // 2, 0), FRAME_W - ds)

@@ -1,0 +1,73 @@
+"""RCCL leg of the sharded device loop: two ranks on two GPUs, ONE all_gather_into_tensor of the predicted bbox_t per frame
+(torch.distributed backend "nccl" = RCCL over xGMI), replicated association, local updates -- both ranks must reproduce
+the unsharded oracle.  Needs two visible devices; on the single-GPU test box it skips itself (the driver's 8-GPU node runs it)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import mot_amd
+    import orc
+    from multiple_object_tracking_amd import parallel as par, synth
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    n, nframes = 96, 6
+    scene = synth.Scene(n, 80, stream_id=61, miss_pct=5, fp_pct=3)
+    items = list(scene.frames(nframes))
+    ctx = mot_amd.MotContext(max_tracks=128, max_dets=128, device=rank, rank=rank, world=world)
+    oracle = orc.OracleMot(orc.load_oracle(), 0, 0, 128)
+    ok = True
+    gathered = None
+    for f, (frame, dets) in enumerate(items):
+        fd = torch.from_numpy(frame).cuda()
+        da = mot_amd.boxes_array(dets) if len(dets) else np.zeros(1, mot_amd.BBOX_DTYPE)
+        dd = torch.from_numpy(da.view(np.uint8)).cuda()
+        seg_ptr, spr = ctx.step_begin_device(fd.data_ptr())
+        local = torch.as_tensor(par.DevArray(seg_ptr, spr * 24), device="cuda")
+        if gathered is None:
+            gathered = torch.empty(world * spr * 24, dtype=torch.uint8, device="cuda")
+        ctx.sync()                                                  # the predict kernel wrote this rank's segment
+        par.all_gather_boxes(local, gathered)
+        torch.cuda.synchronize()
+        ctx.step_finish_device(gathered.data_ptr(), dd.data_ptr(), len(dets))
+        ref = oracle.step(frame, dets)
+        boxes, tids, _ = ctx.live_tracks()
+        ok &= bool(np.array_equal(tids, ref["tids"]))
+        ok &= all(np.array_equal(boxes[k], ref["live"][k]) for k in ("l", "t", "b", "r", "type"))
+    dist.barrier()
+    q.put((rank, ok))
+    ctx.close(); oracle.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_rccl_all_gather():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL)")
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)
