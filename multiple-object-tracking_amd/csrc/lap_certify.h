@@ -24,7 +24,29 @@ __device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scra
     int reason = 0;                                                     // 0 certified, 1 solver gave up / n.a., 2 infeasible dual, 3 too many near-tight edges, 4 tie
     if (solve != 0 || bad) reason = 1; else if (viol) reason = 2; else if (ne > LAP_EDGES) reason = 3;
     int ncyc = 0;
-    if (!reason) {
+    if (!reason && ne <= 16 * 64) {
+        // the usual case, a few hundred edges: wavefront 0 alone, no workgroup barriers (LDS operations of one wavefront execute in order)
+        if (tid < 64) {
+            const int lane = tid;
+            for (int e = lane; e < ne; e += 64) ed[e] = L.edges[e];
+            for (int i = lane; i <= nR; i += 64) alive[i] = 1;
+            for (int it = 0; it <= nR + 1; it++) {
+                for (int i = lane; i <= nR; i += 64) hasout[i] = 0;
+                for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; const int s = x >> 16, d = x & 0xFFFF; if (alive[s] && alive[d]) hasout[s] = 1; }
+                bool ch = false;
+                for (int i = lane; i <= nR; i += 64) if (alive[i] && !hasout[i]) { alive[i] = 0; ch = true; }
+                if (!__ballot(ch)) break;
+            }
+            int mine = 0;
+            for (int i = lane; i <= nR; i += 64) mine += alive[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+            if (lane == 0) flag2[1] = mine;
+        }
+        __syncthreads();
+        ncyc = flag2[1];
+        if (ncyc) reason = 4;
+    } else if (!reason) {
         for (int e = tid; e < ne; e += MK_THREADS) ed[e] = L.edges[e];
         for (int i = tid; i <= nR; i += MK_THREADS) alive[i] = 1;
         __syncthreads();

@@ -193,7 +193,9 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     if (tid < nR) { const int j = S.cj[tid * LAP_K]; if (S.lock[j] == (unsigned)tid) { S.rowOfCol[j] = (short)tid; S.colOfRow[tid] = (short)j; S.mcost[tid] = S.cc[tid * LAP_K]; } }
     __syncthreads();
     int rounds = 0, free0 = -1, searches = 0, commits = 0;
+    const long long t_init = wall_clock64(); long long t_sr = 0, t_cm = 0;
     for (;;) {
+        const long long t_r0 = wall_clock64();
         // free rows, ascending
         const bool isfree = tid < nR && S.colOfRow[tid] < 0;
         const u64 bal = __ballot(isfree);
@@ -242,20 +244,37 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
                 const int cjc = cj2v == 0xFFFF ? 0 : cj2v;
                 const double v2 = S.v[cjc];
                 const int ow2 = S.rowOfCol[cjc];
-                const int cj2 = lane < LAP_K ? cj2v : 0xFFFF;
-                const double nd = (lane < LAP_K && cj2v != 0xFFFF) ? best + ((ccv - v2) - ui) : DBL_MAX;
+                const double ndc = cj2v != 0xFFFF ? best + ((ccv - v2) - ui) : DBL_MAX;   // lane l holds candidate l & 7
+                // which touched slot already holds each candidate (mk: per slot, the candidate that matches it; hit: per candidate)
+                int mk = -1; unsigned hit = 0;
 #pragma unroll
                 for (int k = 0; k < LAP_K; k++) {
-                    const int j2 = __builtin_amdgcn_readlane(cj2, k);
-                    if (j2 == 0xFFFF) break;
-                    if (j2 == j) continue;
-                    const double ndk = readlane_f64(nd, k);
-                    const u64 m = __ballot(lane < nt && tcol == j2);
-                    if (m) { if (((m >> lane) & 1) && !tscan && ndk < td) { td = ndk; tpred = i; tpk = k; } }
-                    else if (nt == LAP_TS) { fail = true; break; }
-                    else { const int o2 = __builtin_amdgcn_readlane(ow2, k); if (lane == nt) { tcol = j2; td = ndk; tpred = i; tpk = k; tscan = false; trow = o2; } nt++; }
+                    const int j2 = __builtin_amdgcn_readlane(cj2v, k);
+                    const bool eq = lane < nt && tcol == j2;           // 0xFFFF (no candidate) never equals a column
+                    if (eq) mk = k;
+                    if (__ballot(eq)) hit |= 1u << k;
                 }
-                if (fail) break;
+                // a touched, unscanned column improves (the scanned column itself matches its own scanned slot and is skipped here)
+                {
+                    const int src = (mk < 0 ? 0 : mk) << 2;
+                    const u64 nb = (u64)__double_as_longlong(ndc);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)nb), hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(nb >> 32));
+                    const double ndm = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                    if (mk >= 0 && !tscan && ndm < td) { td = ndm; tpred = i; tpk = mk; }
+                }
+                // candidates that are new to this search take the next slots, in candidate order
+                unsigned newm = 0;
+#pragma unroll
+                for (int k = 0; k < LAP_K; k++) if (__builtin_amdgcn_readlane(cj2v, k) != 0xFFFF) newm |= 1u << k;
+                newm &= ~hit;
+                if (nt + __popc(newm) > LAP_TS) { fail = true; break; }
+                while (newm) {
+                    const int k = __ffs((int)newm) - 1; newm &= newm - 1;
+                    const int fc = __builtin_amdgcn_readlane(cj2v, k), fo = __builtin_amdgcn_readlane(ow2, k);
+                    const double fn = readlane_f64(ndc, k);
+                    if (lane == nt) { tcol = fc; td = fn; tpred = i; tpk = k; tscan = false; trow = fo; }
+                    nt++;
+                }
             }
             if (fail) { if (lane == 0) { R.ok = 0; S.flag[0] = 1; } continue; }
             // record: touched columns, price decrements of the scanned ones, locks
@@ -277,6 +296,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
             if (lane == 0) { R.nt = nt; R.plen = plen; R.ok = plen > 0; if (plen <= 0) S.flag[0] = 2; }
         }
         __syncthreads();
+        const long long t_r1 = wall_clock64(); t_sr += t_r1 - t_r0;
         if (S.flag[0]) break;
         // commits: a search that holds the lock of every column it scanned and of its end column
         for (int q = wave; q < ns; q += MK_THREADS / 64) {
@@ -293,7 +313,9 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
             }
         }
         __syncthreads();
+        t_cm += wall_clock64() - t_r1;
     }
+    const long long t_loop = wall_clock64();
     __syncthreads();
     const int status = S.flag[0] ? 1 : 0;
     // duals, Gamma = sum_i (c[i][M(i)] - rowmin_i), margins
@@ -323,6 +345,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
         L.hdr[LAP_H_SOLVE] = status;
         L.hdr[LAP_H_LAST + 1] = rounds; L.hdr[LAP_H_LAST + 2] = free0; L.hdr[LAP_H_LAST + 3] = searches; L.hdr[LAP_H_LAST + 4] = ctot;
         L.hdr[LAP_H_LAST + 7] = (int)(wall_clock64() - t_begin);
+        L.hdr[49] = (int)(t_init - t_begin); L.hdr[50] = (int)t_sr; L.hdr[51] = (int)t_cm; L.hdr[52] = (int)(wall_clock64() - t_loop);   // (debug: phase ticks)
     }
 }
 

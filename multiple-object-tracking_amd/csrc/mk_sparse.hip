@@ -115,33 +115,40 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         } else S.tlive[tid] = 0;
         __syncthreads();
     }
-    // ---- step 1 (:93-101): rows ascending, each stars its first zero BY COLUMN INDEX whose column is still free.  A row whose
-    // first zero lies in a column with a single zero can be starred out of order; the others go through an ordered pass ----
-    bool contested = false;
-    if (r < nR && zm) {
-        int fz = 0xFFFF;
+    // ---- step 1 (:93-101): rows ascending, each stars its first zero BY COLUMN INDEX whose column is still free.
+    // A row with ONE zero ("simple") can only ever want that column: among the simple rows of a column the lowest one gets it, unless
+    // a lower row with several zeros took it first.  Only the rows with several zeros ("complex": equal row minima, e.g. two tracks
+    // on one centroid) need the ordered pass, and they are few: wavefront 0 walks them in ascending order and asks, per zero column in
+    // ascending order, whether a lower simple row claims it (minSimple) or an earlier complex row took it (starRowOfCol). ----
+    int* minSimple = S.cnt;                                            // fill cursors are spent
+    minSimple[tid] = 0x7FFFFFFF;
+    __syncthreads();
+    const int nz = __popc(zm);
+    int fz = 0xFFFF;
 #pragma unroll
-        for (int k = 0; k < SPK; k++) if ((zm >> k) & 1) fz = min(fz, (int)myc[k]);
-        if (__popc(S.tzero[fz]) == 1) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; }
-        else contested = true;
-    }
+    for (int k = 0; k < SPK; k++) if ((zm >> k) & 1) fz = min(fz, (int)myc[k]);
+    if (r < nR && nz == 1) atomicMin(&minSimple[fz], r);
     {
-        const u64 bal = __ballot(contested);
+        const bool complex_row = r < nR && nz > 1;
+        const u64 bal = __ballot(complex_row);
         if (lane == 0) S.wave_tot[wave] = __popcll(bal);
         __syncthreads();
-        int off = 0, ncont = 0;
-        for (int w = 0; w < MK_THREADS / 64; w++) { const int t = S.wave_tot[w]; if (w < wave) off += t; ncont += t; }
-        if (contested) S.clist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
+        int off = 0, ncx = 0;
+        for (int w = 0; w < MK_THREADS / 64; w++) { const int t = S.wave_tot[w]; if (w < wave) off += t; ncx += t; }
+        if (complex_row) S.clist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
         __syncthreads();
-        if (wave == 0) {                                               // ordered pass: lane = candidate slot of the row in turn
-            for (int q = 0; q < ncont; q++) {
+        if (wave == 0) {                                               // ordered pass over the complex rows: lane = candidate slot
+            for (int q = 0; q < ncx; q++) {
                 const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
                 unsigned key = 0xFFFFu;
-                if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (S.starRowOfCol[c] < 0) key = (unsigned)c; }
+                if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (minSimple[c] > rr && S.starRowOfCol[c] < 0) key = (unsigned)c; }
                 key = wave_min_u32_dpp(key);
                 if (lane == 0 && key != 0xFFFFu) { S.starColOfRow[rr] = (short)key; S.starRowOfCol[key] = (short)rr; }
             }
         }
+        __syncthreads();
+        // simple rows: the lowest claimant of a column stars it unless a complex row holds it
+        if (r < nR && nz == 1 && minSimple[fz] == r && S.starRowOfCol[fz] < 0) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; }
         __syncthreads();
     }
     {   // step 2a: covered columns = starred columns; hz = hzAll = columns that hold a zero
