@@ -40,6 +40,29 @@ def test_traffic_derivation_on_committed_counters():
     assert 1.0 <= tj["kcf_predict_bytes_per_launch_n1024"] / alg_predict < 1.05
 
 
+def test_round2_traffic_derivation_and_bench_line():
+    prof = os.path.join(ROOT, "profiles")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "derive_traffic.py"),
+                          os.path.join(prof, "r02_pmc_fetch_size.csv"), os.path.join(prof, "r02_pmc_write_size.csv"), "1024"],
+                         capture_output=True, text=True, check=True)
+    tj = json.loads(out.stdout)
+    assert tj == json.load(open(os.path.join(prof, "r02_traffic.json")))
+    assert 1.0 <= tj["kcf_predict_bytes_per_launch_n1024"] / (1024 * (19200 + 54560 + 880 + 48)) < 1.05
+    for name in ("r02_bench_n1024.json", "r02_bench_n1024_driver_style.json"):
+        j = json.loads(open(os.path.join(prof, name)).read().strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "cpu_baseline", "steady_state", "latency_bound"):
+            assert key in j, (name, key)
+        r = j["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert abs(r["traffic"] - tj["kcf_predict_bytes_per_launch_n1024"]) / tj["kcf_predict_bytes_per_launch_n1024"] < 0.01   # PMC passes of the same build
+        c = j["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["all_cores"]["cores"] >= 1
+        lb = j["latency_bound"]
+        assert 0 < lb["share_of_frame"] < 1 and sum(lb["decided_by"].values()) == lb["frames"]
+        assert abs(j["value"] - j["config"]["live_tracks_end"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+
+
 def test_committed_bench_line_keeps_the_contract():
     j = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_n1024.json")).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",

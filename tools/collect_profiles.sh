@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02; mkdir -p $O
+python bench.py > $O/bench_n1024.json 2> $O/bench_n1024.err
+python bench.py --steps 20 --warmup 5 > $O/bench_n1024_driver.json 2>/dev/null
+python bench.py --tracks 64 --no-cpu-baseline > $O/bench_n64.json 2>/dev/null
+python bench.py --tracks 256 --no-cpu-baseline > $O/bench_n256.json 2>/dev/null
+python bench.py --tracks 512 --no-cpu-baseline > $O/bench_n512.json 2>/dev/null
+python bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline > $O/bench_n256_s148_multiscale.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_default -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_driver -- python3 bench.py --steps 20 --warmup 5 --steady 0 --profile-frames 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --steady 0 --no-cpu-baseline --profile-frames 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 20 --warmup 5 --steady 0 --no-cpu-baseline --profile-frames 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --steady 0 --no-cpu-baseline --profile-frames 0 > $O/pmc_sq.log 2>&1
+ls -R $O | head -60

@@ -15,7 +15,7 @@ def med(path, counter):
             if row["Counter_Name"] != counter:
                 continue
             name = row["Kernel_Name"]
-            for key in ("kcf_predict", "kcf_update", "munkres", "assoc_min", "assoc_sub", "dl_lifecycle", "dl_scatter", "kalman"):
+            for key in ("kcf_predict", "kcf_update", "munkres", "assoc_min", "assoc_sub", "lap_rowscan", "lap_solve", "lap_verify", "mk_sparse", "mk_postcheck", "dl_lifecycle", "dl_scatter", "kalman"):
                 if key in name:
                     per.setdefault(key, []).append(float(row["Counter_Value"]))
                     break
