@@ -25,26 +25,28 @@ __device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scra
     if (solve != 0 || bad) reason = 1; else if (viol) reason = 2; else if (ne > LAP_EDGES) reason = 3;
     int ncyc = 0;
     if (!reason && ne <= 16 * 64) {
-        // the usual case, a few hundred edges: wavefront 0 alone, no workgroup barriers (LDS operations of one wavefront execute in order)
+        // the usual case, a few hundred edges: wavefront 0 alone, no workgroup barriers (LDS operations of one wavefront execute in order).
+        // Only edge sources can survive a peel round, so the rounds walk the edge list, never the node range: alive[] starts as "is the
+        // source of some edge", hasout[] holds the number of the last round in which the node still had an edge into the alive set.
         if (tid < 64) {
             const int lane = tid;
-            for (int e = lane; e < ne; e += 64) ed[e] = L.edges[e];
-            for (int i = lane; i <= nR; i += 64) alive[i] = 1;
-            for (int it = 0; it <= nR + 1; it++) {
-                for (int i = lane; i <= nR; i += 64) hasout[i] = 0;
-                for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; const int s = x >> 16, d = x & 0xFFFF; if (alive[s] && alive[d]) hasout[s] = 1; }
+            unsigned* aw = reinterpret_cast<unsigned*>(alive); unsigned* hw = reinterpret_cast<unsigned*>(hasout);
+            for (int i = lane; i < (MK_MAXN + 64) / 4; i += 64) { aw[i] = 0; hw[i] = 0; }
+            for (int e = lane; e < ne; e += 64) { const unsigned x = L.edges[e]; ed[e] = x; alive[x >> 16] = 1; }
+            for (int it = 1;; it++) {
+                for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; if (alive[x >> 16] && alive[x & 0xFFFF]) hasout[x >> 16] = (unsigned char)it; }
                 bool ch = false;
-                for (int i = lane; i <= nR; i += 64) if (alive[i] && !hasout[i]) { alive[i] = 0; ch = true; }
+                for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; if (alive[x >> 16] && hasout[x >> 16] != (unsigned char)it) { alive[x >> 16] = 0; ch = true; } }
                 if (!__ballot(ch)) break;
+                if (it == 250) { for (int i = lane; i < (MK_MAXN + 64) / 4; i += 64) hw[i] = 0; it = 0; }   // (round numbers are bytes: start over)
             }
             int mine = 0;
-            for (int i = lane; i <= nR; i += 64) mine += alive[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-            if (lane == 0) flag2[1] = mine;
+            for (int e = lane; e < ne; e += 64) if (alive[ed[e] >> 16]) mine = 1;
+            if (lane == 0) flag2[1] = 0;
+            if (__ballot(mine != 0) && lane == 0) flag2[1] = 1;
         }
         __syncthreads();
-        ncyc = flag2[1];
+        ncyc = flag2[1] ? 2 : 0;                                        // (a count is only kept by the block path below)
         if (ncyc) reason = 4;
     } else if (!reason) {
         for (int e = tid; e < ne; e += MK_THREADS) ed[e] = L.edges[e];

@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     const int bad = L.hdr[LAP_H_BAD];
     const int reason = lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(sp_raw), S.flag);
     __syncthreads();
+    const long long t_cert = wall_clock64();
     if (reason == 0) { if (tid == 0) L.hdr[LAP_H_MODE] = 0; return; }
     if (bad) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }          // negative / non-finite costs: dense emulation
     // ---- set-up: candidate entries (values in registers: only the row's own thread ever touches them), d = c - row minimum
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         } else S.tlive[tid] = 0;
         __syncthreads();
     }
+    const long long t_lists = wall_clock64();
     // ---- step 1 (:93-101): rows ascending, each stars its first zero BY COLUMN INDEX whose column is still free.
     // A row with ONE zero ("simple") can only ever want that column: among the simple rows of a column the lowest one gets it, unless
     // a lower row with several zeros took it first.  Only the rows with several zeros ("complex": equal row minima, e.g. two tracks
@@ -163,39 +165,46 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     bool done = ncov == nR;
     int n_prime = 0, n_s5 = 0, n_aug = 0; long long t_s3 = 0, t_s5 = 0;
     const long long t_setup = wall_clock64() - t_begin;
-    const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
-    u64 cC = (lane < MK_MAXW) ? S.covC[lane] : 0, cR = 0, phaseUnc = 0;   // wave 0: lane w holds word w
-    u64 hzr = (lane < MK_MAXW) ? S.hz[lane] : 0, hzAllr = hzr;            // wave 0: columns with a live zero / with any zero
-    bool hz_dirty = false;                                                // step 5 changed the masks: wave 0 rebuilds hzr / hzAllr
+    // Wavefront 0 keeps the 1024-bit masks as 32-bit words, lane l (and its mirror l + 32) holding word l & 31: covered columns /
+    // rows, columns uncovered in this phase, columns with a live zero (hzr) / with any zero (hzAllr).  Mirroring the upper half lets
+    // every lane store its word to the LDS copies without a branch.
+    unsigned* covR32 = reinterpret_cast<unsigned*>(S.covR); unsigned* covC32 = reinterpret_cast<unsigned*>(S.covC);
+    const int l5 = lane & 31;
+    const unsigned vC = (l5 * 32 + 32 <= nC) ? ~0u : (l5 * 32 >= nC ? 0u : ((1u << (nC & 31)) - 1u));
+    unsigned cC = covC32[l5], cR = 0, ph = 0;
+    unsigned hzr = reinterpret_cast<unsigned*>(S.hz)[l5], hzAllr = hzr;
+    int nstar = ncov;                                                  // starred columns: + 1 per augmentation
+    bool hz_dirty = false;                                             // step 5 changed the masks: wave 0 rebuilds hzr / hzAllr
     int status = 0;
     while (!done) {
         const long long t_a = wall_clock64();
         // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
         if (wave == 0) {
-            int action = 0; int from = 0; bool found = false;
+            int action = 0; bool found = false;
+            unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
             if (hz_dirty) {                                            // after a step 5: one pass over the column masks
-                u64 nl = 0, na = 0;
+                unsigned nl = 0, na = 0;
 #pragma unroll
                 for (int w = 0; w < MK_MAXW; w++) {
                     const u64 bl = __ballot(S.tlive[w * 64 + lane] != 0), ba = __ballot(S.tzero[w * 64 + lane] != 0);
-                    if (lane == w) { nl = bl; na = ba; }
+                    if (l5 == 2 * w) { nl = (unsigned)bl; na = (unsigned)ba; }
+                    if (l5 == 2 * w + 1) { nl = (unsigned)(bl >> 32); na = (unsigned)(ba >> 32); }
                 }
                 hzr = nl; hzAllr = na; hz_dirty = false;
             }
             while (action == 0) {
                 if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
-                u64 cand = hzr & ~cC & vC;
-                const int fw = from >> 6;
-                if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
-                const int col = wave_first_bit(cand, lane, MK_MAXW);
-                if (col < 0) { if (found) { found = false; from = 0; continue; } action = 2; break; }
+                const unsigned cand = hzr & ~cC & vC & fm;
+                const unsigned cb = (unsigned)__ballot(cand != 0);     // (the upper half mirrors the lower one)
+                if (!cb) { if (found) { found = false; fm = ~0u; continue; } action = 2; break; }
+                const int cw = __ffs((int)cb) - 1;
+                const int col = cw * 32 + __ffs(__builtin_amdgcn_readlane((int)cand, cw)) - 1;
                 // first uncovered row holding a zero in this column: ONE LDS round trip (every lane issues both loads, no branch between them)
                 const unsigned tlv = S.tlive[col];
-                const unsigned tle = S.tl[col * SP_TLS + (lane & (SP_TLS - 1))];
+                const unsigned tle = S.tl[col * SP_TLS + l5];
                 const unsigned lv = (unsigned)__builtin_amdgcn_readfirstlane((int)tlv);
+                const int row = __builtin_amdgcn_readlane((int)tle, lv ? __ffs((int)lv) - 1 : 0) >> 4;   // (before the check: both loads are issued together)
                 if (lv == 0) { action = 4; break; }                    // hz out of step with the masks: cannot happen
-                const int slot = __ffs((int)lv) - 1;
-                const int row = __builtin_amdgcn_readlane((int)tle, slot) >> 4;
                 // the row's star, its zeros and where they sit in their columns' lists: one more round trip, all loads issued together
                 const int kk = lane & (SPK - 1);
                 const int sc_v = S.starColOfRow[row];
@@ -204,7 +213,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 const int ps = S.pos[kk * MK_MAXN + row];
                 const int sc = __builtin_amdgcn_readfirstlane(sc_v);
                 const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)m_v);
-                if (lane == 0) S.primeColOfRow[row] = (short)col;      // :255
+                S.primeColOfRow[row] = (short)col;                     // :255 (every lane stores the same value)
                 if (sc < 0) {
                     // ---------- step 4 (:283-334) ----------
                     n_aug++;
@@ -221,32 +230,37 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                         last = cc;
                     }
                     last = __builtin_amdgcn_readfirstlane(last);
-                    if (lane < MK_MAXW) { u64 t = cR; while (t) { const int r2 = lane * 64 + __ffsll((long long)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
-                    if (lane == 0) S.primeColOfRow[row] = -1;
-                    cR = 0;
-                    cC |= phaseUnc; if (last >= 0 && lane == (last >> 6)) cC |= 1ull << (last & 63);
-                    phaseUnc = 0;
-                    if (lane < MK_MAXW) S.covR[lane] = 0;
+                    if (lane < 32) { unsigned t = cR; while (t) { const int r2 = lane * 32 + __ffs((int)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
+                    S.primeColOfRow[row] = -1;
+                    cR = 0; covR32[l5] = 0;
+                    cC |= ph; if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);   // step 2a: every starred column is covered again
+                    ph = 0;
                     hzr = hzAllr;
                     for (int i = lane; i < nC; i += 64) S.tlive[i] = S.tzero[i];      // all rows uncovered again (:324-330)
-                    int total = 0;
-                    for (int w = 0; w < wordsC; w++) total += __popcll(readlane64(cC, w));
-                    if (total == nR) { action = 3; break; }
-                    from = 0; found = false;
+                    if (++nstar == nR) { action = 3; break; }          // step 2b
+                    fm = ~0u; found = false;
                     continue;
                 }
                 // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
-                if (lane == (row >> 6)) { cR |= 1ull << (row & 63); S.covR[lane] = cR; }
+                cR |= (l5 == (row >> 5)) ? (1u << (row & 31)) : 0u;
+                covR32[l5] = cR;
                 bool emptied = false;
                 if (lane < SPK && ((m >> lane) & 1)) { const unsigned bitv = 1u << ps; emptied = atomicAnd(&S.tlive[c2], ~bitv) == bitv; }
                 for (u64 eb = __ballot(emptied); eb; eb &= eb - 1) {   // columns that lost their last live zero (usually none or one)
                     const int ce = __builtin_amdgcn_readlane(c2, __ffsll((long long)eb) - 1);
-                    if (lane == (ce >> 6)) hzr &= ~(1ull << (ce & 63));
+                    hzr &= ~((l5 == (ce >> 5)) ? (1u << (ce & 31)) : 0u);
                 }
-                if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); }
-                found = true; from = col + 1;                          // :273
+                {
+                    const unsigned sb = (l5 == (sc >> 5)) ? (1u << (sc & 31)) : 0u;
+                    cC &= ~sb; ph |= sb;
+                }
+                found = true;
+                {   // the sweep continues behind this column (:273)
+                    const int from = col + 1, fw = from >> 5;
+                    fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
+                }
             }
-            if (lane < MK_MAXW) S.covC[lane] = cC;
+            covC32[l5] = cC;
             if (lane == 0) S.flag[1] = action;
         }
         __syncthreads();
@@ -306,7 +320,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
         L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
         L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
-        L.hdr[48] = (int)t_setup;                                      // (debug: set-up ticks)
+        L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
     }
 }
 
