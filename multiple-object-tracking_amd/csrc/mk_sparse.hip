@@ -32,7 +32,7 @@ namespace {
 
 struct SpShared {
     double Scol[MK_MAXN];                    // S_j
-    double red[MK_THREADS / 64];
+    u64 hkey;                                // step 5: order-preserving key of the minimum (LDS atomicMin, one per wavefront)
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
     unsigned tzero[MK_MAXN];                 // per column: which of its slots hold a zero
     unsigned tlive[MK_MAXN];                 // ... a zero in an UNCOVERED row
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 }
             }
             covC32[l5] = cC;
-            if (lane == 0) S.flag[1] = action;
+            if (lane == 0) { S.flag[1] = action; S.hkey = ~0ull; }
         }
         __syncthreads();
         const int action = S.flag[1];
@@ -279,12 +279,12 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
             unc[k] = myc[k] != 0xFFFF && !bit_of(S.covC, myc[k]);
             if (!rc && unc[k] && dv[k] < h) h = dv[k];
         }
-        h = wave_min_f64_dpp(h);
-        if (lane == 0) S.red[wave] = h;
+        {
+            const u64 hk = wave_min_u64_dpp(dkey(h));
+            if (lane == 0) atomicMin(&S.hkey, hk);
+        }
         __syncthreads();
-        h = S.red[0];
-#pragma unroll
-        for (int w = 1; w < MK_THREADS / 64; w++) { const double o = S.red[w]; if (o < h) h = o; }
+        h = dunkey(S.hkey);
         if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
         unsigned nm = 0;
 #pragma unroll
