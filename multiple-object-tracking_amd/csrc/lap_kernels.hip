@@ -193,6 +193,56 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     if (tid < nR) { const int j = S.cj[tid * LAP_K]; if (S.lock[j] == (unsigned)tid) { S.rowOfCol[j] = (short)tid; S.colOfRow[tid] = (short)j; S.mcost[tid] = S.cc[tid * LAP_K]; } }
     __syncthreads();
     int rounds = 0, free0 = -1, searches = 0, commits = 0;
+    // ---- round 0: every free row tries, all at once (thread = row), the shortest augmenting path that scans at most ONE column: its
+    // best column j0 is free (take it), or j0's owner i2 is scanned and the closest column after that -- among the row's other
+    // candidates and i2's candidates -- is free (the row takes it, or i2 moves there and the row takes j0).  Same locks as below
+    // (lowest row wins), same dual update (the scanned column's price drops by the path length).  Most free rows end here; the
+    // wave-per-search rounds below take what is left. ----
+    {
+        const int i = tid;
+        const bool isfree0 = i < nR && S.colOfRow[i] < 0;
+        int h_end = -1, h_scan = -1, h_k = 0, h_k0 = 0, h_i2 = -1, h_via = 0; double h_delta = 0.0;
+        S.lock[tid] = 0xFFFFFFFFu;
+        __syncthreads();
+        if (isfree0) {
+            double us = DBL_MAX; int k0 = 0;
+#pragma unroll
+            for (int k = 0; k < LAP_K; k++) { const int j = S.cj[i * LAP_K + k]; if (j != 0xFFFF) { const double x = S.cc[i * LAP_K + k] - S.v[j]; if (x < us) { us = x; k0 = k; } } }
+            const int j0 = S.cj[i * LAP_K + k0];
+            const int i2 = S.rowOfCol[j0];
+            if (i2 < 0) { h_end = j0; h_k = k0; }
+            else {
+                const double ui2 = S.mcost[i2] - S.v[j0];
+                double best = DBL_MAX; int bj = -1, bk = 0, via = 0;
+#pragma unroll
+                for (int k = 0; k < LAP_K; k++) {                      // the row's other candidates (earlier slots: they win ties)
+                    const int j = S.cj[i * LAP_K + k];
+                    if (j != 0xFFFF && k != k0) { const double d = (S.cc[i * LAP_K + k] - S.v[j]) - us; if (d < best) { best = d; bj = j; bk = k; via = 0; } }
+                }
+#pragma unroll
+                for (int k = 0; k < LAP_K; k++) {                      // the owner's candidates
+                    const int j = S.cj[i2 * LAP_K + k];
+                    if (j != 0xFFFF && j != j0) { const double d = (S.cc[i2 * LAP_K + k] - S.v[j]) - ui2; if (d < best) { best = d; bj = j; bk = k; via = 1; } }
+                }
+                if (bj >= 0 && S.rowOfCol[bj] < 0) { h_end = bj; h_scan = j0; h_k = bk; h_k0 = k0; h_i2 = i2; h_via = via; h_delta = best; }
+            }
+            if (h_end >= 0) { atomicMin(&S.lock[h_end], (unsigned)i); if (h_scan >= 0) atomicMin(&S.lock[h_scan], (unsigned)i); }
+        }
+        __syncthreads();
+        if (h_end >= 0 && S.lock[h_end] == (unsigned)i && (h_scan < 0 || S.lock[h_scan] == (unsigned)i)) {
+            commits++;
+            if (h_scan < 0) { S.colOfRow[i] = (short)h_end; S.rowOfCol[h_end] = (short)i; S.mcost[i] = S.cc[i * LAP_K + h_k]; }
+            else {
+                S.v[h_scan] -= h_delta;
+                if (!h_via) { S.colOfRow[i] = (short)h_end; S.rowOfCol[h_end] = (short)i; S.mcost[i] = S.cc[i * LAP_K + h_k]; }
+                else {
+                    S.colOfRow[h_i2] = (short)h_end; S.rowOfCol[h_end] = (short)h_i2; S.mcost[h_i2] = S.cc[h_i2 * LAP_K + h_k];
+                    S.colOfRow[i] = (short)h_scan; S.rowOfCol[h_scan] = (short)i; S.mcost[i] = S.cc[i * LAP_K + h_k0];
+                }
+            }
+        }
+        __syncthreads();
+    }
     const long long t_init = wall_clock64(); long long t_sr = 0, t_cm = 0;
     for (;;) {
         const long long t_r0 = wall_clock64();
@@ -305,7 +355,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
             const bool need = lane < nt && R.flag[lane] != 0;
             const bool lost = need && S.lock[R.col[lane]] != (unsigned)q;
             if (__ballot(lost)) continue;
-            commits++;
+            if (lane == 0) commits++;
             if (lane < nt && (R.flag[lane] & 1)) S.v[R.col[lane]] -= R.dec[lane];
             if (lane < R.plen) {
                 const int pi = R.prow[lane], pc = R.pcol[lane];
@@ -331,7 +381,12 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
     if (lane == 0) S.red[wave] = g;
     L.v[tid] = S.v[tid]; L.colOfRow[tid] = S.colOfRow[tid]; L.rowOfCol[tid] = S.rowOfCol[tid];
     __syncthreads();
-    if (lane == 0) S.wave_tot[wave] = commits;                         // (wave-uniform counter)
+    {   // round 0 counted per thread, the rounds per wavefront (lane 0 carries both)
+        int c0 = commits;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o);
+        if (lane == 0) S.wave_tot[wave] = c0;
+    }
     __syncthreads();
     if (tid == 0) {
         double gamma = 0.0; int ctot = 0;
