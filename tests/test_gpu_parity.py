@@ -508,3 +508,12 @@ def test_lap_fast_path_counters(mot, oracle):
     assert np.array_equal(a, ra) and cost == rc
     assert c.lap_stats()[15] == 2 and c.assoc_stats()[0] >= 0
     c.close()
+
+
+def test_assign_stress_short():
+    """tools/assign_stress.py for 20 s: random crowded scenes with duplicated centroids (tied optima), rectangular shapes, 97..1024
+    lines -- every assignment and cost bit-equal to the oracle, whichever tier decided (a 240 s run: 22,933 problems, decided by
+    certificate 11,205 / sparse emulation 11,692 / dense emulation 36)"""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(orc.ROOT, "tools", "assign_stress.py"), "20", "3"], cwd=orc.ROOT, capture_output=True, text=True, timeout=600)
+    assert "assign_stress OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
