@@ -80,7 +80,11 @@ typedef struct mot_config {
     int rank, world;   /* track sharding: this context owns KCF/Kalman state of tracks with tid % world == rank */
     void* stream;      /* hipStream_t to launch on, or NULL to create a private stream */
     int dev_rows, dev_cols; /* template size of the device-resident loop (mot_step_frame_device); 0 = 80 */
-    int reserved[4];   /* must be zero */
+    int dev_size_lo, dev_size_hi; /* device-resident loop with per-track template sizes (the reference freezes rows / cols at tracker_new
+                          from the spawning detection, kcf.cpp:148-152, td.cpp:626-627): one pool per SQUARE size in lo..hi (at most 128
+                          sizes, all on the same side of the LDS-resident / HBM-slab split); a detection of another size spawns no
+                          track (counted).  0, 0 = the single dev_rows x dev_cols template */
+    int reserved[2];   /* must be zero */
 } mot_config;
 
 typedef struct mot_ctx mot_ctx; /* opaque */

@@ -39,7 +39,7 @@ BBOX_DTYPE = np.dtype([("l", "<i4"), ("t", "<i4"), ("b", "<i4"), ("r", "<i4"), (
 class MotConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("tracker_kind", C.c_int), ("fhog_mode", C.c_int), ("fft_mode", C.c_int),
                 ("max_tracks", C.c_int), ("max_dets", C.c_int), ("rank", C.c_int), ("world", C.c_int),
-                ("stream", C.c_void_p), ("dev_rows", C.c_int), ("dev_cols", C.c_int), ("reserved", C.c_int * 4)]
+                ("stream", C.c_void_p), ("dev_rows", C.c_int), ("dev_cols", C.c_int), ("dev_size_lo", C.c_int), ("dev_size_hi", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class MotError(RuntimeError):
@@ -93,7 +93,7 @@ class MotContext:
     """One tracker context = one GPU (one process per GPU in multi-GPU runs)."""
 
     def __init__(self, tracker_kind=TRACKER_KCF, device=0, max_tracks=256, max_dets=128, fhog_mode=FHOG_INTEL_APPROX,
-                 fft_mode=FFT_AUTO, rank=0, world=1, stream=None, dev_size=80):
+                 fft_mode=FFT_AUTO, rank=0, world=1, stream=None, dev_size=80, dev_sizes=None):
         self.lib = load_library()
         cfg = MotConfig()
         self.lib.mot_config_default(C.byref(cfg))
@@ -101,6 +101,8 @@ class MotContext:
         cfg.fhog_mode, cfg.fft_mode, cfg.rank, cfg.world = fhog_mode, fft_mode, rank, world
         cfg.stream = stream
         cfg.dev_rows = cfg.dev_cols = dev_size
+        if dev_sizes:                                                  # (lo, hi): one pool per square template size, per-track sizes in the device loop
+            cfg.dev_size_lo, cfg.dev_size_hi = int(dev_sizes[0]), int(dev_sizes[1])
         self.cfg = cfg
         self._h = C.c_void_p()
         self._chk(self.lib.mot_ctx_create(C.byref(cfg), C.byref(self._h)))

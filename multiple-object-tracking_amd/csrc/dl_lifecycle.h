@@ -3,7 +3,8 @@
 #pragma once
 #include "mot_dev.h"
 
-#define DL_LIFE_SCRATCH_INTS (2048 + 16 + 4)
+#define DL_MAX_CLASSES 128
+#define DL_LIFE_SCRATCH_INTS (2048 + 16 + 4 + DL_MAX_CLASSES)
 
 struct DLState {
     int* nlive; unsigned* next_tid; int* nfree; int* free_slots;
@@ -17,6 +18,14 @@ struct DLState {
     int* err;                     // [8]: spawns dropped for template-size mismatch, capacity drops, pool exhausted, all-gather segment overflow,
                                   //      [4] sticky: a Munkres helper hand-off timed out (frame dropped; read-backs return MOT_ERR_DEVICE)
     int cap, max_dets, rank, world, spr, rows, cols, kind;
+    // size classes (KCF): per-track template sizes as the reference has them (rows / cols frozen at tracker_new from the spawning
+    // detection, kcf.cpp:148-152, td.cpp:626-627): square templates cls_lo .. cls_lo + ncls - 1 px, one pool per class.  ncls <= 1:
+    // the single rows x cols template.
+    int ncls, cls_lo;
+    int* cls;                     // [cap] class of every live track
+    int* loc_cls; int* upd_cls;   // class of every predict / update item
+    int* nfree_c; int* free_c;    // [ncls] fill of, [ncls][cap] the per-class free slot stacks
+    const KcfPool* pools;         // [ncls] device table of pool descriptors
 };
 
 __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* wave_tot, int& total)
@@ -47,6 +56,7 @@ __device__ inline void dl_build_lists(const DLState& S, int n, int* wave_tot)
             if (pos >= S.spr) atomicAdd(&S.err[3], 1);                 // cannot happen: a segment holds cap boxes (mot_ctx.hip)
             else if (rk == S.rank) {
                 S.loc_slots[pos] = S.slot[t];
+                if (S.ncls > 1) S.loc_cls[pos] = S.cls[t];
                 if (S.kind == MOT_TRACKER_KALMAN) S.gather[(size_t)S.rank * S.spr + pos] = S.bbox[t];   // predict is in/out (kalman.cpp:112-115)
             }
         }
@@ -64,9 +74,12 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     int* at = scratch; int* ad = scratch + 1024;
     int* wave_tot = scratch + 2048;
     int* cnt = scratch + 2048 + 16;   // [0] update list, [1] free stack top
+    int* cntc = scratch + 2048 + 16 + 4;  // size classes: per-class free stack tops
     const int t = threadIdx.x;
     const int nT = *S.nlive;
+    const bool multi = S.kind == MOT_TRACKER_KCF && S.ncls > 1;
     if (t == 0) { cnt[0] = 0; cnt[1] = *S.nfree; }
+    if (multi && t < S.ncls) cntc[t] = S.nfree_c[t];
     at[t] = -1; ad[t] = -1;
     __syncthreads();
     // td.cpp:472-502 -- scatter of the assignment vector (rows = the smaller side, td.cpp:462-469)
@@ -76,9 +89,10 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     }
     __syncthreads();
     // td.cpp:512-582 (counters, update box) and :585-609 (lost rule)
-    int slot = -1, age = 0, vis = 0, inv = 0; unsigned tid = 0; bbox_t bb{}; bool keep = false, mine = false;
+    int slot = -1, age = 0, vis = 0, inv = 0, tcls = 0; unsigned tid = 0; bbox_t bb{}; bool keep = false, mine = false;
     if (t < nT) {
         slot = S.slot[t]; tid = S.tid[t]; age = S.age[t]; vis = S.vis[t]; inv = S.inv[t];
+        if (multi) tcls = S.cls[t];
         bb = trk_pred[t];
         const int j = at[t];
         if (j >= 0) { bb = dets[j]; vis++; age++; inv = 0; }
@@ -87,20 +101,23 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
         keep = !lost;
         mine = ((int)(tid % (unsigned)S.world) == S.rank);
         if (mine) {
-            if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; }
+            if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; if (multi) S.upd_cls[q] = tcls; }
+            else if (multi) { const int q = atomicAdd(&cntc[tcls], 1); S.free_c[(size_t)tcls * S.cap + q] = slot; }
             else { const int q = atomicAdd(&cnt[1], 1); S.free_slots[q] = slot; }   // tracker_delete (td.cpp:599)
         }
     }
     int n_keep;
     const int newpos = block_excl_scan_flag(keep, wave_tot, n_keep);
     __syncthreads();
-    if (keep) { S.slot[newpos] = slot; S.tid[newpos] = tid; S.age[newpos] = age; S.vis[newpos] = vis; S.inv[newpos] = inv; S.bbox[newpos] = bb; }
+    if (keep) { S.slot[newpos] = slot; S.tid[newpos] = tid; S.age[newpos] = age; S.vis[newpos] = vis; S.inv[newpos] = inv; S.bbox[newpos] = bb; if (multi) S.cls[newpos] = tcls; }
     // td.cpp:612-644 -- spawn a tracker per unassigned detection, in detection order
-    bool spawn = false; bbox_t db{};
+    bool spawn = false; bbox_t db{}; int scls = 0;
     if (t < nD && ad[t] < 0) {
         db = dets[t];
         spawn = true;
-        if (S.kind == MOT_TRACKER_KCF && ((db.b - db.t + 1) != S.rows || (db.r - db.l + 1) != S.cols)) { spawn = false; atomicAdd(&S.err[0], 1); }
+        const int drows = db.b - db.t + 1, dcols = db.r - db.l + 1;
+        if (multi) { scls = drows - S.cls_lo; if (drows != dcols || scls < 0 || scls >= S.ncls) { spawn = false; atomicAdd(&S.err[0], 1); } }   // no class for this template size
+        else if (S.kind == MOT_TRACKER_KCF && (drows != S.rows || dcols != S.cols)) { spawn = false; atomicAdd(&S.err[0], 1); }
     }
     int n_spawn;
     const int spos = block_excl_scan_flag(spawn, wave_tot, n_spawn);
@@ -113,14 +130,17 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
             const bool m2 = ((int)(ntid % (unsigned)S.world) == S.rank);
             int ns = -1;
             if (m2) {
-                const int top = atomicSub(&cnt[1], 1) - 1;
-                if (top >= 0) ns = S.free_slots[top]; else atomicAdd(&S.err[2], 1);
+                if (multi) { const int top = atomicSub(&cntc[scls], 1) - 1; if (top >= 0) ns = S.free_c[(size_t)scls * S.cap + top]; else atomicAdd(&S.err[2], 1); }
+                else { const int top = atomicSub(&cnt[1], 1) - 1; if (top >= 0) ns = S.free_slots[top]; else atomicAdd(&S.err[2], 1); }
             }
             S.slot[idx] = ns; S.tid[idx] = ntid; S.age[idx] = 0; S.vis[idx] = 0; S.inv[idx] = 0; S.bbox[idx] = db;
+            if (multi) S.cls[idx] = scls;
             if (ns >= 0) {
                 if (S.kind == MOT_TRACKER_KCF) {
-                    kp.pos[ns] = db; kp.scale[ns] = make_float2(1.f, 1.f); kp.first_update[ns] = 1;     // kcf.cpp:200-210
+                    const KcfPool& sp = multi ? S.pools[scls] : kp;
+                    sp.pos[ns] = db; sp.scale[ns] = make_float2(1.f, 1.f); sp.first_update[ns] = 1;     // kcf.cpp:200-210
                     const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = ns; S.upd_boxes[q] = db; S.upd_det[q] = t;   // first update, td.cpp:631-640
+                    if (multi) S.upd_cls[q] = scls;
                 } else {
                     const double v[6] = { (double)db.l, (double)db.t, (double)db.r, (double)db.b, 0.0, 0.0 }; // kalman.cpp:152-157
                     for (int q = 0; q < 6; q++) kal.x[(size_t)ns * 6 + q] = v[q];
@@ -135,6 +155,7 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
         *S.nlive = n_new; *S.next_tid = tid0 + (unsigned)(n_new - n_keep);
         *S.upd_count = cnt[0]; *S.nfree = max(cnt[1], 0);
     }
+    if (multi && t < S.ncls) S.nfree_c[t] = max(cntc[t], 0);
     __threadfence_block();
     __syncthreads();
     // lists for the next frame's predict

@@ -756,13 +756,9 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+__device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int item = blockIdx.x;
-    if (item >= n) return;
-    if (l.count && item >= *l.count) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;      // HBM-slab templates: region C + staging in LDS
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -847,13 +843,31 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_ker
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
+    kcf_predict_body<kLds>(p, l, item, smem);
+}
+// size classes (device loop with per-track template sizes, kcf.cpp:148-152): the workgroup's pool descriptor comes from a device
+// table, indexed by the class of its track
+template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    const KcfPool p = l.pools[l.cls[item]];
+    kcf_predict_body<kLds>(p, l, item, smem);
+}
+
+template <bool kLds>
+__device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
+{
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -956,12 +970,32 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
 }
 
 template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    kcf_update_body<kLds>(p, l, item, smem);
+}
+template <bool kLds>
+__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    const KcfPool p = l.pools[l.cls[item]];
+    kcf_update_body<kLds>(p, l, item, smem);
+}
+
+template <bool kLds>
 __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     const Regions r = carve(p, base);
     bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
     features_prepare<false>(p, l, item, box, r, threadIdx.x, blockDim.x);
@@ -976,7 +1010,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_crop_kernel(const KcfPool
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
-    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * p.lds_floats;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     const Regions r = carve(p, base);
     const int tid = threadIdx.x, nt = blockDim.x;
     phase_crop(p, l.frame, nullptr, l.boxes_in[item], r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
@@ -1047,6 +1081,12 @@ static hipError_t set_lds_attr(K kern, size_t bytes)
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
+    if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
+        const size_t ldsm = l.lds_bytes;
+        if (p.use_lds) { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<true>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
+        return hipGetLastError();
+    }
     const size_t lds = kcf_lds_bytes(p);
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_predict_kernel<true>, lds); if (e != hipSuccess) return e;
@@ -1061,6 +1101,12 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
 hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu)
 {
     if (n <= 0) return hipSuccess;
+    if (l.pools) {
+        const size_t ldsm = l.lds_bytes;
+        if (p.use_lds) { hipError_t e = set_lds_attr(kcf_update_multi_kernel<true>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_update_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
+        return hipGetLastError();
+    }
     size_t lds = kcf_lds_bytes(p);
     // exclusive_cu: ask for more than half of a CU's LDS so that no second workgroup (of this or of a concurrently running
     // KCF kernel) is placed on the same CU

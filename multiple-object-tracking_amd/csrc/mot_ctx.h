@@ -74,6 +74,6 @@ struct mot_ctx {
 
 namespace mot_impl {
 int ensure_device(mot_ctx* c);
-int get_pool(mot_ctx* c, int rows, int cols, int* out_idx);
+int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch = false);   // shared_scratch: no HBM slab of its own (the caller points gscratch at a shared one)
 int devloop_check(mot_ctx* c);   // mot_devloop.hip
 }

@@ -60,7 +60,7 @@ void make_twiddles(std::vector<float2>& t, int n)
 } // namespace
 
 namespace mot_impl {
-int get_pool(mot_ctx* c, int rows, int cols, int* out_idx)
+int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
 {
     for (size_t i = 0; i < c->pools.size(); i++)
         if (c->pools[i]->dev.rows == rows && c->pools[i]->dev.cols == cols) { *out_idx = (int)i; return MOT_OK; }
@@ -115,7 +115,7 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx)
     HIPCHK(hipMemcpy(ph->yf_re.p, yfre.data(), yfre.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ph->tw_r.p, twr.data(), twr.size() * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ph->tw_c.p, twc.data(), twc.size() * sizeof(float2), hipMemcpyHostToDevice));
-    if (!p.use_lds) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
+    if (!p.use_lds && !shared_scratch) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
     p.xm = ph->xm.p; p.alpha = ph->alpha.p; p.pos = ph->pos.p; p.scale = ph->scale.p; p.first_update = ph->first.p; p.response = ph->response.p;
     p.cos_win = ph->cos_win.p; p.yf_re = ph->yf_re.p; p.tw_r = ph->tw_r.p; p.tw_c = ph->tw_c.p; p.sse_tab = c->sse_tab.p; p.gscratch = ph->gscratch.p;
     c->pools.push_back(std::move(ph));
@@ -303,6 +303,10 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     if (!cfg || !out) return fail(MOT_ERR_ARG, "null argument");
     if (cfg->max_tracks < 1 || cfg->max_tracks > 1024 || cfg->max_dets < 1 || cfg->max_dets > 1024) return fail(MOT_ERR_ARG, "max_tracks / max_dets must be in 1..1024");
     if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(MOT_ERR_ARG, "bad rank/world");
+    if (cfg->dev_size_lo || cfg->dev_size_hi) {
+        if (cfg->dev_size_lo < 8 || cfg->dev_size_hi < cfg->dev_size_lo || cfg->dev_size_hi > MOT_FRAME_H || cfg->dev_size_hi - cfg->dev_size_lo + 1 > 128)
+            return fail(MOT_ERR_ARG, "dev_size_lo..dev_size_hi must be 8 <= lo <= hi <= 720 with at most 128 sizes");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MOT_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(MOT_ERR_ARG, "device %d out of range (%d devices)", cfg->device, ndev);

@@ -72,6 +72,11 @@ struct KcfLaunch {
     const float2* det_spec;   // blend launch: spectra written by a feature-only launch ...
     const int* det_index;     // ... and [n] the detection whose spectrum item uses (-1: compute from boxes_in[item] as usual)
     int slab_base;            // HBM-slab templates: item i works in slab (slab_base + i) -- a launch that may run beside another KCF launch gets slabs of its own
+    // size classes (device loop with per-track template sizes): item i uses pools[cls[i]]; one shared scratch with a common stride
+    const KcfPool* pools;     // device table of pool descriptors, or null (single pool passed by value)
+    const int* cls;           // [n] class of every item
+    int slab_stride;          // floats per slab of the shared HBM scratch (0: the pool's own lds_floats)
+    unsigned lds_bytes;       // dynamic LDS of the launch = the largest need of any class
 };
 
 struct KalmanPool {

@@ -38,6 +38,8 @@ struct DevLoop {
     DLState S{};
     int pool = -1;
     DevBuf<int> ints; DevBuf<bbox_t> boxes; DevBuf<unsigned> tids;
+    // size classes: pool index of every class, device table of their descriptors, one shared HBM scratch, LDS need of a launch
+    std::vector<int> cls_pool; DevBuf<KcfPool> pools_dev; DevBuf<float> shared_scratch; int slab_stride = 0; unsigned lds_bytes = 0;
     bool begun = false; const void* frame = nullptr;
     hipEvent_t ev[8]{}; bool ev_ok = false;
     // split update (KCF): the spectra of all detection boxes are computed on a second, low-priority stream while the
@@ -71,9 +73,27 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     const int cap = c->cfg.max_tracks, md = c->cfg.max_dets;
     S.cap = cap; S.max_dets = md; S.rank = c->cfg.rank; S.world = c->cfg.world; S.spr = c->slots_per_rank; S.kind = c->cfg.tracker_kind;
     S.rows = c->cfg.dev_rows > 0 ? c->cfg.dev_rows : 80; S.cols = c->cfg.dev_cols > 0 ? c->cfg.dev_cols : 80;
-    if (S.kind == MOT_TRACKER_KCF) { int rc = get_pool(c, S.rows, S.cols, &d->pool); if (rc) return rc; }
+    S.ncls = 1; S.cls_lo = S.rows;
+    if (S.kind == MOT_TRACKER_KCF && c->cfg.dev_size_lo > 0) {
+        // per-track template sizes: one pool per square size; all descriptors in a device table, one HBM scratch for all
+        S.cls_lo = c->cfg.dev_size_lo; S.ncls = c->cfg.dev_size_hi - c->cfg.dev_size_lo + 1;
+        std::vector<KcfPool> tab((size_t)S.ncls);
+        size_t maxf = 0; unsigned maxlds = 0; int use0 = -1;
+        for (int k = 0; k < S.ncls; k++) {
+            int pi; int rc = get_pool(c, S.cls_lo + k, S.cls_lo + k, &pi, true); if (rc) return rc;
+            d->cls_pool.push_back(pi);
+            const KcfPool& kp = c->pools[pi]->dev;
+            if (use0 < 0) use0 = kp.use_lds; else if (use0 != kp.use_lds) return fail(MOT_ERR_ARG, "template sizes %d..%d straddle the LDS-resident / HBM-slab split", c->cfg.dev_size_lo, c->cfg.dev_size_hi);
+            maxf = std::max(maxf, (size_t)kp.lds_floats); maxlds = std::max(maxlds, (unsigned)kcf_lds_bytes(kp));
+        }
+        if (!use0) { HIPCHK(d->shared_scratch.alloc((size_t)(cap + md) * maxf)); for (int pi : d->cls_pool) c->pools[pi]->dev.gscratch = d->shared_scratch.p; }
+        for (int k = 0; k < S.ncls; k++) tab[k] = c->pools[d->cls_pool[k]]->dev;
+        HIPCHK(d->pools_dev.alloc((size_t)S.ncls)); HIPCHK(hipMemcpy(d->pools_dev.p, tab.data(), sizeof(KcfPool) * S.ncls, hipMemcpyHostToDevice));
+        S.pools = d->pools_dev.p; d->slab_stride = (int)maxf; d->lds_bytes = maxlds; d->pool = d->cls_pool[0];
+    } else if (S.kind == MOT_TRACKER_KCF) { int rc = get_pool(c, S.rows, S.cols, &d->pool); if (rc) return rc; }
+    const bool multi = S.ncls > 1;
     // one int arena: nlive, next_tid(as tids), nfree, loc_count, upd_count, err[4], then arrays
-    const size_t nints = 16 + (size_t)cap * 8 + 2 * (size_t)(cap + md) + 64;
+    const size_t nints = 16 + (size_t)cap * 8 + 2 * (size_t)(cap + md) + 64 + (multi ? (size_t)cap * 2 + (cap + md) + S.ncls + (size_t)S.ncls * cap : 0);
     HIPCHK(d->ints.alloc(nints)); HIPCHK(hipMemsetAsync(d->ints.p, 0, nints * sizeof(int), c->stream));
     HIPCHK(d->tids.alloc((size_t)cap + 4)); HIPCHK(hipMemsetAsync(d->tids.p, 0, (cap + 4) * sizeof(unsigned), c->stream));
     HIPCHK(d->boxes.alloc((size_t)cap * 2 + cap + md + 8)); HIPCHK(hipMemsetAsync(d->boxes.p, 0, d->boxes.n * sizeof(bbox_t), c->stream));
@@ -81,6 +101,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     S.nlive = ip; S.nfree = ip + 1; S.loc_count = ip + 2; S.upd_count = ip + 3; S.err = ip + 4; ip += 16;
     S.free_slots = ip; ip += cap; S.slot = ip; ip += cap; S.age = ip; ip += cap; S.vis = ip; ip += cap; S.inv = ip; ip += cap;
     S.rankpos = ip; ip += cap; S.loc_slots = ip; ip += cap; S.upd_slots = ip; ip += cap + md; S.upd_det = ip; ip += cap + md;
+    if (multi) { S.cls = ip; ip += cap; S.loc_cls = ip; ip += cap; S.upd_cls = ip; ip += cap + md; S.nfree_c = ip; ip += S.ncls; S.free_c = ip; ip += (size_t)S.ncls * cap; }
     S.next_tid = d->tids.p; S.tid = d->tids.p + 4;
     S.bbox = d->boxes.p; S.pred = S.bbox + cap; S.upd_boxes = S.pred + cap;
     S.gather = c->d_gather.p;
@@ -89,11 +110,20 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     for (int i = 0; i < cap; i++) fs[i] = cap - 1 - i;
     HIPCHK(hipMemcpyAsync(S.free_slots, fs.data(), sizeof(int) * cap, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(S.nfree, &cap, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    std::vector<int> nfc;
+    if (multi) {
+        nfc.assign((size_t)S.ncls, cap);
+        HIPCHK(hipMemcpyAsync(S.nfree_c, nfc.data(), sizeof(int) * S.ncls, hipMemcpyHostToDevice, c->stream));
+        for (int k = 0; k < S.ncls; k++) HIPCHK(hipMemcpyAsync(S.free_c + (size_t)k * cap, fs.data(), sizeof(int) * cap, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (S.kind == MOT_TRACKER_KCF) {
         c->pools[d->pool]->free_slots.clear();                           // the device owns the pool now
+        for (int pi : d->cls_pool) c->pools[pi]->free_slots.clear();
         const char* ev = getenv("MOT_SPLIT_UPDATE");                     // default on; 0 keeps the fused update kernel
-        if (!ev || atoi(ev) != 0) {
+        // (size classes: the spectrum a detection is adopted with depends on the adopting track's template size, which is only
+        // known after the assignment -- the fused update kernel is used)
+        if ((!ev || atoi(ev) != 0) && !multi) {
             const KcfPool& kp = c->pools[d->pool]->dev;
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // lo = numerically largest = lowest priority
@@ -152,6 +182,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     }
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
+        if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
         HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
     } else HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
@@ -187,6 +218,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const int upd_max = S.spr + nD;
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
+        if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
         if (split) { HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = d->det_spec.p; l.det_index = S.upd_det; }
         HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
         if (split) HIPCHK(hipEventRecord(d->ev_upd, c->stream));

@@ -92,6 +92,30 @@ def test_device_loop_multiscale_150(mot, oracle):
     m.close(); c.close()
 
 
+@pytest.mark.parametrize("n,lo,hi,miss,fp", [(200, 72, 88, 3, 2), (96, 140, 156, 0, 0)])
+def test_device_loop_per_track_template_sizes(mot, oracle, n, lo, hi, miss, fp):
+    """per-track template sizes in the device-resident loop: every tracker freezes rows / cols at spawn from the spawning detection
+    (kcf.cpp:148-152, td.cpp:626-627), and every frame's detections have a random size in lo..hi, so tracks of 17 different
+    template sizes live side by side and each update resizes a lo..hi crop to its own track's template (td.cpp:528-537).
+    One pool per size, predict / update kernels pick the descriptor per item.  72..88: LDS-resident kernels; 140..156: HBM slab."""
+    from multiple_object_tracking_amd import synth
+    nframes = 6
+    scene = synth.Scene(n, (lo + hi) // 2, stream_id=45, det_sizes=(lo, hi), miss_pct=miss, fp_pct=fp)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d[:256] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    c = mot.MotContext(max_tracks=256, max_dets=256, dev_sizes=(lo, hi))
+    m = orc.OracleMot(oracle, 0, 0, 256)
+    for f in range(nframes):
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        boxes, tids, ages = c.live_tracks()
+        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    assert len(tids) >= n // 2
+    m.close(); c.close()
+
+
 def test_device_loop_eight_ranks_on_one_gpu(mot, oracle):
     """BASELINE configs[3] shape: 1024 tracks sharded tid % 8 over eight contexts (here on one GPU, the all-gather emulated
     with device copies) must equal the unsharded oracle"""
