@@ -44,10 +44,10 @@ def alg_bytes(size):
             "blend": 3 * 31 * nb * 8 + 3 * nb * 4 + 24}
 
 
-def gen_stream(n_tracks, size, n_frames, stream_id=0, det_sizes=None):
+def gen_stream(n_tracks, size, n_frames, stream_id=0, det_sizes=None, first_frame_exact=True):
     import mot_amd
     from multiple_object_tracking_amd import synth
-    scene = synth.Scene(n_tracks, size, stream_id=stream_id, det_sizes=det_sizes, first_frame_exact=det_sizes is not None)
+    scene = synth.Scene(n_tracks, size, stream_id=stream_id, det_sizes=det_sizes, first_frame_exact=det_sizes is not None and first_frame_exact)
     frames = np.empty((n_frames, 720, 1280, 3), np.uint8)
     dets = np.zeros((n_frames, n_tracks), mot_amd.BBOX_DTYPE)
     for f, (frame, d) in enumerate(scene.frames(n_frames)):
@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--det-sizes", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="multi-scale detections (BASELINE configs[4]): tracks are spawned with the --size template from frame 0, "
                          "from frame 1 on every detection is a random square of LO..HI px that the tracker resizes to its template")
+    ap.add_argument("--per-track-sizes", action="store_true",
+                    help="with --det-sizes LO HI: every track keeps the template size of the detection that spawned it (the reference's "
+                         "behaviour, kcf.cpp:148-152) -- one pool per size LO..HI in the device-resident loop; informative, not the headline config")
     ap.add_argument("--mode", choices=["sharded", "streams"], default="sharded",
                     help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded tid %% N, one all-gather per frame (BASELINE configs[3], strong scaling); "
                          "streams = N independent camera streams of --tracks tracks each, one per GPU, no collective (BASELINE configs[4], weak scaling)")
@@ -181,7 +184,9 @@ def main():
     mot_rank, mot_world = (0, 1) if streams else (rank, world)
     n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
     n_frames = 1 + args.warmup + args.steps + args.steady + n_prof
-    frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0, det_sizes=tuple(args.det_sizes) if args.det_sizes else None)
+    frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0, det_sizes=tuple(args.det_sizes) if args.det_sizes else None,
+                                  first_frame_exact=not args.per_track_sizes)
+    dev_sizes = tuple(args.det_sizes) if (args.per_track_sizes and args.det_sizes) else None
     frames_d = torch.from_numpy(frames_h).cuda()
     dets_d = torch.from_numpy(dets_h.view(np.uint8).reshape(n_frames, -1)).cuda()
     frame_bytes = 720 * 1280 * 3
@@ -189,7 +194,7 @@ def main():
 
     stream = torch.cuda.Stream()
     ctx = mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(n_tracks, 1), max_dets=max(n_tracks, 1),
-                             rank=mot_rank, world=mot_world, stream=stream.cuda_stream, dev_size=size)
+                             rank=mot_rank, world=mot_world, stream=stream.cuda_stream, dev_size=size, dev_sizes=dev_sizes)
 
     gathered = None
     extra = []                                                       # --streams-per-gpu: more independent contexts on streams of their own
@@ -197,7 +202,7 @@ def main():
         for _ in range(args.streams_per_gpu - 1):
             st = torch.cuda.Stream()
             extra.append((st, mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(n_tracks, 1),
-                                                 max_dets=max(n_tracks, 1), stream=st.cuda_stream, dev_size=size)))
+                                                 max_dets=max(n_tracks, 1), stream=st.cuda_stream, dev_size=size, dev_sizes=dev_sizes)))
 
     def step(f):
         fp = frames_d.data_ptr() + f * frame_bytes
@@ -303,6 +308,7 @@ def main():
                        **({"streams_per_gpu": args.streams_per_gpu, "note": "K independent contexts on K HIP streams of one GPU; value = all streams"} if extra else {}),
                        "tracks_total": n_tracks * (world if streams else 1) * (1 + len(extra)), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
                        "live_tracks_end": n_live, "patch": size, **({"det_sizes": args.det_sizes} if args.det_sizes else {}),
+                       **({"per_track_template_sizes": True} if dev_sizes else {}),
                        "parallelism": (f"{world} replicas, no collective" if streams else f"track-shard x{world}, 1 all-gather/frame") if world > 1 else "single GPU"},
         }
         ab = alg_bytes(size)
