@@ -70,7 +70,8 @@ struct Ctx {
 // Phase 0: crop + gray + (bilinear resize) -> P[c*ldp + r]
 // ---------------------------------------------------------------------------
 __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, const float* __restrict__ patch,
-                           bbox_t box, float* __restrict__ P, uint8_t* __restrict__ raw, int tid, int nt, int raw_cap = 1 << 30)
+                           bbox_t box, float* __restrict__ P, uint8_t* __restrict__ raw, int tid, int nt, int raw_cap = 1 << 30,
+                           float* __restrict__ gbuf = nullptr, int gcap = 0)
 {
     const int rows = p.rows, cols = p.cols, npx = rows * cols;
     if (patch) {
@@ -126,6 +127,32 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
     const float ys = ((float)hs) / ((float)rows);
     FastDiv drs; // flat source index -> (col, row) of the gray scratch
     const uint32_t urs = (uint32_t)max(rows_s, 1);
+    // Two steps like the reference when the gray image of the source box fits the scratch `gbuf` (LDS): every source pixel
+    // is converted ONCE (coalesced BGR reads along the frame rows), the four taps of an output pixel are LDS reads.
+    // Element s of the scratch is the pixel (top + s % rows_s, left + s / rows_s), s < hs * ws.
+    const int nsrc = hs * ws;
+    if (gbuf && hs > 0 && ws > 0 && nsrc <= gcap && rows_s == hs) {
+        const uint32_t uws = (uint32_t)ws;
+        for (int i = tid; i < nsrc; i += nt) {
+            const uint32_t r = (uint32_t)i / uws, c = (uint32_t)i - r * uws;       // frame-row major: consecutive threads, consecutive pixels
+            gbuf[c * urs + r] = gray_of(frame, top + (int)r, left + (int)c);
+        }
+        __syncthreads();
+        for (int d = tid; d < npx; d += nt) {
+            uint32_t y, x; p.d_cols.divmod((uint32_t)d, y, x);
+            float sy = (float)y * ys; int y0 = (int)sy; float fracy = sy - (float)y0, ifracy = 1.0f - fracy;
+            int y1 = y0 + 1; if (y1 >= hs) y1 = y0;
+            float sx = (float)x * xs; int x0 = (int)sx; float fracx = sx - (float)x0, ifracx = 1.0f - fracx;
+            int x1 = x0 + 1; if (x1 >= ws) x1 = x0;
+            const float c1 = gbuf[y0 * ws + x0], c2 = gbuf[y0 * ws + x1], c3 = gbuf[y1 * ws + x0], c4 = gbuf[y1 * ws + x1];
+            float l0 = ifracx * c1 + fracx * c2;                           // drawlib.c:625-627
+            float l1 = ifracx * c3 + fracx * c4;
+            float v = ifracy * l0 + fracy * l1;
+            uint32_t c, r; p.d_rows.divmod((uint32_t)d, c, r);             // KCF reads the flat array column-major
+            P[c * p.ldp + r] = v;
+        }
+        return;
+    }
     for (int d = tid; d < npx; d += nt) {
         uint32_t y, x; p.d_cols.divmod((uint32_t)d, y, x);             // dst flat = y*width + x
         float sy = (float)y * ys; int y0 = (int)sy; float fracy = sy - (float)y0, ifracy = 1.0f - fracy;
@@ -504,6 +531,168 @@ __device__ void dft_cols_reg(const KcfPool& p, const float2* __restrict__ in, fl
     }
 }
 
+// ---- DFTs as f32 matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 multiply-adds, k-ordered) ----
+// A line transform of prime length (37 cells at 148 px) has no butterfly; as a product with the constant twiddle matrix
+// it runs at the MFMA rate instead of one multiply-add and one twiddle fetch per VALU slot.  The constant operand comes
+// from the pool's fragment-ordered tables and stays in registers for the whole call.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float* smem_base() { extern __shared__ __attribute__((aligned(16))) float smem_b[]; return smem_b; }
+
+// rows: sF[line*ldf + y] (real, y < hb) -> sT[line*ldf + n], n = 2k + (re, im), k < fh
+__device__ void dft_rows_mfma(const KcfPool& p, const float* __restrict__ sF, float* __restrict__ sT, int nlines, int tid, int nt_)
+{
+    const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6;
+    const int hb = p.hb, ldf = 2 * p.fh, ks = (hb + 3) >> 2, ntl = (ldf + 15) >> 4;
+    const int mtiles = (nlines + 15) >> 4, kq = lane >> 4;
+    for (int t = 0; t < ntl; t++) {                                    // 16 output floats (8 bins) per pass; its twiddle fragments stay in registers
+        const float* tb = p.mf_rows + t * 64 + lane;
+        asm volatile("" : "+v"(tb));                                   // keeps the fragment loads of all passes from being hoisted (and spilled) together
+        float bw[MOT_MF_KS_R];
+#pragma unroll
+        for (int s = 0; s < MOT_MF_KS_R; s++) bw[s] = (s < ks) ? tb[s * 3 * 64] : 0.f;
+        for (int mt = wave; mt < mtiles; mt += nw) {
+            const int line = min(mt * 16 + (lane & 15), nlines - 1);
+            const float* in = sF + line * ldf;
+            f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < MOT_MF_KS_R; s++) {
+                if (s < ks) {
+                    const int k = 4 * s + kq;
+                    const float a = (k < hb) ? in[min(k, hb - 1)] : 0.f;   // the pad floats of a line are not data
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s], acc, 0, 0, 0);
+                }
+            }
+            const int n = t * 16 + (lane & 15), l0 = mt * 16 + kq * 4;
+            if (n < ldf) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (l0 + r < nlines) sT[(l0 + r) * ldf + n] = acc[r];
+            }
+        }
+    }
+}
+
+// columns, forward: sT[(ch*wb + x)*ldf + n] -> out[(ch*wb + x')*ldf + n]:
+//   out_re = sum_x cos * T_re + sin * T_im,  out_im = sum_x cos * T_im - sin * T_re   (W = cos - i sin)
+// as [cos | sin] (wb x 2wb) times [T ; T'] (2wb x ldf), T'[x][n] = n even ? T[x][n + 1] : -T[x][n - 1]
+__device__ void dft_cols_mfma(const KcfPool& p, const float* __restrict__ sT, float* __restrict__ out, int g, int tid, int nt_)
+{
+    const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6;
+    const int wb = p.wb, ldf = 2 * p.fh, ks = (2 * wb + 3) >> 2, ntl = (ldf + 15) >> 4, mtl = (wb + 15) >> 4;
+    const int kq = lane >> 4, units = g * ntl;
+    for (int mt = 0; mt < mtl; mt++) {                                 // 16 output positions x' per pass; its twiddle fragments stay in registers
+        const float* ta = p.mf_cols + mt * MOT_MF_KS_C * 64 + lane;
+        asm volatile("" : "+v"(ta));                                   // see dft_rows_mfma
+        float aw[MOT_MF_KS_C];
+#pragma unroll
+        for (int s = 0; s < MOT_MF_KS_C; s++) aw[s] = (s < ks) ? ta[s * 64] : 0.f;
+        for (int u = wave; u < units; u += nw) {
+            const int ch = u / ntl, nt = u - ch * ntl;
+            const int n = nt * 16 + (lane & 15), nc = min(n, ldf - 1);
+            const float* T = sT + ch * wb * ldf;
+            f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s = 0; s < MOT_MF_KS_C; s++) {
+                if (s < ks) {
+                    const int k = 4 * s + kq;
+                    const bool second = k >= wb;
+                    const int x = min(second ? k - wb : k, wb - 1);
+                    float v = T[x * ldf + (second ? (nc ^ 1) : nc)];
+                    v = (second && (n & 1)) ? -v : v;
+                    v = (k < 2 * wb && n < ldf) ? v : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], v, acc, 0, 0, 0);
+                }
+            }
+            if (n < ldf) {
+                float* o = out + (size_t)ch * wb * ldf + n;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int xp = mt * 16 + kq * 4 + r;
+                    if (xp < wb) o[xp * ldf] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+// Both passes in one: the row spectra of a channel never leave the accumulators.  A 16 x 16 result tile of the row product
+// holds T[x = 16xt + 4(lane/16) + r][n = lane%16] in register r -- exactly the B-operand shape of a k-step of the column
+// product if that step's k runs over x = 16xt + 4q + r, q = 0..3; the order of the k's of a sum is free, so the column
+// product takes the tiles as they are and the CONSTANT operand (pool table mf_cols2) is stored in that k order.  T' (the
+// re/im swap of the sine half) is the neighbouring lane's value: one DPP move.
+//   F[(c*wb + x)*ldf + y] (LDS) -> out[(c*wb + x')*ldf + n]
+__device__ __attribute__((noinline)) void dft2_mfma(const KcfPool& p, int f_off, float* __restrict__ out, int nch, int tid, int nt_)
+{
+    extern __shared__ __attribute__((aligned(16))) float dft2_smem[];
+    const float* __restrict__ F = dft2_smem + f_off;                   // LDS (kept out of line: its 72 constant fragments get a register allocation of their own)
+    const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6, q = lane >> 4, m = lane & 15;
+    const int hb = p.hb, wb = p.wb, ldf = 2 * p.fh, ksr = (hb + 3) >> 2, ntl = (ldf + 15) >> 4, xtl = (wb + 15) >> 4;
+    for (int t = 0; t < ntl; t++) {                                    // 16 output floats (8 bins) per pass
+        const float* tb = p.mf_rows + t * 64 + lane;
+        const float* tc = p.mf_cols2 + lane;
+        asm volatile("" : "+v"(tb), "+v"(tc));                         // keeps the fragment loads of all passes from being hoisted (and spilled) together
+        float bw[MOT_MF_KS_R], cw[3][3][4][2];
+#pragma unroll
+        for (int s = 0; s < MOT_MF_KS_R; s++) bw[s] = (s < ksr) ? tb[s * 3 * 64] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 3; mt++)
+#pragma unroll
+            for (int xt = 0; xt < 3; xt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    cw[mt][xt][r][0] = (mt < xtl && xt < xtl) ? tc[(((mt * 3 + xt) * 4 + r) * 2 + 0) * 64] : 0.f;
+                    cw[mt][xt][r][1] = (mt < xtl && xt < xtl) ? tc[(((mt * 3 + xt) * 4 + r) * 2 + 1) * 64] : 0.f;
+                }
+        const int n = t * 16 + m;
+        for (int ch = wave; ch < nch; ch += nw) {
+            const float* Fc = F + ch * wb * ldf;
+            float v[3][4], v2[3][4];
+#pragma unroll
+            for (int xt = 0; xt < 3; xt++) {
+                f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+                if (xt < xtl) {
+                    const int x = xt * 16 + m;
+                    const float* in = Fc + min(x, wb - 1) * ldf;
+#pragma unroll
+                    for (int s = 0; s < MOT_MF_KS_R; s++) {
+                        if (s < ksr) {
+                            const int k = 4 * s + q;
+                            const float a = (x < wb && k < hb) ? in[min(k, hb - 1)] : 0.f;   // pad lines / pad floats are not data
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[s], acc, 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[xt][r] = acc[r];
+                    const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0xB1, 0xF, 0xF, false));   // lane ^ 1
+                    v2[xt][r] = (n & 1) ? -pv : pv;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 3; mt++) {
+                if (mt < xtl) {
+                    f32x4 o = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                    for (int xt = 0; xt < 3; xt++) {
+                        if (xt < xtl) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[mt][xt][r][0], v[xt][r], o, 0, 0, 0);
+                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[mt][xt][r][1], v2[xt][r], o, 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (n < ldf) {
+                        float* op = out + (size_t)ch * wb * ldf + n;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) { const int xp = mt * 16 + q * 4 + r; if (xp < wb) op[xp * ldf] = o[r]; }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- radix 4x5 prime-factor 20-point transforms, one thread per transform ----
 #define C1_5 0.30901699437494742f   /* cos(2pi/5) */
 #define C2_5 (-0.80901699437494742f) /* cos(4pi/5) */
@@ -597,6 +786,7 @@ __device__ __forceinline__ void cfft20_inplace(float2* __restrict__ base, int st
 
 // forward 2-D r2c of `nch` feature planes; result S[(ch*wb + x')*fh + k] in region B.
 // F lives in region B (row stride ldf = 2*fh floats); T is the ping-pong buffer of the generic path.
+template <bool SLAB>
 __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* __restrict__ regB,
                             const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt,
                             float* __restrict__ stage = nullptr)
@@ -612,7 +802,7 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
             cfft20_inplace<-1>(S + ch * 220 + k, 11);
         }
         __syncthreads();
-    } else if (stage && p.stage_G > 0) {
+    } else if (SLAB && stage && p.stage_G > 0) {
         // HBM-slab templates: G channel planes at a time through LDS (features in, rows DFT, columns DFT, spectrum out
         // in place: a channel's spectrum occupies exactly the bytes of its feature plane); same arithmetic as below
         const int planeF = p.wb * 2 * p.fh;                           // floats of one feature plane == floats of its half spectrum
@@ -622,6 +812,13 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
             const float2* src = reinterpret_cast<const float2*>(regB + (size_t)c0 * planeF);   // planeF is even
             for (int i = tid; i < g * planeF / 2; i += nt) reinterpret_cast<float2*>(sF)[i] = src[i];
             __syncthreads();
+            if (p.mf) {
+                dft_rows_mfma(p, sF, reinterpret_cast<float*>(sT), g * p.wb, tid, nt);
+                __syncthreads();
+                dft_cols_mfma(p, reinterpret_cast<const float*>(sT), regB + (size_t)c0 * planeF, g, tid, nt);
+                __syncthreads();
+                continue;
+            }
             const bool reg = p.hb <= MOT_DFT_REG_MAX && p.wb <= MOT_DFT_REG_MAX && p.hb >= 2 && p.wb >= 2;
             if (reg) dft_rows_reg(p, sF, sT, twr, g * p.wb, tid, nt); else dft_rows_generic(p, sF, sT, twr, g, tid, nt);
             __syncthreads();
@@ -727,8 +924,13 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
     const float* patch = l.patches ? l.patches + (size_t)item * p.rows * p.cols : nullptr;
     // byte staging area of the crop: region B, or the LDS staging area of an HBM-slab template
-    if (stage) phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(stage), tid, nt, p.stage_floats * 4);
-    else phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt);
+    if (stage) {
+        // gray scratch of a resized crop: the LDS staging area, or (source boxes beyond 175 x 175 at 148 px) regions B..T of the slab
+        const bbox_t sb = box; const int nsrc = (sb.b - sb.t + 1) * (sb.r - sb.l + 1);
+        const bool in_lds = nsrc <= p.stage_floats;
+        phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(stage), tid, nt, p.stage_floats * 4, in_lds ? stage : r.B, in_lds ? p.stage_floats : p.lds_floats - p.offB);
+    }
+    else phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt, 1 << 30, r.B, p.offC - p.offB);
     __syncthreads();
     DBG_STAMP(1);
     float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.cols * p.ldp);
@@ -746,13 +948,18 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
 }
 
 // one half of the channels -> windowed features -> spectrum in region B (overlays Mq / bins, then itself)
-template <int HALF>
+template <int HALF, bool SLAB>
 __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum, float* stage = nullptr)
 {
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
-    phase_channels<HALF>(p, r.A, r.N, r.B, fo, l.feat_windowed, tid, nt);
+    // HBM-slab templates with MFMA tables: the half's feature planes go straight into the LDS staging area and both DFT
+    // passes run from there (no slab round trip of the planes, no row-spectrum buffer)
+    const bool fused = SLAB && spectrum && stage && p.mf && p.stage_floats >= MOT_HALF0 * p.wb * 2 * p.fh;
+    phase_channels<HALF>(p, r.A, r.N, fused ? stage : r.B, fo, l.feat_windowed, tid, nt);
     __syncthreads();
-    if (spectrum) fft_forward(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
+    DBG_STAMP(8 + HALF);
+    if (fused) { dft2_mfma(p, (int)(stage - smem_base()), r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt); __syncthreads(); }
+    else if (spectrum) fft_forward<SLAB>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
 }
 
 template <bool kLds>
@@ -780,7 +987,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
     float zr = 0.f, zi = 0.f;
-    half_spectrum<0>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     if (pre) {
         if (tid < p.nbins) {
@@ -797,7 +1004,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         }
     }
     __syncthreads();
-    half_spectrum<1>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(6);
     if (pre) {
         if (tid < p.nbins) {
@@ -940,12 +1147,12 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
             }
         }
     } else {
-    if (!dspec) half_spectrum<0>(p, l, item, r, tid, nt, true, stage);
+    if (!dspec) half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     UPDATE_HALF(0, MOT_HALF0);
     if (!dspec) {
         __syncthreads();
-        half_spectrum<1>(p, l, item, r, tid, nt, true, stage);
+        half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
     }
     DBG_STAMP(6);
     UPDATE_HALF(MOT_HALF0, MOT_NCHAN);
@@ -999,9 +1206,9 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool
     const Regions r = carve(p, base);
     bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
     features_prepare<false>(p, l, item, box, r, threadIdx.x, blockDim.x);
-    half_spectrum<0>(p, l, item, r, threadIdx.x, blockDim.x, false);
+    half_spectrum<0, false>(p, l, item, r, threadIdx.x, blockDim.x, false);
     __syncthreads();
-    half_spectrum<1>(p, l, item, r, threadIdx.x, blockDim.x, false);
+    half_spectrum<1, false>(p, l, item, r, threadIdx.x, blockDim.x, false);
 }
 
 template <bool kLds>

@@ -33,7 +33,7 @@ struct PoolHost {
     int cap = 0;
     std::vector<int> free_slots;
     DevBuf<float2> xm; DevBuf<float> alpha; DevBuf<bbox_t> pos; DevBuf<float2> scale; DevBuf<int> first; DevBuf<float> response;
-    DevBuf<float> cos_win, yf_re; DevBuf<float2> tw_r, tw_c; DevBuf<float> gscratch;
+    DevBuf<float> cos_win, yf_re; DevBuf<float2> tw_r, tw_c; DevBuf<float> gscratch; DevBuf<float> mf_rows, mf_cols, mf_cols2;
 };
 
 struct TrackRec { int kind; int pool; int slot; int rows, cols; bool live; };

@@ -115,6 +115,36 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
     HIPCHK(hipMemcpy(ph->yf_re.p, yfre.data(), yfre.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ph->tw_r.p, twr.data(), twr.size() * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ph->tw_c.p, twc.data(), twc.size() * sizeof(float2), hipMemcpyHostToDevice));
+    p.mf = 0; p.mf_rows = nullptr; p.mf_cols = nullptr; p.mf_cols2 = nullptr;
+    if (!p.use_lds && !p.fft20 && p.hb <= MOT_DFT_MFMA_MAX && p.wb <= MOT_DFT_MFMA_MAX) {
+        // constant operands of the DFT-as-GEMM kernels in MFMA fragment order, from the same float twiddles as the other paths
+        const int ldf = 2 * p.fh;
+        std::vector<float> mr((size_t)MOT_MF_KS_R * 3 * 64, 0.f), mc((size_t)3 * MOT_MF_KS_C * 64, 0.f);
+        for (int s = 0; s < MOT_MF_KS_R; s++) for (int nt = 0; nt < 3; nt++) for (int l = 0; l < 64; l++) {
+            const int k = 4 * s + (l >> 4), n = 16 * nt + (l & 15);
+            if (k < p.hb && n < ldf) { const float2 w = twr[(size_t)((long)(n >> 1) * k % p.hb)]; mr[((size_t)s * 3 + nt) * 64 + l] = (n & 1) ? -w.y : w.x; }
+        }
+        for (int mt = 0; mt < 3; mt++) for (int s = 0; s < MOT_MF_KS_C; s++) for (int l = 0; l < 64; l++) {
+            const int xp = 16 * mt + (l & 15), k = 4 * s + (l >> 4);
+            if (xp < p.wb && k < 2 * p.wb) { const int x = k < p.wb ? k : k - p.wb; const float2 w = twc[(size_t)((long)xp * x % p.wb)]; mc[((size_t)mt * MOT_MF_KS_C + s) * 64 + l] = k < p.wb ? w.x : w.y; }
+        }
+        std::vector<float> mc2((size_t)3 * 3 * 4 * 2 * 64, 0.f);
+        for (int mt = 0; mt < 3; mt++) for (int xt = 0; xt < 3; xt++) for (int r = 0; r < 4; r++) for (int l = 0; l < 64; l++) {
+            const int xp = 16 * mt + (l & 15), x = 16 * xt + 4 * (l >> 4) + r;
+            if (xp < p.wb && x < p.wb) {
+                const float2 w = twc[(size_t)((long)xp * x % p.wb)];
+                mc2[((((size_t)mt * 3 + xt) * 4 + r) * 2 + 0) * 64 + l] = w.x; mc2[((((size_t)mt * 3 + xt) * 4 + r) * 2 + 1) * 64 + l] = w.y;
+            }
+        }
+        HIPCHK(ph->mf_cols2.alloc(mc2.size()));
+        HIPCHK(hipMemcpy(ph->mf_cols2.p, mc2.data(), mc2.size() * sizeof(float), hipMemcpyHostToDevice));
+        p.mf_cols2 = ph->mf_cols2.p;
+        HIPCHK(ph->mf_rows.alloc(mr.size())); HIPCHK(ph->mf_cols.alloc(mc.size()));
+        HIPCHK(hipMemcpy(ph->mf_rows.p, mr.data(), mr.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ph->mf_cols.p, mc.data(), mc.size() * sizeof(float), hipMemcpyHostToDevice));
+        p.mf_rows = ph->mf_rows.p; p.mf_cols = ph->mf_cols.p;
+        const char* ev = getenv("MOT_DFT_MFMA"); p.mf = (ev && atoi(ev) == 0) ? 0 : 1;
+    }
     if (!p.use_lds && !shared_scratch) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
     p.xm = ph->xm.p; p.alpha = ph->alpha.p; p.pos = ph->pos.p; p.scale = ph->scale.p; p.first_update = ph->first.p; p.response = ph->response.p;
     p.cos_win = ph->cos_win.p; p.yf_re = ph->yf_re.p; p.tw_r = ph->tw_r.p; p.tw_c = ph->tw_c.p; p.sse_tab = c->sse_tab.p; p.gscratch = ph->gscratch.p;
@@ -677,6 +707,7 @@ int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long*
     c->dbg_on = enable != 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (predict8 && getenv("MOT_DBG_CHANNELS")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "channels phase: half0 %lld half1 %lld ticks (of %lld, %lld)\n", t[8] - t[4], t[9] - t[5], t[5] - t[4], t[6] - t[5]); }
     if (update8) HIPCHK(hipMemcpy(update8, c->dbg.p + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return MOT_OK;
 }

@@ -53,7 +53,16 @@ struct KcfPool {
     const float2* tw_r;       // [hb] (cos,sin)(2*pi*j/hb)
     const float2* tw_c;       // [wb]
     const uint16_t* sse_tab;  // [4096] rcp | rsqrt mantissa tables
+    // DFTs as f32 MFMA products (HBM-slab templates with hb, wb <= MOT_DFT_MFMA_MAX): the constant operand, stored in the
+    // lane order of v_mfma_f32_16x16x4_f32 fragments (one coalesced 256-byte load per fragment)
+    const float* mf_rows;     // [ks_r][3][64]: B[k = 4s + lane/16][n = 16nt + lane%16] = (cos, -sin)(2 pi (n/2) k / hb), 0 outside
+    const float* mf_cols;     // [3][ks_c][64]: A[x' = 16mt + lane%16][k = 4s + lane/16] = k < wb ? cos(2 pi x' k / wb) : sin(2 pi x' (k - wb) / wb), 0 outside
+    const float* mf_cols2;    // [3 mt][3 xt][4 r][cos, sin][64]: A[x' = 16mt + lane%16][x = 16xt + 4(lane/16) + r] (the k order of dft2_mfma)
+    int mf;                   // 1: tables present
 };
+#define MOT_DFT_MFMA_MAX 41    /* line length up to which the MFMA DFT holds its constant fragments in registers */
+#define MOT_MF_KS_R ((MOT_DFT_MFMA_MAX + 3) / 4)
+#define MOT_MF_KS_C ((2 * MOT_DFT_MFMA_MAX + 3) / 4)
 
 struct KcfLaunch {
     const int* slots;         // [n] pool slot per workgroup (device)

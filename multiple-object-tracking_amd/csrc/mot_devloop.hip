@@ -132,7 +132,9 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             // detection-feature workgroups (2.44 -> 2.58 M updates/s at 1024 tracks).  0 (or a refusal by the runtime): a
             // low-priority stream over the whole chip, as in round 1.
             const char* rs = getenv("MOT_SIDE_RESERVE");
-            const int reserve = rs ? atoi(rs) : 32;
+            // HBM-slab templates run one workgroup per CU for hundreds of microseconds: taking CUs away from them costs a
+            // second round (256 tracks at 148 x 148: 322 k -> 240 k updates/s), so only LDS-resident templates reserve by default
+            const int reserve = rs ? atoi(rs) : (kp.use_lds ? 32 : 0);
             bool masked = false;
             if (reserve > 0 && reserve < 256) {
                 uint32_t mask[8];
