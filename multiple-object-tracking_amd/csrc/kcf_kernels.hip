@@ -236,14 +236,15 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // contributions of its <= 8x8 pixel footprint in the reference's order
 // (x outer, y inner), so every R1 value is bit-identical.  Then :225-230.
 // ---------------------------------------------------------------------------
-// PRELOAD (HBM-slab templates, 256-VGPR budget): the eight footprint columns are loaded first, all in flight at once,
-// because there every load is an L2 round trip; the LDS-resident kernels load column by column (128-VGPR budget).
-template <bool PRELOAD>
+// NPRE (HBM-slab templates): the footprint columns are loaded four at a time, all in flight at once, because there every
+// load is an L2 round trip; the LDS-resident kernels load column by column.
+template <int NPRE>
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
                            float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt)
 {
     const int hb = p.hb, wb = p.wb, nb = p.nb, LP = p.ldp;
     const int h0 = hb * 4, w0 = wb * 4;
+    constexpr int GRP = NPRE ? NPRE : 1;                               // footprint columns whose loads are in flight together
     for (int cell = tid; cell < nb; cell += nt) {
         uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
         // HBM-slab templates accumulate in a per-thread LDS scratch (the read-modify-write chain would otherwise run at L2
@@ -262,39 +263,38 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         // to exactly these values (all operands are multiples of 1/8, products multiples of 1/64).
         const float wq[8] = { 0.125f, 0.375f, 0.625f, 0.875f, 0.875f, 0.625f, 0.375f, 0.125f };
         const int x0 = 4 * (int)cx - 2, y0 = 4 * (int)cy - 2;
-        float4 pma[PRELOAD ? 8 : 1], pmb[PRELOAD ? 8 : 1]; uint32_t pba[PRELOAD ? 8 : 1], pbb[PRELOAD ? 8 : 1];
-        if (PRELOAD) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int x = min(max(x0 + i, x_lo), x_hi);               // clamped: always a valid column
-                const float* mp = Mq + x * LP + 4 * (int)cy;
-                pma[i] = *reinterpret_cast<const float4*>(mp); pmb[i] = *reinterpret_cast<const float4*>(mp + 4);
-                pba[i] = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
-                pbb[i] = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
+        for (int i0 = 0; i0 < 8; i0 += GRP) {
+            float4 pma[GRP], pmb[GRP]; uint32_t pba[GRP], pbb[GRP];
+#pragma unroll
+            for (int g = 0; g < GRP; g++) {
+                const int x = min(max(x0 + i0 + g, x_lo), x_hi);          // clamped: always a valid column
+                const float* mp = Mq + x * LP + 4 * (int)cy;              // = [x][2 + (4cy-2)], 16-byte aligned
+                pma[g] = *reinterpret_cast<const float4*>(mp); pmb[g] = *reinterpret_cast<const float4*>(mp + 4);
+                pba[g] = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
+                pbb[g] = *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int x = x0 + i;
-            if (x < x_lo || x > x_hi) continue;
-            int ob[8]; float term[8];
-            const float* mp = Mq + x * LP + 4 * (int)cy;               // = [x][2 + (4cy-2)], 16-byte aligned
-            const float4 ma = PRELOAD ? pma[i] : *reinterpret_cast<const float4*>(mp), mb = PRELOAD ? pmb[i] : *reinterpret_cast<const float4*>(mp + 4);
-            const uint32_t ba = PRELOAD ? pba[i] : *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy);
-            const uint32_t bb = PRELOAD ? pbb[i] : *reinterpret_cast<const uint32_t*>(bins + x * LP + 4 * (int)cy + 4);
-            const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
+            for (int g = 0; g < GRP; g++) {
+                const int i = i0 + g, x = x0 + i;
+                if (x < x_lo || x > x_hi) continue;
+                int ob[8]; float term[8];
+                const float4 ma = pma[g], mb = pmb[g];
+                const uint32_t ba = pba[g], bb = pbb[g];
+                const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int y = y0 + j;
-                const bool valid = (y >= y_lo) && (y <= y_hi);
-                const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
-                ob[j] = valid ? bj : (100 + j);                        // invalid slots never match
-                term[j] = (wq[i] * wq[j]) * mv[j];
+                for (int j = 0; j < 8; j++) {
+                    const int y = y0 + j;
+                    const bool valid = (y >= y_lo) && (y <= y_hi);
+                    const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
+                    ob[j] = valid ? bj : (100 + j);                        // invalid slots never match
+                    term[j] = (wq[i] * wq[j]) * mv[j];
+                }
+                // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
+                // same orientation sees the earlier sum; few instructions, the latency is covered by the other waves
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) Rc[ob[j]] += term[j];
             }
-            // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
-            // same orientation sees the earlier sum; few instructions, the latency is covered by the other waves
-#pragma unroll
-            for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) Rc[ob[j]] += term[j];
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
         if (nmul) {
@@ -306,14 +306,16 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
             }
         }
         if (scratch) {
-            float* out = R1 + cell * R1S;
+            // in the slab R1 is orientation-major, R1[o * nb + cell]: a wave's store covers 64 neighbouring cells (cell-major
+            // rows of 19 floats cost the texture addresser one cache line per lane and access)
 #pragma unroll
-            for (int o = 0; o < MOT_NORI; o++) out[o] = Rc[o];
+            for (int o = 0; o < MOT_NORI; o++) R1[o * nb + cell] = Rc[o];
         }
     }
 }
 
 // Phase 3a: E[cell] = sum_o (R1[o]+R1[o+9])^2  (gradientMex.cpp:308-309, 240-241)
+template <bool SOA>   // SOA: R1[o * nb + cell] (HBM slab), else R1[cell * R1S + o] (LDS)
 __device__ void phase_energy(const KcfPool& p, const float* __restrict__ R1, float* __restrict__ E, int tid, int nt)
 {
     const int nb = p.nb;
@@ -321,7 +323,7 @@ __device__ void phase_energy(const KcfPool& p, const float* __restrict__ R1, flo
         float e = 0.0f;
 #pragma unroll
         for (int o = 0; o < 9; o++) {
-            float r2 = R1[cell * R1S + o] + R1[cell * R1S + o + 9];
+            float r2 = SOA ? R1[o * nb + cell] + R1[(o + 9) * nb + cell] : R1[cell * R1S + o] + R1[cell * R1S + o + 9];
             e += r2 * r2;
         }
         E[cell] = e;
@@ -346,7 +348,7 @@ __device__ void phase_norm(const KcfPool& p, const float* __restrict__ E, float*
 // Channels are produced in two halves (0: channels 0..15, 1: channels 16..30) so the feature / spectrum buffer
 // holds 16 planes instead of 31 and two workgroups fit in one CU's LDS.
 #define MOT_HALF0 16
-template <int HALF>
+template <int HALF, bool SOA>
 __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, const float* __restrict__ N,
                                float* __restrict__ F, float* __restrict__ feat_out, int feat_windowed, int tid, int nt)
 {
@@ -364,7 +366,7 @@ __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, c
 #pragma unroll
         for (int o = 0; o < MOT_NORI; o++) {
             if (HALF == 0 && o >= MOT_HALF0) continue;                  // half 0 needs the first 16 sensitive channels only
-            const float v = R1[cell * R1S + o];
+            const float v = SOA ? R1[o * nb + cell] : R1[cell * R1S + o];
             if (o < 9) rlo[o] = v;
             float t0 = v * n0; if (t0 > clip) t0 = clip;
             float t1 = v * n1; if (t1 > clip) t1 = clip;
@@ -437,97 +439,6 @@ __device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in
             j += (int)xp; if (j >= wb) j -= wb;
         }
         out[i] = make_float2(re, im);
-    }
-}
-
-// ---- register-resident generic DFTs for lengths up to MOT_DFT_REG_MAX (templates up to 164 px): one thread owns a
-// whole line, folds it once into sums / differences of the mirrored pairs (x, n-x) -- cos is even and sin is odd, so
-// every output needs half the multiplies -- and walks the outputs with a WAVE-UNIFORM twiddle index (broadcast LDS
-// reads, no per-lane index arithmetic).  Used by the LDS-staged path of the HBM-slab templates.
-#define MOT_DFT_REG_MAX 41
-#define MOT_DFT_PAIRS ((MOT_DFT_REG_MAX - 1) / 2)
-
-// twiddle j of a table held one entry per lane (n <= 64): two v_readlane with a scalar lane index instead of an LDS read
-// per multiply-add pair (the LDS pipeline of the CU, shared by all waves, was the bottleneck of these loops)
-__device__ __forceinline__ float2 lane_twiddle(float2 mine, int j)
-{
-    return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), j)),
-                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), j)));
-}
-
-// real rows: F[row*ldf + y] -> T[row*fh + k], k = 0..fh-1 (same convention as dft_rows_generic)
-__device__ void dft_rows_reg(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
-                             const float2* __restrict__ twr, int nrows, int tid, int nt)
-{
-    const int hb = p.hb, fh = p.fh, ldf = 2 * fh, H = (hb - 1) >> 1;
-    const bool even = !(hb & 1);
-    const float2 twl = twr[min(tid & 63, hb - 1)];                    // lane l holds twiddle l
-    for (int row0 = 0; row0 < nrows; row0 += nt) {                    // whole waves stay in the loop (readlane needs the table lanes)
-        const int row = min(row0 + tid, nrows - 1);
-        const bool live = row0 + tid < nrows;
-        const float* in = F + row * ldf;
-        float s[MOT_DFT_PAIRS], d[MOT_DFT_PAIRS];
-#pragma unroll
-        for (int y = 1; y <= MOT_DFT_PAIRS; y++) {
-            const float a = in[min(y, hb - 1)], b = in[max(hb - y, 0)];
-            s[y - 1] = (y <= H) ? a + b : 0.f; d[y - 1] = (y <= H) ? a - b : 0.f;
-        }
-        const float in0 = in[0], mid = even ? in[hb >> 1] : 0.f;
-        float2* out = T + row * fh;
-        for (int k = 0; k < fh; k++) {                                // wave-uniform
-            float re = in0 + ((k & 1) ? -mid : mid), im = 0.f;
-            int j = 0;
-#pragma unroll
-            for (int y = 1; y <= MOT_DFT_PAIRS; y++) {
-                j += k; if (j >= hb) j -= hb;
-                const float2 w = lane_twiddle(twl, j);
-                re += s[y - 1] * w.x; im -= d[y - 1] * w.y;
-            }
-            if (live) out[k] = make_float2(re, im);
-        }
-    }
-}
-
-// complex columns: in[(ch*wb + x)*fh + k] -> out[(ch*wb + x')*fh + k]; the two halves of the output range go to the
-// two halves of the workgroup (uniform per wave)
-template <int SIGN>
-__device__ void dft_cols_reg(const KcfPool& p, const float2* __restrict__ in, float2* __restrict__ out,
-                             const float2* __restrict__ twc, int nch, int tid, int nt)
-{
-    const int wb = p.wb, fh = p.fh, H = (wb - 1) >> 1, ncols = nch * fh, half = nt >> 1;
-    const bool even = !(wb & 1);
-    const int part = tid >= half ? 1 : 0, hw = (wb + 1) >> 1;
-    const int x0 = part * hw, x1 = min(wb, x0 + hw);
-    const float2 twl = twc[min(tid & 63, wb - 1)];                    // lane l holds twiddle l
-    for (int col0 = 0; col0 < ncols; col0 += half) {
-        const int colr = col0 + tid - part * half;
-        const bool live = colr < ncols;
-        const int col = min(colr, ncols - 1);
-        uint32_t ch, k; p.d_fh.divmod((uint32_t)col, ch, k);
-        const float2* src = in + (size_t)ch * wb * fh + k;
-        float2 s[MOT_DFT_PAIRS], d[MOT_DFT_PAIRS];
-#pragma unroll
-        for (int x = 1; x <= MOT_DFT_PAIRS; x++) {
-            const float2 a = src[min(x, wb - 1) * fh], b = src[max(wb - x, 0) * fh];
-            const bool on = x <= H;
-            s[x - 1] = on ? make_float2(a.x + b.x, a.y + b.y) : make_float2(0.f, 0.f);
-            d[x - 1] = on ? make_float2(a.x - b.x, a.y - b.y) : make_float2(0.f, 0.f);
-        }
-        const float2 a0 = src[0], mid = even ? src[(wb >> 1) * fh] : make_float2(0.f, 0.f);
-        float2* dst = out + (size_t)ch * wb * fh + k;
-        for (int xp = x0; xp < x1; xp++) {                            // uniform per wave
-            const float sg = (xp & 1) ? -1.f : 1.f;
-            float re = a0.x + sg * mid.x, im = a0.y + sg * mid.y;
-            int j = 0;
-#pragma unroll
-            for (int x = 1; x <= MOT_DFT_PAIRS; x++) {
-                j += xp; if (j >= wb) j -= wb;
-                const float2 w = lane_twiddle(twl, j);
-                if (SIGN < 0) { re += s[x - 1].x * w.x + d[x - 1].y * w.y; im += s[x - 1].y * w.x - d[x - 1].x * w.y; }
-                else          { re += s[x - 1].x * w.x - d[x - 1].y * w.y; im += s[x - 1].y * w.x + d[x - 1].x * w.y; }
-            }
-            if (live) dst[xp * fh] = make_float2(re, im);
-        }
     }
 }
 
@@ -620,28 +531,22 @@ __device__ void dft_cols_mfma(const KcfPool& p, const float* __restrict__ sT, fl
 // product takes the tiles as they are and the CONSTANT operand (pool table mf_cols2) is stored in that k order.  T' (the
 // re/im swap of the sine half) is the neighbouring lane's value: one DPP move.
 //   F[(c*wb + x)*ldf + y] (LDS) -> out[(c*wb + x')*ldf + n]
-__device__ __attribute__((noinline)) void dft2_mfma(const KcfPool& p, int f_off, float* __restrict__ out, int nch, int tid, int nt_)
+__device__ __attribute__((noinline)) void dft2_mfma(const KcfPool& p, int f_off, int cw_off, float* __restrict__ out, int nch, int tid, int nt_)
 {
     extern __shared__ __attribute__((aligned(16))) float dft2_smem[];
-    const float* __restrict__ F = dft2_smem + f_off;                   // LDS (kept out of line: its 72 constant fragments get a register allocation of their own)
+    const float* __restrict__ F = dft2_smem + f_off;                   // LDS (kept out of line: a register allocation of its own)
+    float* __restrict__ cw = dft2_smem + cw_off;                       // LDS copy of the column fragments [mt][xt][r][cos, sin][lane]
     const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6, q = lane >> 4, m = lane & 15;
     const int hb = p.hb, wb = p.wb, ldf = 2 * p.fh, ksr = (hb + 3) >> 2, ntl = (ldf + 15) >> 4, xtl = (wb + 15) >> 4;
+    for (int i = tid; i < 3 * 3 * 4 * 2 * 64; i += nt_) cw[i] = p.mf_cols2[i];
+    __syncthreads();
+    const float* cwl = cw + lane;
     for (int t = 0; t < ntl; t++) {                                    // 16 output floats (8 bins) per pass
         const float* tb = p.mf_rows + t * 64 + lane;
-        const float* tc = p.mf_cols2 + lane;
-        asm volatile("" : "+v"(tb), "+v"(tc));                         // keeps the fragment loads of all passes from being hoisted (and spilled) together
-        float bw[MOT_MF_KS_R], cw[3][3][4][2];
+        asm volatile("" : "+v"(tb));                                   // keeps the fragment loads of all passes from being hoisted (and spilled) together
+        float bw[MOT_MF_KS_R];
 #pragma unroll
         for (int s = 0; s < MOT_MF_KS_R; s++) bw[s] = (s < ksr) ? tb[s * 3 * 64] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 3; mt++)
-#pragma unroll
-            for (int xt = 0; xt < 3; xt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    cw[mt][xt][r][0] = (mt < xtl && xt < xtl) ? tc[(((mt * 3 + xt) * 4 + r) * 2 + 0) * 64] : 0.f;
-                    cw[mt][xt][r][1] = (mt < xtl && xt < xtl) ? tc[(((mt * 3 + xt) * 4 + r) * 2 + 1) * 64] : 0.f;
-                }
         const int n = t * 16 + m;
         for (int ch = wave; ch < nch; ch += nw) {
             const float* Fc = F + ch * wb * ldf;
@@ -677,8 +582,8 @@ __device__ __attribute__((noinline)) void dft2_mfma(const KcfPool& p, int f_off,
                         if (xt < xtl) {
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
-                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[mt][xt][r][0], v[xt][r], o, 0, 0, 0);
-                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[mt][xt][r][1], v2[xt][r], o, 0, 0, 0);
+                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(cwl[(((mt * 3 + xt) * 4 + r) * 2 + 0) * 64], v[xt][r], o, 0, 0, 0);
+                                o = __builtin_amdgcn_mfma_f32_16x16x4f32(cwl[(((mt * 3 + xt) * 4 + r) * 2 + 1) * 64], v2[xt][r], o, 0, 0, 0);
                             }
                         }
                     }
@@ -791,7 +696,7 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
                             const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt,
                             float* __restrict__ stage = nullptr)
 {
-    if (p.fft20) {
+    if (!SLAB && p.fft20) {
         const int nrows = nch * p.wb;
         for (int r = tid; r < nrows; r += nt) rfft20_inplace(regB + r * 22);
         __syncthreads();
@@ -819,11 +724,9 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
                 __syncthreads();
                 continue;
             }
-            const bool reg = p.hb <= MOT_DFT_REG_MAX && p.wb <= MOT_DFT_REG_MAX && p.hb >= 2 && p.wb >= 2;
-            if (reg) dft_rows_reg(p, sF, sT, twr, g * p.wb, tid, nt); else dft_rows_generic(p, sF, sT, twr, g, tid, nt);
+            dft_rows_generic(p, sF, sT, twr, g, tid, nt);                 // lines longer than MOT_DFT_MFMA_MAX cells (templates beyond 164 px)
             __syncthreads();
-            if (reg) dft_cols_reg<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
-            else dft_cols_generic<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
+            dft_cols_generic<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
             __syncthreads();
         }
     } else {
@@ -937,10 +840,10 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
-    phase_hist<SLAB>(p, Mq, bins, r.A, stage, tid, nt);              // R1 overlays the patch
+    phase_hist<SLAB ? 4 : 0>(p, Mq, bins, r.A, stage, tid, nt);              // R1 overlays the patch
     __syncthreads();
     DBG_STAMP(3);
-    phase_energy(p, r.A, r.E, tid, nt);
+    phase_energy<SLAB>(p, r.A, r.E, tid, nt);
     __syncthreads();
     phase_norm(p, r.E, r.N, tid, nt);
     __syncthreads();
@@ -954,11 +857,11 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
     // HBM-slab templates with MFMA tables: the half's feature planes go straight into the LDS staging area and both DFT
     // passes run from there (no slab round trip of the planes, no row-spectrum buffer)
-    const bool fused = SLAB && spectrum && stage && p.mf && p.stage_floats >= MOT_HALF0 * p.wb * 2 * p.fh;
-    phase_channels<HALF>(p, r.A, r.N, fused ? stage : r.B, fo, l.feat_windowed, tid, nt);
+    const bool fused = SLAB && spectrum && stage && p.mf && p.stage_floats >= MOT_HALF0 * p.wb * 2 * p.fh + MOT_MF_CW_FLOATS;
+    phase_channels<HALF, SLAB>(p, r.A, r.N, fused ? stage : r.B, fo, l.feat_windowed, tid, nt);
     __syncthreads();
     DBG_STAMP(8 + HALF);
-    if (fused) { dft2_mfma(p, (int)(stage - smem_base()), r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt); __syncthreads(); }
+    if (fused) { dft2_mfma(p, (int)(stage - smem_base()), (int)(stage - smem_base()) + MOT_HALF0 * p.wb * 2 * p.fh, r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt); __syncthreads(); }
     else if (spectrum) fft_forward<SLAB>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
 }
 
@@ -1050,7 +953,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1061,7 +964,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_ker
 // size classes (device loop with per-track template sizes, kcf.cpp:148-152): the workgroup's pool descriptor comes from a device
 // table, indexed by the class of its track
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1177,7 +1080,7 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
 }
 
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1186,7 +1089,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_kern
     kcf_update_body<kLds>(p, l, item, smem);
 }
 template <bool kLds>
-__global__ void __launch_bounds__(MOT_KCF_THREADS, kLds ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1258,7 +1161,7 @@ void kcf_pool_layout(KcfPool& p)
     p.szC = 0; p.stage_floats = 0; p.stage_G = 0;
     if (!p.use_lds) {
         const int avail = (int)(MOT_LDS_LIMIT / sizeof(float)) - up4(szC);
-        const int hist = up4(MOT_KCF_THREADS * R1S);
+        const int hist = up4(MOT_KCF_THREADS_SLAB * R1S);
         const int plane2 = 2 * p.wb * 2 * p.fh;                      // feature plane + its row spectrum, floats
         if (avail >= hist) {
             p.szC = up4(szC);
@@ -1291,7 +1194,7 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
         const size_t ldsm = l.lds_bytes;
         if (p.use_lds) { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<true>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
-        else { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), ldsm, s, l, n); }
         return hipGetLastError();
     }
     const size_t lds = kcf_lds_bytes(p);
@@ -1300,7 +1203,7 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
         hipLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
     } else {
         hipError_t e = set_lds_attr(kcf_predict_kernel<false>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+        hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
     }
     return hipGetLastError();
 }
@@ -1311,7 +1214,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     if (l.pools) {
         const size_t ldsm = l.lds_bytes;
         if (p.use_lds) { hipError_t e = set_lds_attr(kcf_update_multi_kernel<true>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
-        else { hipError_t e = set_lds_attr(kcf_update_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_update_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), ldsm, s, l, n); }
         return hipGetLastError();
     }
     size_t lds = kcf_lds_bytes(p);
@@ -1323,7 +1226,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
         hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
     } else {
         hipError_t e = set_lds_attr(kcf_update_kernel<false>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+        hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
     }
     return hipGetLastError();
 }

@@ -9,6 +9,7 @@
 #define MOT_CELL 4            // trackers/kcf.cpp:488
 #define MOT_ASSOC_CTL_WORDS (1024 + 4 * 16384)   // assoc_common.h: control words + tagged COVBITS / BMOUT granules
 #define MOT_KCF_THREADS 512   // one workgroup per track
+#define MOT_KCF_THREADS_SLAB 512   // HBM-slab templates: one workgroup per CU, so the whole CU's wave slots belong to it
 #define MOT_LDS_LIMIT (160 * 1024)
 
 struct FastDiv {              // exact n/d for n*d < 2^32
@@ -63,6 +64,7 @@ struct KcfPool {
 #define MOT_DFT_MFMA_MAX 41    /* line length up to which the MFMA DFT holds its constant fragments in registers */
 #define MOT_MF_KS_R ((MOT_DFT_MFMA_MAX + 3) / 4)
 #define MOT_MF_KS_C ((2 * MOT_DFT_MFMA_MAX + 3) / 4)
+#define MOT_MF_CW_FLOATS (3 * 3 * 4 * 2 * 64)   /* column fragments of the fused transform */
 
 struct KcfLaunch {
     const int* slots;         // [n] pool slot per workgroup (device)
