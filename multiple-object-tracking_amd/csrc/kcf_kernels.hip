@@ -19,7 +19,11 @@
 #include "bin_thresholds.inc"
 
 #define PI_F 3.14159265f /* libhog/gradientMex.cpp:12 */
-#define R1S 19   /* LDS stride of one cell's 18 orientation bins (odd: conflict-free across lanes, no multiply per access) */
+/* R1 (18 orientation sums per cell) in LDS is WAVE-INTERLEAVED: bin o of cell c lives at ((c / 64) * 18 + o) * 64 + c % 64, so
+ * a lane's read-modify-writes always hit bank = lane whatever the (data-dependent) bin -- cell-major rows made the
+ * histogram's scatter 2- to 4-way bank-conflicted.  In the HBM slab R1 is orientation-major (coalesced), o * nb + c. */
+#define R1W(c, o) ((((c) >> 6) * MOT_NORI + (o)) * 64 + ((c) & 63))
+template <bool SOA> __device__ __forceinline__ int r1_index(int nb, int cell, int o) { return SOA ? o * nb + cell : R1W(cell, o); }
 
 namespace {
 
@@ -50,6 +54,23 @@ __device__ __forceinline__ float sse_rsqrt(float x, const uint16_t* tab)
     r = (e == 0) ? (s | 0x7f800000u) : r;                    // +-0 / denormal -> +-inf
     r = (e == 0xff && m) ? (u | 0x400000u) : r;              // NaN -> quiet NaN
     return u2f(r);
+}
+
+// The two call sites of phase_gradmag see a restricted domain: m2 = gx*gx + gy*gy is finite and >= +0 (gray values are
+// 0..255), and rcp's argument is min(rsqrt(m2), 1e10f), a positive normal number <= 1e10 -- the sign / NaN / infinity /
+// underflow cases of the general emulations above cannot occur there and are dropped (same bits on that domain).
+__device__ __forceinline__ float sse_rsqrt_nonneg_finite(float x, const uint16_t* tab)
+{
+    const uint32_t u = f2u(x), e = u >> 23, m = u & 0x7fffff;          // sign bit is 0
+    const int E = (int)e - 127, odd = E & 1;
+    const int ep = 126 - ((E - odd) >> 1);
+    const uint32_t r = ((uint32_t)ep << 23) | ((uint32_t)tab[2048 + odd * 1024 + (m >> 13)] << 11);
+    return u2f((e == 0) ? 0x7f800000u : r);                             // +0 / denormal -> +inf
+}
+__device__ __forceinline__ float sse_rcp_pos_normal(float x, const uint16_t* tab)
+{
+    const uint32_t u = f2u(x), e = u >> 23, m = u & 0x7fffff;          // 1 <= e <= 160: 253 - e > 0
+    return u2f(((253u - e) << 23) | ((uint32_t)tab[m >> 12] << 11));
 }
 
 // drawlib.c:234 -- double arithmetic, one rounding to float at the end.
@@ -185,6 +206,8 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
     const int h = p.rows, w = p.cols, LP = p.ldp, ng = p.ng;
     const int thr0[9] = MOT_BIN_THR0;
     { const int t1[9] = MOT_BIN_THR1; for (int j = 0; j < 9; j++) if (t1[j] != thr0[j]) __builtin_trap(); }   // both sign flags share the thresholds
+    if (thr0[4] != 1) __builtin_trap();
+    for (int j = 0; j < 4; j++) if (thr0[5 + j] != -thr0[3 - j] + 1) __builtin_trap();                           // the mirror structure the bin count relies on
     const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
     for (int it = tid; it < w * ng; it += nt) {
         uint32_t x, kq; p.d_ng.divmod((uint32_t)it, x, kq);
@@ -208,15 +231,18 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
             const float gx = (rr[j] - ll[j]) * rx;
             const float gy = (yp - ym) * ry;
             const float m2 = gx * gx + gy * gy;
-            float m = approx ? sse_rsqrt(m2, tab) : 1.0f / sqrtf(m2);
+            float m = approx ? sse_rsqrt_nonneg_finite(m2, tab) : 1.0f / sqrtf(m2);
             m = (m < 1e10f) ? m : 1e10f;                               // _mm_min_ps(m, 1e10f)
-            const float mag = approx ? sse_rcp(m, tab) : 1.0f / m;
+            const float mag = approx ? sse_rcp_pos_normal(m, tab) : 1.0f / m;
             float g = (gx * m) * 10000.0f;
             g = u2f(f2u(g) ^ (f2u(gy) & 0x80000000u));
             const int idx = (int)g;
-            int b = (gy < 0.0f) ? MOT_BIN_TOP1 : MOT_BIN_TOP0;
-#pragma unroll
-            for (int q = 0; q < 9; q++) b -= (idx >= thr0[q]) ? 1 : 0;
+            // bin = TOP - #{q : idx >= thr[q]}.  The nine thresholds are {-u3, -u2, -u1, -u0, 1, u0 + 1, u1 + 1, u2 + 1, u3 + 1}
+            // (checked below), so with a = |idx| and k = #{q : a > u_q} the count is 5 + k for idx >= 1 and 4 - k otherwise:
+            // four compares instead of nine
+            const int a = idx < 0 ? -idx : idx;
+            const int k = (a > -thr0[3]) + (a > -thr0[2]) + (a > -thr0[1]) + (a > -thr0[0]);
+            int b = ((gy < 0.0f) ? MOT_BIN_TOP1 : MOT_BIN_TOP0) - ((idx >= 1) ? 5 + k : 4 - k);
             if (b >= 18) b = 0;
             mq[j] = mag * 0.0625f;                                     // norm = 1/bin/bin (:152,132)
             bq[j] = (uint32_t)b;
@@ -249,9 +275,9 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
         // HBM-slab templates accumulate in a per-thread LDS scratch (the read-modify-write chain would otherwise run at L2
         // latency) and copy the finished cell out
-        float* __restrict__ Rc = scratch ? scratch + tid * R1S : R1 + cell * R1S;
+        float* __restrict__ Rc = scratch ? scratch + R1W(tid, 0) : R1 + R1W(cell, 0);   // bin o at Rc[o * 64]
 #pragma unroll
-        for (int o = 0; o < MOT_NORI; o++) Rc[o] = 0.0f;
+        for (int o = 0; o < MOT_NORI; o++) Rc[o * 64] = 0.0f;
         const int x_lo = max(0, 4 * (int)cx - 2), x_hi = min(w0 - 1, 4 * (int)cx + 5);
         const int y_lo = max(0, 4 * (int)cy - 2), y_hi = min(h0 - 1, 4 * (int)cy + 5);
         // One column of the footprint (<= 8 pixels) per round: all LDS reads of the round are issued together and
@@ -293,29 +319,29 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
                 // same orientation sees the earlier sum; few instructions, the latency is covered by the other waves
 #pragma unroll
-                for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) Rc[ob[j]] += term[j];
+                for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) Rc[ob[j] * 64] += term[j];
             }
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
         if (nmul) {
             const float c = 8.f / 7.f;
             for (int o = 0; o < MOT_NORI; o++) {
-                float v = Rc[o];
+                float v = Rc[o * 64];
                 for (int k = 0; k < nmul; k++) v *= c;
-                Rc[o] = v;
+                Rc[o * 64] = v;
             }
         }
         if (scratch) {
             // in the slab R1 is orientation-major, R1[o * nb + cell]: a wave's store covers 64 neighbouring cells (cell-major
             // rows of 19 floats cost the texture addresser one cache line per lane and access)
 #pragma unroll
-            for (int o = 0; o < MOT_NORI; o++) R1[o * nb + cell] = Rc[o];
+            for (int o = 0; o < MOT_NORI; o++) R1[o * nb + cell] = Rc[o * 64];
         }
     }
 }
 
 // Phase 3a: E[cell] = sum_o (R1[o]+R1[o+9])^2  (gradientMex.cpp:308-309, 240-241)
-template <bool SOA>   // SOA: R1[o * nb + cell] (HBM slab), else R1[cell * R1S + o] (LDS)
+template <bool SOA>   // SOA: R1[o * nb + cell] (HBM slab), else wave-interleaved (LDS)
 __device__ void phase_energy(const KcfPool& p, const float* __restrict__ R1, float* __restrict__ E, int tid, int nt)
 {
     const int nb = p.nb;
@@ -323,7 +349,7 @@ __device__ void phase_energy(const KcfPool& p, const float* __restrict__ R1, flo
         float e = 0.0f;
 #pragma unroll
         for (int o = 0; o < 9; o++) {
-            float r2 = SOA ? R1[o * nb + cell] + R1[(o + 9) * nb + cell] : R1[cell * R1S + o] + R1[cell * R1S + o + 9];
+            float r2 = R1[r1_index<SOA>(nb, cell, o)] + R1[r1_index<SOA>(nb, cell, o + 9)];
             e += r2 * r2;
         }
         E[cell] = e;
@@ -366,7 +392,7 @@ __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, c
 #pragma unroll
         for (int o = 0; o < MOT_NORI; o++) {
             if (HALF == 0 && o >= MOT_HALF0) continue;                  // half 0 needs the first 16 sensitive channels only
-            const float v = SOA ? R1[o * nb + cell] : R1[cell * R1S + o];
+            const float v = R1[r1_index<SOA>(nb, cell, o)];
             if (o < 9) rlo[o] = v;
             float t0 = v * n0; if (t0 > clip) t0 = clip;
             float t1 = v * n1; if (t1 > clip) t1 = clip;
@@ -807,9 +833,8 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* c
     r.twc = reinterpret_cast<float2*>(c); c += 2 * p.wb;
     r.zf = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
     r.tmp = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
-    r.E = c; c += p.nb;
+    r.E = c; r.resp = c; c += p.nb;                                 // the cell energies are dead long before the response exists
     r.N = c; c += (p.hb + 1) * (p.wb + 1);
-    r.resp = c; c += p.nb;
     r.red_v = c; c += 16;
     r.red_i = reinterpret_cast<int*>(c); c += 16;
     return r;
@@ -873,6 +898,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int slot = l.slots[item];
+    if (l.dbg && threadIdx.x == 0 && item < 4096) l.dbg[32 + 3 * item] = wall_clock64();
     const bbox_t pos = p.pos[slot];                                    // kcf_t::pos == tracker_info.bbox (td.cpp:351-354)
     // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
     // they land while the features are computed
@@ -948,6 +974,11 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
             o.t = min(max(o.t, 0), MOT_FRAME_H - 1); o.b = min(max(o.b, 0), MOT_FRAME_H - 1);
         }
         if (l.boxes_out) l.boxes_out[item] = o;
+        if (l.dbg && item < 4096) {
+            unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));   // cu / se / xcc of this workgroup
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            l.dbg[32 + 3 * item + 1] = wall_clock64(); l.dbg[32 + 3 * item + 2] = ((long long)xcc << 32) | hw;
+        }
     }
     DBG_STAMP(7);
 }
@@ -1149,9 +1180,10 @@ void kcf_pool_layout(KcfPool& p)
     p.eta = 0.05f; p.lambda = 0.0001f;
     const int spec = MOT_HALF0 * p.nbins * 2;                         // floats of 16 spectrum planes / padded feature planes
     auto up4 = [](int v) { return (v + 3) & ~3; };
-    int szA = p.cols * p.ldp; if (19 * p.nb > szA) szA = 19 * p.nb;   // patch, then R1[cell][19]
+    const int r1f = MOT_NORI * 64 * ((p.nb + 63) / 64);              // R1, wave-interleaved (the slab's orientation-major form is smaller)
+    int szA = p.cols * p.ldp; if (r1f > szA) szA = r1f;               // patch, then R1
     int szB = p.cols * p.ldp + (p.cols * p.ldp + 3) / 4 + 8; if (spec > szB) szB = spec;   // Mq + bins in the padded column layout
-    const int szC = 2048 + 2 * p.hb + 2 * p.wb + 4 * p.nbins + p.nb + (p.hb + 1) * (p.wb + 1) + p.nb + 32;
+    const int szC = 2048 + 2 * p.hb + 2 * p.wb + 4 * p.nbins + p.nb + (p.hb + 1) * (p.wb + 1) + 32;   // E and resp share their nb floats
     const int szT = p.fft20 ? 0 : spec;                               // ping-pong buffer of the generic DFT
     p.offA = 0; p.offB = up4(szA); p.offC = p.offB + up4(szB); p.offT = p.offC + up4(szC);
     p.lds_floats = p.offT + up4(szT);
@@ -1161,7 +1193,7 @@ void kcf_pool_layout(KcfPool& p)
     p.szC = 0; p.stage_floats = 0; p.stage_G = 0;
     if (!p.use_lds) {
         const int avail = (int)(MOT_LDS_LIMIT / sizeof(float)) - up4(szC);
-        const int hist = up4(MOT_KCF_THREADS_SLAB * R1S);
+        const int hist = up4(MOT_KCF_THREADS_SLAB * MOT_NORI);
         const int plane2 = 2 * p.wb * 2 * p.fh;                      // feature plane + its row spectrum, floats
         if (avail >= hist) {
             p.szC = up4(szC);

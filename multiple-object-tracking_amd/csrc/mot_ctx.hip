@@ -703,12 +703,17 @@ int mot_crop_patch(mot_ctx* c, const bbox_t* box, int rows, int cols, float* pat
 int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long* update8)
 {   // workgroup-0 phase stamps (100 MHz ticks) of the most recent device-loop predict / update launches
     if (!c) return fail(MOT_ERR_ARG, "null ctx");
-    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32)); HIPCHK(hipMemset(c->dbg.p, 0, 32 * sizeof(long long))); }
+    // [0..15] predict, [16..31] update phase stamps of workgroup 0; [32 + 3i ..] start, end, hardware id of predict workgroup i (MOT_DBG_WG=1)
+    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32 + 3 * 4096)); HIPCHK(hipMemset(c->dbg.p, 0, (32 + 3 * 4096) * sizeof(long long))); }
     c->dbg_on = enable != 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (predict8 && getenv("MOT_DBG_CHANNELS")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "channels phase: half0 %lld half1 %lld ticks (of %lld, %lld)\n", t[8] - t[4], t[9] - t[5], t[5] - t[4], t[6] - t[5]); }
     if (update8) HIPCHK(hipMemcpy(update8, c->dbg.p + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (const char* wf = getenv("MOT_DBG_WG")) {                        // per-workgroup start / end of the last predict launch -> text file
+        std::vector<long long> t(3 * 4096); HIPCHK(hipMemcpy(t.data(), c->dbg.p + 32, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(wf, "w")) { for (int i = 0; i < 4096 && t[3 * i]; i++) fprintf(f, "%d %lld %lld %lld\n", i, t[3 * i], t[3 * i + 1], t[3 * i + 2]); fclose(f); }
+    }
     return MOT_OK;
 }
 

@@ -6,6 +6,12 @@ python bench.py --tracks 64 --no-cpu-baseline > $O/bench_n64.json 2>/dev/null
 python bench.py --tracks 256 --no-cpu-baseline > $O/bench_n256.json 2>/dev/null
 python bench.py --tracks 512 --no-cpu-baseline > $O/bench_n512.json 2>/dev/null
 python bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline > $O/bench_n256_s148_multiscale.json 2>/dev/null
+python bench.py --tracks 256 --size 150 --det-sizes 120 180 --per-track-sizes --no-cpu-baseline > $O/bench_n256_per_track_sizes_120_180.json 2>/dev/null
+python bench.py --tracks 1024 --det-sizes 64 96 --per-track-sizes --no-cpu-baseline > $O/bench_n1024_per_track_sizes_64_96.json 2>/dev/null
+MOT_DBG_WG=$O/wg_timeline_n1024.txt python tools/kcf_probe.py --frames 8 > $O/kcf_probe_n1024.log 2>&1
+python tools/wg_timeline.py $O/wg_timeline_n1024.txt >> $O/kcf_probe_n1024.log 2>&1
+python tools/kcf_probe.py --frames 8 --tracks 256 --size 148 --det-sizes 120 180 > $O/kcf_probe_n256_s148.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_s148 -- python3 bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_default -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_driver -- python3 bench.py --steps 20 --warmup 5 --steady 0 --profile-frames 0 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --steady 0 --no-cpu-baseline --profile-frames 0 > /dev/null 2>&1
