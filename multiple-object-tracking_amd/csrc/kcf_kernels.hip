@@ -95,6 +95,9 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
                            float* __restrict__ gbuf = nullptr, int gcap = 0)
 {
     const int rows = p.rows, cols = p.cols, npx = rows * cols;
+    // the pad floats below every patch column are read by the gradient of the rounded-up last 4-pixel group; those pixels
+    // carry weight 0 in the histogram but must stay finite
+    for (int i = tid; i < cols * (p.ldp - rows); i += nt) { const int c = i / (p.ldp - rows), k = i - c * (p.ldp - rows); P[c * p.ldp + rows + k] = 0.0f; }
     if (patch) {
         for (int d = tid; d < npx; d += nt) {
             uint32_t c, r; p.d_rows.divmod((uint32_t)d, c, r);
@@ -254,6 +257,11 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
         *reinterpret_cast<uint16_t*>(bo) = (uint16_t)(bq[0] | (bq[1] << 8));
         *reinterpret_cast<uint16_t*>(bo + 2) = (uint16_t)(bq[2] | (bq[3] << 8));
     }
+    // the two pad slots above and below every column are read (with weight 0) by the histogram: finite magnitude, bin 0
+    for (int i = tid; i < 4 * w; i += nt) {
+        const int x = i >> 2, k = i & 3, idx = x * LP + (k < 2 ? k : LP - 4 + k);
+        Mq[idx] = 0.0f; bins[idx] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -289,6 +297,9 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         // to exactly these values (all operands are multiples of 1/8, products multiples of 1/64).
         const float wq[8] = { 0.125f, 0.375f, 0.625f, 0.875f, 0.875f, 0.625f, 0.375f, 0.125f };
         const int x0 = 4 * (int)cx - 2, y0 = 4 * (int)cy - 2;
+        float wy[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) wy[j] = (y0 + j >= y_lo && y0 + j <= y_hi) ? wq[j] : 0.0f;
 #pragma unroll
         for (int i0 = 0; i0 < 8; i0 += GRP) {
             float4 pma[GRP], pmb[GRP]; uint32_t pba[GRP], pbb[GRP];
@@ -303,23 +314,19 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
                 const int i = i0 + g, x = x0 + i;
-                if (x < x_lo || x > x_hi) continue;
-                int ob[8]; float term[8];
+                // straight-line code, no per-pixel predication: a pixel outside the footprint's valid range gets weight 0 and
+                // adds +0.0f (an exact no-op on the non-negative sums) to whatever bin its clamped column / zeroed pad names
+                const float wx = (x >= x_lo && x <= x_hi) ? wq[i] : 0.0f;
                 const float4 ma = pma[g], mb = pmb[g];
                 const uint32_t ba = pba[g], bb = pbb[g];
                 const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
+                // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
+                // same orientation sees the earlier sum
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const int y = y0 + j;
-                    const bool valid = (y >= y_lo) && (y <= y_hi);
                     const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
-                    ob[j] = valid ? bj : (100 + j);                        // invalid slots never match
-                    term[j] = (wq[i] * wq[j]) * mv[j];
+                    Rc[bj * 64] += (wx * wy[j]) * mv[j];
                 }
-                // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
-                // same orientation sees the earlier sum; few instructions, the latency is covered by the other waves
-#pragma unroll
-                for (int j = 0; j < 8; j++) if (ob[j] < MOT_NORI) Rc[ob[j] * 64] += term[j];
             }
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
