@@ -42,7 +42,11 @@ struct SpShared {
     unsigned short zmask[MK_MAXN];           // zeros of a row as a mask over its candidates
     short starColOfRow[MK_MAXN], starRowOfCol[MK_MAXN], primeColOfRow[MK_MAXN];
     unsigned short clist[MK_MAXN];
-    int cnt[MK_MAXN];                        // set-up only: fill cursors
+    int cnt[MK_MAXN];                        // set-up: fill cursors, then minSimple; event loop: row stamps of a batch (INT_MAX when idle)
+    unsigned char starK[MK_MAXN], primeK[MK_MAXN];   // candidate index of a row's starred / primed zero
+    unsigned ph32[MK_MAXW * 2];              // batch path: LDS copy of the columns uncovered in this phase
+    unsigned dirty32[MK_MAXW * 2];           // columns whose zero masks a step 5 changed (wave 0 refreshes their hz bits)
+    unsigned short blist[64];                // batch path: the candidate columns of one batch, ascending
     int wave_tot[MK_THREADS / 64];
     int flag[8];
 };
@@ -53,7 +57,7 @@ static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certi
 __device__ __forceinline__ bool bit_of(const u64* m, int i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
 __device__ __forceinline__ void lds_clear_bit64(u64* words, int i) { atomicAnd(reinterpret_cast<unsigned*>(words) + (i >> 5), ~(1u << (i & 31))); }
 
-__global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
+__global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int mk_batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_raw[];
     SpShared& S = *reinterpret_cast<SpShared*>(sp_raw);
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     S.cnt[tid] = 0; S.tzero[tid] = 0; S.Scol[tid] = 0.0;
     S.starColOfRow[tid] = -1; S.starRowOfCol[tid] = -1; S.primeColOfRow[tid] = -1;
     if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
+    if (tid < MK_MAXW * 2) S.dirty32[tid] = 0;
     __syncthreads();
     double dv[SPK]; unsigned short myc[SPK];
     unsigned zm = 0;
@@ -144,14 +149,17 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
                 unsigned key = 0xFFFFu;
                 if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (minSimple[c] > rr && S.starRowOfCol[c] < 0) key = (unsigned)c; }
+                const unsigned mykey = key;
                 key = wave_min_u32_dpp(key);
                 if (lane == 0 && key != 0xFFFFu) { S.starColOfRow[rr] = (short)key; S.starRowOfCol[key] = (short)rr; }
+                if (mykey == key && key != 0xFFFFu) S.starK[rr] = (unsigned char)lane;
             }
         }
         __syncthreads();
         // simple rows: the lowest claimant of a column stars it unless a complex row holds it
-        if (r < nR && nz == 1 && minSimple[fz] == r && S.starRowOfCol[fz] < 0) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; }
+        if (r < nR && nz == 1 && minSimple[fz] == r && S.starRowOfCol[fz] < 0) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; S.starK[r] = (unsigned char)(__ffs((int)zm) - 1); }
         __syncthreads();
+        S.cnt[tid] = 0x7FFFFFFF;                                           // from here on: the batch path's row stamps
     }
     {   // step 2a: covered columns = starred columns; hz = hzAll = columns that hold a zero
         const bool has = tid < nC && S.starRowOfCol[tid] >= 0;
@@ -164,11 +172,13 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
     for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
     bool done = ncov == nR;
     int n_prime = 0, n_s5 = 0, n_aug = 0; long long t_s3 = 0, t_s5 = 0;
+    long long t_bat = 0, t_seq = 0, t_augm = 0, t_hz = 0, t_tail = 0, t_p1 = 0; int n_bat = 0, n_seq = 0;   // (debug split of the event loop)
     const long long t_setup = wall_clock64() - t_begin;
     // Wavefront 0 keeps the 1024-bit masks as 32-bit words, lane l (and its mirror l + 32) holding word l & 31: covered columns /
     // rows, columns uncovered in this phase, columns with a live zero (hzr) / with any zero (hzAllr).  Mirroring the upper half lets
     // every lane store its word to the LDS copies without a branch.
-    unsigned* covR32 = reinterpret_cast<unsigned*>(S.covR); unsigned* covC32 = reinterpret_cast<unsigned*>(S.covC);
+    unsigned* covR32 = reinterpret_cast<unsigned*>(S.covR); unsigned* covC32 = reinterpret_cast<unsigned*>(S.covC); unsigned* hz32 = reinterpret_cast<unsigned*>(S.hz);
+    const bool batch_on = mk_batch != 0;
     const int l5 = lane & 31;
     const unsigned vC = (l5 * 32 + 32 <= nC) ? ~0u : (l5 * 32 >= nC ? 0u : ((1u << (nC & 31)) - 1u));
     unsigned cC = covC32[l5], cR = 0, ph = 0;
@@ -182,28 +192,137 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         if (wave == 0) {
             int action = 0; bool found = false;
             unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
-            if (hz_dirty) {                                            // after a step 5: one pass over the column masks
-                unsigned nl = 0, na = 0;
-#pragma unroll
-                for (int w = 0; w < MK_MAXW; w++) {
-                    const u64 bl = __ballot(S.tlive[w * 64 + lane] != 0), ba = __ballot(S.tzero[w * 64 + lane] != 0);
-                    if (l5 == 2 * w) { nl = (unsigned)bl; na = (unsigned)ba; }
-                    if (l5 == 2 * w + 1) { nl = (unsigned)(bl >> 32); na = (unsigned)(ba >> 32); }
+            const long long th0 = wall_clock64();
+            if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
+                // every lane owns word l5 of the masks (the mirror lane recomputes the same), so no cross-lane traffic is needed
+                for (unsigned dw = *reinterpret_cast<volatile unsigned*>(&S.dirty32[l5]); dw; dw &= dw - 1) {
+                    const int b = __ffs((int)dw) - 1, c = l5 * 32 + b;
+                    const unsigned bit = 1u << b;
+                    hzr = S.tlive[c] ? (hzr | bit) : (hzr & ~bit);
+                    hzAllr = S.tzero[c] ? (hzAllr | bit) : (hzAllr & ~bit);
                 }
-                hzr = nl; hzAllr = na; hz_dirty = false;
+                S.dirty32[l5] = 0;
+                hz_dirty = false;
             }
+            const long long th1 = wall_clock64();
+            t_hz += th1 - th0;
+            // step 4 (:283-334) for the primed, unstarred (row, col); afterwards every row is uncovered again and the sweep restarts
+            auto augment = [&](int row, int col) {
+                const long long ta0 = wall_clock64();
+                n_aug++;
+                int last = col;
+                if (lane == 0) {
+                    int cr = row, cc = col;
+                    for (int it = 0; it <= nR + nC; it++) {
+                        const int old_r = S.starRowOfCol[cc];
+                        S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr; S.starK[cr] = S.primeK[cr];
+                        if (old_r < 0) break;
+                        cc = S.primeColOfRow[old_r]; cr = old_r;
+                        if (cc < 0) break;
+                    }
+                    last = cc;
+                }
+                last = __builtin_amdgcn_readfirstlane(last);
+                if (lane < 32) { unsigned t = cR; while (t) { const int r2 = lane * 32 + __ffs((int)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
+                S.primeColOfRow[row] = -1;
+                cR = 0; covR32[l5] = 0;
+                cC |= ph; if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);   // step 2a: every starred column is covered again
+                ph = 0;
+                hzr = hzAllr;
+                for (int i = lane; i < nC; i += 64) S.tlive[i] = S.tzero[i];      // all rows uncovered again (:324-330)
+                fm = ~0u; found = false;
+                t_augm += wall_clock64() - ta0;
+                return ++nstar == nR;                                  // step 2b
+            };
             while (action == 0) {
                 if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
                 const unsigned cand = hzr & ~cC & vC & fm;
                 const unsigned cb = (unsigned)__ballot(cand != 0);     // (the upper half mirrors the lower one)
                 if (!cb) { if (found) { found = false; fm = ~0u; continue; } action = 2; break; }
+                // three or more candidate columns in front of the sweep?  (non-empty words are counted on the scalar side; the
+                // per-lane prefix counts of the batch path come later, only when they are needed)
+                int total = 0;
+                if (batch_on) {
+                    const int nw = __popc(cb);
+                    if (nw >= 3) total = 3;
+                    else {
+                        const int w0 = __ffs((int)cb) - 1;
+                        total = __popc((unsigned)__builtin_amdgcn_readlane((int)cand, w0));
+                        if (nw == 2) total += __popc((unsigned)__builtin_amdgcn_readlane((int)cand, 31 - __clz((int)cb)));
+                    }
+                }
+                const long long te0 = wall_clock64();
+                if (total >= 3) {
+                    n_bat++;
+                    // ---------- BATCH: up to 64 consecutive events of this sweep at once (lane = event).  Taken together are the events
+                    // of the first f candidate columns such that (1) their first uncovered zero rows are pairwise different, (2) no row but
+                    // possibly the last one is unstarred, (3) no column uncovered by one of them (its row's star column) that still has a
+                    // live zero lies in front of a later one -- then no event changes what a later one of the batch sees, and covers,
+                    // primes and live masks end exactly as after the f sequential iterations (CPU model: mks_solve_batched). ----------
+                    covC32[l5] = cC; S.ph32[l5] = ph; hz32[l5] = hzr;  // the LDS copies take the updates
+                    int before = 0; total = 0;                         // candidates in lower words / in all words (counts of the 32 words, bit-sliced through ballots)
+                    {
+                        const int pc = lane < 32 ? __popc(cand) : 0;
+                        const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+                        for (int bb = 0; bb < 6; bb++) { const u64 mb = __ballot((pc >> bb) & 1); before += __popcll(mb & lt) << bb; total += __popcll(mb) << bb; }
+                    }
+                    if (lane < 32) { unsigned t = cand; int o = before; while (t && o < 64) { S.blist[o++] = (unsigned short)(lane * 32 + __ffs((int)t) - 1); t &= t - 1; } }
+                    const int ncand = min(total, 64);
+                    const bool act = lane < ncand;
+                    const int col = act ? (int)*reinterpret_cast<volatile unsigned short*>(&S.blist[lane]) : 0;
+                    const unsigned tlv = S.tlive[col];
+                    const unsigned e = S.tl[col * SP_TLS + (tlv ? __ffs((int)tlv) - 1 : 0)];
+                    if (__ballot(act && tlv == 0)) { action = 4; break; }   // hz out of step with the masks: cannot happen
+                    const int row = (int)(e >> 4) & (MK_MAXN - 1), ke = (int)(e & 15);
+                    const int sc = S.starColOfRow[row];
+                    const unsigned m = S.zmask[row];
+                    if (act) atomicMin(&S.cnt[row], lane);                 // the first event that wants a row owns it
+                    const unsigned tls = S.tlive[sc >= 0 ? sc : 0];
+                    const unsigned psb = 1u << S.pos[(int)(S.starK[row] & (SPK - 1)) * MK_MAXN + row];   // (meaningless, and unused, for an unstarred row)
+                    const int owner = *reinterpret_cast<volatile int*>(&S.cnt[row]);
+                    const unsigned limit = (act && sc > col && (tls & ~psb)) ? (unsigned)sc : 0x7FFFFFFFu;
+                    const unsigned smin = wave_min_u32_dpp(limit);
+                    const u64 stop = __ballot(act && ((unsigned)col > smin || owner != lane));
+                    const u64 augm = __ballot(act && sc < 0);
+                    int f = stop ? __ffsll((long long)stop) - 1 : ncand;
+                    const int ia = augm ? __ffsll((long long)augm) - 1 : 64;
+                    f = min(f, ia + 1);
+                    if (act) S.cnt[row] = 0x7FFFFFFF;
+                    if (lane < f) { S.primeColOfRow[row] = (short)col; S.primeK[row] = (unsigned char)ke; }   // :255
+                    if (lane < f && sc >= 0) {                         // cover the row (:270), uncover its star's column (:271)
+                        atomicOr(&covR32[row >> 5], 1u << (row & 31));
+                        atomicAnd(&covC32[sc >> 5], ~(1u << (sc & 31)));
+                        atomicOr(&S.ph32[sc >> 5], 1u << (sc & 31));
+                        for (unsigned mm = m; mm; mm &= mm - 1) {          // its zeros leave the live masks
+                            const int kk = __ffs((int)mm) - 1, c2 = S.cj[kk * MK_MAXN + row];
+                            const unsigned bitv = 1u << S.pos[kk * MK_MAXN + row];
+                            if (atomicAnd(&S.tlive[c2], ~bitv) == bitv) atomicAnd(&hz32[c2 >> 5], ~(1u << (c2 & 31)));
+                        }
+                    }
+                    n_prime += f - 1;
+                    cR = *reinterpret_cast<volatile unsigned*>(&covR32[l5]); cC = *reinterpret_cast<volatile unsigned*>(&covC32[l5]);
+                    ph = *reinterpret_cast<volatile unsigned*>(&S.ph32[l5]); hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
+                    t_bat += wall_clock64() - te0;
+                    if (ia < f) {
+                        if (augment(__builtin_amdgcn_readlane(row, ia), __builtin_amdgcn_readlane(col, ia))) { action = 3; break; }
+                        continue;
+                    }
+                    found = true;
+                    {   // the sweep continues behind the last column taken (:273)
+                        const int from = __builtin_amdgcn_readlane(col, f - 1) + 1, fw = from >> 5;
+                        fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
+                    }
+                    continue;
+                }
                 const int cw = __ffs((int)cb) - 1;
                 const int col = cw * 32 + __ffs(__builtin_amdgcn_readlane((int)cand, cw)) - 1;
                 // first uncovered row holding a zero in this column: ONE LDS round trip (every lane issues both loads, no branch between them)
                 const unsigned tlv = S.tlive[col];
                 const unsigned tle = S.tl[col * SP_TLS + l5];
                 const unsigned lv = (unsigned)__builtin_amdgcn_readfirstlane((int)tlv);
-                const int row = __builtin_amdgcn_readlane((int)tle, lv ? __ffs((int)lv) - 1 : 0) >> 4;   // (before the check: both loads are issued together)
+                const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)tle, lv ? __ffs((int)lv) - 1 : 0);   // (before the check: both loads are issued together)
+                const int row = (int)(ent >> 4);
                 if (lv == 0) { action = 4; break; }                    // hz out of step with the masks: cannot happen
                 // the row's star, its zeros and where they sit in their columns' lists: one more round trip, all loads issued together
                 const int kk = lane & (SPK - 1);
@@ -214,31 +333,11 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                 const int sc = __builtin_amdgcn_readfirstlane(sc_v);
                 const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)m_v);
                 S.primeColOfRow[row] = (short)col;                     // :255 (every lane stores the same value)
+                S.primeK[row] = (unsigned char)(ent & 15);
+                n_seq++;
                 if (sc < 0) {
-                    // ---------- step 4 (:283-334) ----------
-                    n_aug++;
-                    int last = col;
-                    if (lane == 0) {
-                        int cr = row, cc = col;
-                        for (int it = 0; it <= nR + nC; it++) {
-                            const int old_r = S.starRowOfCol[cc];
-                            S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr;
-                            if (old_r < 0) break;
-                            cc = S.primeColOfRow[old_r]; cr = old_r;
-                            if (cc < 0) break;
-                        }
-                        last = cc;
-                    }
-                    last = __builtin_amdgcn_readfirstlane(last);
-                    if (lane < 32) { unsigned t = cR; while (t) { const int r2 = lane * 32 + __ffs((int)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
-                    S.primeColOfRow[row] = -1;
-                    cR = 0; covR32[l5] = 0;
-                    cC |= ph; if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);   // step 2a: every starred column is covered again
-                    ph = 0;
-                    hzr = hzAllr;
-                    for (int i = lane; i < nC; i += 64) S.tlive[i] = S.tzero[i];      // all rows uncovered again (:324-330)
-                    if (++nstar == nR) { action = 3; break; }          // step 2b
-                    fm = ~0u; found = false;
+                    t_seq += wall_clock64() - te0;
+                    if (augment(row, col)) { action = 3; break; }
                     continue;
                 }
                 // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
@@ -259,7 +358,9 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                     const int from = col + 1, fw = from >> 5;
                     fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
                 }
+                t_seq += wall_clock64() - te0;
             }
+            t_tail += wall_clock64() - th1;                               // (debug: the whole event loop of this cycle)
             covC32[l5] = cC;
             if (lane == 0) { S.flag[1] = action; S.hkey = ~0ull; }
         }
@@ -283,6 +384,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
             const u64 hk = wave_min_u64_dpp(dkey(h));
             if (lane == 0) atomicMin(&S.hkey, hk);
         }
+        t_p1 += wall_clock64() - t_b;
         __syncthreads();
         h = dunkey(S.hkey);
         if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
@@ -304,6 +406,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
                     const unsigned bitv = 1u << S.pos[k * MK_MAXN + r];
                     if ((nm >> k) & 1) { atomicOr(&S.tzero[myc[k]], bitv); if (!rc) atomicOr(&S.tlive[myc[k]], bitv); }
                     else { atomicAnd(&S.tzero[myc[k]], ~bitv); if (!rc) atomicAnd(&S.tlive[myc[k]], ~bitv); }
+                    atomicOr(&S.dirty32[myc[k] >> 5], 1u << (myc[k] & 31));
                 }
             }
             zm = nm; S.zmask[r] = (unsigned short)nm;
@@ -320,7 +423,9 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a)
         L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
         L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
         L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
-        L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
+        L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);
+        L.hdr[60] = (int)t_hz; L.hdr[61] = (int)t_p1; L.hdr[62] = (int)t_tail;
+        L.hdr[55] = (int)t_bat; L.hdr[56] = (int)t_seq; L.hdr[57] = (int)t_augm; L.hdr[58] = n_bat; L.hdr[59] = n_seq;   // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
     }
 }
 
@@ -385,7 +490,9 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_dev = dev;
     }
-    hipLaunchKernelGGL(mk_sparse_kernel, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a);
+    static int batch = -1;                                             // MOT_MK_BATCH=0: one event per iteration of the sparse emulation's event loop
+    if (batch < 0) { const char* ev = getenv("MOT_MK_BATCH"); batch = (ev && atoi(ev) == 0) ? 0 : 1; }
+    hipLaunchKernelGGL(mk_sparse_kernel, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch);
     hipLaunchKernelGGL(mk_postcheck_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -13,6 +13,7 @@
  * the step is still positive, so it was strictly above h), hence the dense run and the sparse run are the same run.
  * The check is done after the fact with the final S_j; if it fails the caller must run the dense emulation.
  */
+#include <stdio.h>
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
@@ -20,11 +21,11 @@
 
 #define MKS_KMAX 16
 
-typedef struct { int status; /* 0 ok, 1 a-posteriori check failed, 2 not applicable */ long primes, s5, aug; double maxS; } mks_info;
+typedef struct { int status; /* 0 ok, 1 a-posteriori check failed, 2 not applicable */ long primes, s5, aug; double maxS; long iters; /* batched variant: event-loop iterations */ } mks_info;
 
 static int cmp_cand(double a, int ja, double b, int jb) { return a < b || (a == b && ja < jb); }
 
-int mks_solve(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info)
+static int mks_run(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info, int batch)
 {
     memset(info, 0, sizeof *info);
     for (int i = 0; i < nR; i++) assignment[i] = -1;
@@ -62,6 +63,73 @@ int mks_solve(const double* c, int nR, int nC, int K, double margin, int* assign
     { int* cur = malloc(sizeof(int) * (size_t)nC); memcpy(cur, tptr, sizeof(int) * (size_t)nC);
       for (int r = 0; r < nR; r++) for (int k = 0; k < K; k++) { const int j = cj[r * K + k]; trow[cur[j]] = r; tk[cur[j]] = k; cur[j]++; }
       free(cur); }
+    if (batch) {
+        /* The device's BATCHED event loop (mk_sparse.hip): up to `batch` consecutive events of one sweep are taken together when
+         * they cannot influence each other -- distinct first rows, every row but possibly the last one starred, and no column
+         * uncovered by an earlier event of the batch that could produce an event of its own before a later column of the batch.
+         * Same primes, covers and augmentations in the same order as the loop below; only the iteration count differs. */
+        int* bc = malloc(sizeof(int) * (size_t)batch), *br = malloc(sizeof(int) * (size_t)batch), *bs = malloc(sizeof(int) * (size_t)batch);
+        int from = 0, found = 0, nstar = 0;
+        for (int j = 0; j < nC; j++) nstar += covC[j];
+        while (nstar < nR) {
+            /* candidates: uncovered columns >= from with a live zero, ascending */
+            int nc = 0;
+            for (int col = from; col < nC && nc < batch; col++) {
+                if (covC[col]) continue;
+                for (int t = tptr[col]; t < tptr[col + 1]; t++) {
+                    const int r = trow[t];
+                    if (covR[r] || !ISZ(r, tk[t])) continue;
+                    bc[nc] = col; br[nc] = r; bs[nc] = starC[r]; nc++;
+                    break;
+                }
+            }
+            info->iters++;
+            if (!nc) {
+                if (found) { found = 0; from = 0; continue; }
+                double h = DBL_MAX;                                        /* step 5 (:337-368) */
+                for (int r = 0; r < nR; r++) if (!covR[r]) for (int k = 0; k < K; k++) if (!covC[cj[r * K + k]] && d[r * K + k] < h) h = d[r * K + k];
+                if (h == DBL_MAX) { info->status = 1; free(bc); free(br); free(bs); goto out; }
+                for (int r = 0; r < nR; r++) for (int k = 0; k < K; k++) {
+                    double x = d[r * K + k];
+                    if (covR[r]) x += h;
+                    if (!covC[cj[r * K + k]]) x -= h;
+                    d[r * K + k] = x;
+                }
+                for (int j = 0; j < nC; j++) if (!covC[j]) S[j] += h;
+                info->s5++;
+                from = 0; found = 0;
+                continue;
+            }
+            /* the longest prefix that is safe to take at once */
+            int f = nc, smin = 0x7FFFFFFF;
+            for (int q = 0; q < nc; q++) {
+                if (bs[q] < 0 || bs[q] <= bc[q]) continue;
+                int live = 0;                                              /* a live zero in the star's column besides the row being covered */
+                for (int t = tptr[bs[q]]; t < tptr[bs[q] + 1]; t++) { const int r = trow[t]; if (r != br[q] && !covR[r] && ISZ(r, tk[t])) { live = 1; break; } }
+                if (live && bs[q] < smin) smin = bs[q];
+            }
+            for (int q = 0; q < nc; q++) {
+                int stop = bc[q] > smin;
+                for (int i = 0; i < q && !stop; i++) if (br[i] == br[q]) stop = 1;
+                if (stop) { f = q; break; }
+                if (bs[q] < 0) { f = q + 1; break; }
+            }
+            if (getenv("MKS_DEBUG")) { int why = 0; if (f < nc) { if (bc[f] > smin) why = 1; else why = 2; } if (f > 0 && bs[f - 1] < 0) why = 3; fprintf(stderr, "nc %d f %d why %d\n", nc, f, why); }
+            for (int q = 0; q < f; q++) {
+                const int r = br[q], col = bc[q];
+                primeC[r] = col; info->primes++;
+                if (starC[r] < 0) {                                        /* step 4 (:283-334) */
+                    info->aug++;
+                    int cr = r, cc = col;
+                    for (;;) { const int old_r = starR[cc]; starC[cr] = cc; starR[cc] = cr; if (old_r < 0) break; cc = primeC[old_r]; cr = old_r; }
+                    for (int z = 0; z < nR; z++) { primeC[z] = -1; covR[z] = 0; }
+                    for (int z = 0; z < nC; z++) covC[z] = starR[z] >= 0;
+                    nstar++; from = 0; found = 0;
+                } else { covR[r] = 1; covC[starC[r]] = 0; found = 1; from = col + 1; }
+            }
+        }
+        free(bc); free(br); free(bs);
+    } else
     for (;;) {
         int n = 0; for (int j = 0; j < nC; j++) n += covC[j];
         if (n == nR) break;                                            /* step 2b (:216-237) */
@@ -114,6 +182,11 @@ int mks_solve(const double* c, int nR, int nC, int K, double margin, int* assign
     for (int j = 0; j < nC; j++) if (S[j] > info->maxS) info->maxS = S[j];
 out:
     if (!info->status) for (int r = 0; r < nR; r++) assignment[r] = starC[r];
+    (void)0;
     free(cj); free(d); free(rowmin); free(covC); free(covR); free(starC); free(starR); free(primeC); free(S); free(tptr); free(trow); free(tk);
     return info->status;
 }
+
+int mks_solve(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info) { return mks_run(c, nR, nC, K, margin, assignment, info, 0); }
+/* same run with the event loop taken `batch` (<= 64 on the device) events at a time where that is provably order-neutral */
+int mks_solve_batched(const double* c, int nR, int nC, int K, double margin, int batch, int* assignment, mks_info* info) { return mks_run(c, nR, nC, K, margin, assignment, info, batch < 1 ? 1 : batch); }
