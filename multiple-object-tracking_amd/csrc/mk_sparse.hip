@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
     for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
     bool done = ncov == nR;
     int n_prime = 0, n_s5 = 0, n_aug = 0; long long t_s3 = 0, t_s5 = 0;
-    long long t_bat = 0, t_seq = 0, t_augm = 0, t_hz = 0, t_tail = 0, t_p1 = 0; int n_bat = 0, n_seq = 0;   // (debug split of the event loop)
+    int n_bat = 0, n_seq = 0;                                           // (debug: iterations of the batch / the one-event path)   // (debug split of the event loop)
     const long long t_setup = wall_clock64() - t_begin;
     // Wavefront 0 keeps the 1024-bit masks as 32-bit words, lane l (and its mirror l + 32) holding word l & 31: covered columns /
     // rows, columns uncovered in this phase, columns with a live zero (hzr) / with any zero (hzAllr).  Mirroring the upper half lets
@@ -192,7 +192,6 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
         if (wave == 0) {
             int action = 0; bool found = false;
             unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
-            const long long th0 = wall_clock64();
             if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
                 // every lane owns word l5 of the masks (the mirror lane recomputes the same), so no cross-lane traffic is needed
                 for (unsigned dw = *reinterpret_cast<volatile unsigned*>(&S.dirty32[l5]); dw; dw &= dw - 1) {
@@ -204,11 +203,8 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                 S.dirty32[l5] = 0;
                 hz_dirty = false;
             }
-            const long long th1 = wall_clock64();
-            t_hz += th1 - th0;
             // step 4 (:283-334) for the primed, unstarred (row, col); afterwards every row is uncovered again and the sweep restarts
             auto augment = [&](int row, int col) {
-                const long long ta0 = wall_clock64();
                 n_aug++;
                 int last = col;
                 if (lane == 0) {
@@ -223,15 +219,21 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                     last = cc;
                 }
                 last = __builtin_amdgcn_readfirstlane(last);
-                if (lane < 32) { unsigned t = cR; while (t) { const int r2 = lane * 32 + __ffs((int)t) - 1; S.primeColOfRow[r2] = -1; t &= t - 1; } }
+                // every covered row loses its prime and is uncovered again (:324-330): the live masks of the columns that hold its zeros
+                // go back to the zero masks (tlive == tzero & ~(slots of covered rows) everywhere, so no other column differs)
+                if (lane < 32) {
+                    for (unsigned t = cR; t; t &= t - 1) {
+                        const int r2 = lane * 32 + __ffs((int)t) - 1;
+                        S.primeColOfRow[r2] = -1;
+                        for (unsigned mm = S.zmask[r2]; mm; mm &= mm - 1) { const int c2 = S.cj[(__ffs((int)mm) - 1) * MK_MAXN + r2]; S.tlive[c2] = S.tzero[c2]; }
+                    }
+                }
                 S.primeColOfRow[row] = -1;
                 cR = 0; covR32[l5] = 0;
                 cC |= ph; if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);   // step 2a: every starred column is covered again
                 ph = 0;
                 hzr = hzAllr;
-                for (int i = lane; i < nC; i += 64) S.tlive[i] = S.tzero[i];      // all rows uncovered again (:324-330)
                 fm = ~0u; found = false;
-                t_augm += wall_clock64() - ta0;
                 return ++nstar == nR;                                  // step 2b
             };
             while (action == 0) {
@@ -251,7 +253,6 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                         if (nw == 2) total += __popc((unsigned)__builtin_amdgcn_readlane((int)cand, 31 - __clz((int)cb)));
                     }
                 }
-                const long long te0 = wall_clock64();
                 if (total >= 3) {
                     n_bat++;
                     // ---------- BATCH: up to 64 consecutive events of this sweep at once (lane = event).  Taken together are the events
@@ -303,7 +304,6 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                     n_prime += f - 1;
                     cR = *reinterpret_cast<volatile unsigned*>(&covR32[l5]); cC = *reinterpret_cast<volatile unsigned*>(&covC32[l5]);
                     ph = *reinterpret_cast<volatile unsigned*>(&S.ph32[l5]); hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
-                    t_bat += wall_clock64() - te0;
                     if (ia < f) {
                         if (augment(__builtin_amdgcn_readlane(row, ia), __builtin_amdgcn_readlane(col, ia))) { action = 3; break; }
                         continue;
@@ -336,7 +336,6 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                 S.primeK[row] = (unsigned char)(ent & 15);
                 n_seq++;
                 if (sc < 0) {
-                    t_seq += wall_clock64() - te0;
                     if (augment(row, col)) { action = 3; break; }
                     continue;
                 }
@@ -358,9 +357,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                     const int from = col + 1, fw = from >> 5;
                     fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
                 }
-                t_seq += wall_clock64() - te0;
             }
-            t_tail += wall_clock64() - th1;                               // (debug: the whole event loop of this cycle)
             covC32[l5] = cC;
             if (lane == 0) { S.flag[1] = action; S.hkey = ~0ull; }
         }
@@ -384,7 +381,6 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
             const u64 hk = wave_min_u64_dpp(dkey(h));
             if (lane == 0) atomicMin(&S.hkey, hk);
         }
-        t_p1 += wall_clock64() - t_b;
         __syncthreads();
         h = dunkey(S.hkey);
         if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
@@ -424,8 +420,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
         L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
         L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
         L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);
-        L.hdr[60] = (int)t_hz; L.hdr[61] = (int)t_p1; L.hdr[62] = (int)t_tail;
-        L.hdr[55] = (int)t_bat; L.hdr[56] = (int)t_seq; L.hdr[57] = (int)t_augm; L.hdr[58] = n_bat; L.hdr[59] = n_seq;   // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
+        L.hdr[58] = n_bat; L.hdr[59] = n_seq;                             // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
     }
 }
 

@@ -114,7 +114,8 @@ static int mks_run(const double* c, int nR, int nC, int K, double margin, int* a
                 if (stop) { f = q; break; }
                 if (bs[q] < 0) { f = q + 1; break; }
             }
-            if (getenv("MKS_DEBUG")) { int why = 0; if (f < nc) { if (bc[f] > smin) why = 1; else why = 2; } if (f > 0 && bs[f - 1] < 0) why = 3; fprintf(stderr, "nc %d f %d why %d\n", nc, f, why); }
+            static int dbg = -1; if (dbg < 0) dbg = getenv("MKS_DEBUG") != NULL;
+            if (dbg) { int why = 0; if (f < nc) { if (bc[f] > smin) why = 1; else why = 2; } if (f > 0 && bs[f - 1] < 0) why = 3; fprintf(stderr, "nc %d f %d why %d\n", nc, f, why); }
             for (int q = 0; q < f; q++) {
                 const int r = br[q], col = bc[q];
                 primeC[r] = col; info->primes++;

@@ -1,0 +1,62 @@
+"""CPU checks of the sparse order-exact Munkres emulation's model (oracle/mk_sparse_model.c, a CPU model of csrc/mk_sparse.hip)
+against the oracle's dense order-exact Munkres (oracle/mot_oracle.c:orc_assignment_optimal, hungarian.cpp:29-368).
+
+Properties: (1) status == 0 (the a-posteriori check of every non-candidate entry passed) implies assignment == reference
+assignment; (2) the BATCHED event loop (what the device runs: up to 64 order-neutral step-3 events per iteration) performs exactly
+the primes, step-5 passes and augmentations of the one-event-at-a-time loop and ends with the same assignment."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from orc import P
+from test_lap_model import mm
+
+
+class MksInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("primes", C.c_long), ("s5", C.c_long), ("aug", C.c_long), ("maxS", C.c_double), ("iters", C.c_long)]
+
+
+@pytest.fixture(scope="module")
+def mks():
+    orc.build_oracle()
+    so = os.path.join(orc.ORACLE_DIR, "libmk_sparse_model.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(orc.ORACLE_DIR, "mk_sparse_model.c")):
+        subprocess.check_call(["make", "-C", orc.ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+    return C.CDLL(so)
+
+
+def run(lib, d, nr, nc, batch):
+    a = np.full(max(nr, 1), -1, np.int32)
+    info = MksInfo()
+    d = np.ascontiguousarray(d, np.float64)
+    margin = C.c_double(1e-9 * (1.0 + float(d.max()) if d.size else 1.0))
+    if batch:
+        lib.mks_solve_batched(P(d), nr, nc, 8, margin, batch, P(a), C.byref(info))
+    else:
+        lib.mks_solve(P(d), nr, nc, 8, margin, P(a), C.byref(info))
+    return a[:nr], info
+
+
+def test_sparse_model_vs_oracle_and_batched_loop(mks):
+    lib = orc.load_oracle()
+    rng = np.random.default_rng(20261003)
+    accepted = batched_shorter = 0
+    for it in range(700):
+        kind = int(rng.integers(0, 9))
+        nr = int(rng.integers(1, 90)); nc = nr + int(rng.integers(0, 12))
+        d = mm(rng, nr, nc, kind)
+        a0, i0 = run(mks, d, nr, nc, 0)
+        for b in (64, 2):
+            a1, i1 = run(mks, d, nr, nc, b)
+            assert (i0.status, i0.primes, i0.s5, i0.aug) == (i1.status, i1.primes, i1.s5, i1.aug), (it, kind, nr, nc, b)
+            assert np.array_equal(a0, a1), (it, kind, nr, nc, b)
+            batched_shorter += (b == 64 and i1.iters < i0.primes + i0.s5)
+        if i0.status == 0:
+            ref, _ = orc.assignment_optimal(lib, d, nr, nc)
+            assert np.array_equal(a0, ref), (it, kind, nr, nc)
+            accepted += 1
+    assert accepted > 100 and batched_shorter > 20, (accepted, batched_shorter)
