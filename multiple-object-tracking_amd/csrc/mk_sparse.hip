@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
     if (tid < MK_MAXW * 2) S.dirty32[tid] = 0;
     __syncthreads();
     double dv[SPK]; unsigned short myc[SPK];
-    unsigned zm = 0;
+    unsigned zm = 0, vk = 0;                                           // zero / present bits of the row's candidates
 #pragma unroll
     for (int k = 0; k < SPK; k++) { dv[k] = DBL_MAX; myc[k] = 0xFFFF; }
     if (r < nR) {
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
             myc[k] = L.ccol[(size_t)r * SPK + k];
-            if (myc[k] != 0xFFFF) { dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
+            if (myc[k] != 0xFFFF) { vk |= 1u << k; dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
         }
     }
 #pragma unroll
@@ -369,13 +369,18 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
         if (action == 4) { status = 2; break; }
         // ================= step 5 (:337-368) on the candidate entries: thread = row =================
         n_s5++;
+        // straight-line code (no per-candidate predication): an absent candidate has the value DBL_MAX, counts as covered and is
+        // carried through the update unchanged in effect (DBL_MAX + h == DBL_MAX); "x + 0.0" / "x - 0.0" are exact, so selecting
+        // the addend instead of the operation gives the reference's bits (:355-364)
         const bool rc = bit_of(S.covR, r);
         bool unc[SPK];
         double h = DBL_MAX;
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
-            unc[k] = myc[k] != 0xFFFF && !bit_of(S.covC, myc[k]);
-            if (!rc && unc[k] && dv[k] < h) h = dv[k];
+            const int cc = myc[k] & (MK_MAXN - 1);                     // (0xFFFF -> a valid index; masked out by vk)
+            unc[k] = ((vk >> k) & 1) && !((covC32[cc >> 5] >> (cc & 31)) & 1u);
+            const double cand_v = (!rc && unc[k]) ? dv[k] : DBL_MAX;
+            h = cand_v < h ? cand_v : h;
         }
         {
             const u64 hk = wave_min_u64_dpp(dkey(h));
@@ -385,15 +390,12 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
         h = dunkey(S.hkey);
         if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
         unsigned nm = 0;
+        const double hr = rc ? h : 0.0;
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
-            if (myc[k] != 0xFFFF) {
-                double x = dv[k];
-                if (rc) x += h;                                        // :355-358
-                if (unc[k]) x -= h;                                    // :361-364
-                dv[k] = x;
-                if (fabs(x) < DBL_EPSILON) nm |= 1u << k;
-            }
+            const double x = (dv[k] + hr) - (unc[k] ? h : 0.0);        // :355-358, :361-364
+            dv[k] = x;
+            nm |= (fabs(x) < DBL_EPSILON) ? (1u << k) : 0u;
         }
         if (nm != zm) {                                                // zero bits that changed: the column-side masks follow
 #pragma unroll
