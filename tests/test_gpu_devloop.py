@@ -238,3 +238,37 @@ def test_device_loop_empty_and_bursty_frames(mot, oracle, kind):
         assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
     assert len(ref["tids"]) == 0, "every track must have been dropped by the lost rule"
     m.close(); c.close()
+
+
+def test_device_loop_per_track_sizes_two_ranks_on_one_gpu(mot, oracle):
+    """per-track template sizes AND the tid % world shard together: two contexts of one GPU (the all-gather emulated with device
+    copies), 150 tracks of sizes 74..86 with misses and false positives, must equal the unsharded oracle"""
+    from multiple_object_tracking_amd import synth
+    hip = C.CDLL("libamdhip64.so")
+    W, n, lo, hi = 2, 150, 74, 86
+    scene = synth.Scene(n, 80, stream_id=46, det_sizes=(lo, hi), miss_pct=3, fp_pct=2)
+    items = list(scene.frames(6))
+    frames = [f for f, _ in items]; dets = [d[:256] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    ranks = [mot.MotContext(max_tracks=256, max_dets=256, rank=r, world=W, dev_sizes=(lo, hi)) for r in range(W)]
+    m = orc.OracleMot(oracle, 0, 0, 256)
+    for f in range(len(frames)):
+        segs = [c.step_begin_device(fd[f].data_ptr()) for c in ranks]
+        spr = segs[0][1]
+        for c in ranks:
+            c.sync()
+        bases = [segs[r][0] - r * spr * 24 for r in range(W)]
+        for dst in range(W):
+            for src in range(W):
+                if src != dst:
+                    assert hip.hipMemcpy(C.c_void_p(bases[dst] + src * spr * 24), C.c_void_p(segs[src][0]), spr * 24, 3) == 0
+        for r, c in enumerate(ranks):
+            c.step_finish_device(bases[r], dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        for r, c in enumerate(ranks):
+            boxes, tids, _ = c.live_tracks()
+            assert np.array_equal(tids, ref["tids"]), f"frame {f} rank {r}"
+            assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} rank {r}"
+    m.close()
+    for c in ranks:
+        c.close()
