@@ -400,6 +400,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         __syncthreads();
         if (tid == 0) {
             L.hdr[LAP_H_LAST + 15] = mode == 0 ? 0 : (certified ? 1 : 2);   // what this frame used: 0 certificate, 1 sparse emulation, 2 dense emulation
+            if (a.ws.dense_hint) *reinterpret_cast<volatile int*>(a.ws.dense_hint) = certified ? 0 : 1;
             if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
             // re-arm for the next launch (this workgroup is the last reader)
             L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2; *L.cmaxkey = 0ull;
@@ -934,7 +935,10 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
     // behind the fast path the dense emulation is the rare last resort: one workgroup, not the 1 + 128 workgroup helper grid
     // (whose launch alone costs more than the common case's whole final kernel)
-    const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && !lap));
+    // ... unless the stream keeps needing it (detector misses + false positives force far matches no tier can certify): the final
+    // kernel leaves a hint in pinned host memory, read here without synchronisation (stale by a frame or two: it only picks the grid)
+    const bool hinted = lap && ws.dense_hint && *reinterpret_cast<volatile int*>(ws.dense_hint) != 0;
+    const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life, lap ? 1 : 0);
     return hipGetLastError();

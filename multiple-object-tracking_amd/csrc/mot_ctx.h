@@ -58,7 +58,7 @@ struct mot_ctx {
     // staging (capacity = max_tracks + max_dets)
     int stage_cap = 0;
     mot_impl::DevBuf<int> d_slots; mot_impl::DevBuf<bbox_t> d_boxes_a, d_boxes_b, d_dets; mot_impl::DevBuf<float> d_patches; size_t patches_cap = 0;
-    mot_impl::PinBuf<int> h_slots; mot_impl::PinBuf<bbox_t> h_boxes_a, h_boxes_b; mot_impl::PinBuf<int> h_assign; mot_impl::PinBuf<double> h_cost; mot_impl::PinBuf<float> h_patches;
+    mot_impl::PinBuf<int> h_slots; mot_impl::PinBuf<bbox_t> h_boxes_a, h_boxes_b; mot_impl::PinBuf<int> h_assign; mot_impl::PinBuf<int> h_hint; mot_impl::PinBuf<double> h_cost; mot_impl::PinBuf<float> h_patches;
     // association
     AssocWs assoc{}; mot_impl::DevBuf<double> a_dist; mot_impl::DevBuf<unsigned long long> a_zr, a_zc, a_linemin; mot_impl::DevBuf<int> a_assign, a_status; mot_impl::DevBuf<double> a_cost;
     mot_impl::DevBuf<double> a_user; mot_impl::DevBuf<unsigned long long> a_ctl; mot_impl::DevBuf<unsigned char> a_lap;

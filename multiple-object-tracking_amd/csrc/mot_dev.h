@@ -133,6 +133,8 @@ struct AssocWs {
     int* status;              // [16]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow, timers
     unsigned long long* ctl;  // control block + result buffers of the step-5 helper workgroups (MOT_ASSOC_CTL_WORDS u64)
     LapWs lap;                // fast-path workspace (lap.ccol == nullptr: not available)
+    int* dense_hint;          // pinned host int, written by the final kernel: 1 = this launch fell through to the dense emulation (a
+                              // scheduling hint for the NEXT launches -- read by the host without synchronisation, never a result)
 };
 
 // host-side launchers implemented in the .hip files
