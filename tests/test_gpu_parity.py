@@ -122,6 +122,51 @@ def test_kcf_sequence_golden(mot, name, fft_mode):
     c.close()
 
 
+@pytest.mark.parametrize("rows,cols", [(120, 164), (164, 124), (148, 100), (100, 156)])
+def test_kcf_nonsquare_templates_vs_oracle(mot, oracle, rows, cols):
+    """non-square templates, most of them beyond the LDS limit (HBM-slab kernels, MFMA DFT with hb != wb): predict / update of a few
+    tracks from the bound frame against the oracle -- equal arg-max and boxes, response peak within 1e-4 (kcf.cpp:148-152 freezes
+    rows x cols per track; td.cpp:344-384, 512-582)"""
+    from multiple_object_tracking_amd import synth
+    scene = synth.Scene(6, 80, stream_id=9)
+    frames = list(scene.frames(4))
+    frame0, d80 = frames[0]
+    dets0 = []
+    for d in d80:                                                      # same centres, rows x cols boxes inside the frame
+        cy, cx = (d[1] + d[2]) // 2, (d[0] + d[3]) // 2
+        t = min(max(cy - rows // 2, 0), 720 - rows); l = min(max(cx - cols // 2, 0), 1280 - cols)
+        dets0.append((l, t, t + rows - 1, l + cols - 1, d[4], d[5]))
+    c = mot.MotContext(max_tracks=8, max_dets=8)
+    c.frame_upload(frame0)
+    ids = c.tracks_new(dets0)
+    nb = (rows // 4) * (cols // 4)
+    oks = []
+    for d in dets0:
+        b = orc.boxes_array([d])
+        k = C.c_void_p(oracle.orc_kcf_new(P(b), 0))
+        oracle.orc_kcf_update(k, P(orc.crop_patch(oracle, frame0, d, rows, cols)), P(b))
+        oks.append(k)
+    boxes = [tuple(d) for d in dets0]
+    for frame, _ in frames[1:]:
+        c.frame_upload(frame)
+        pred = c.predict_batch(ids, clamp=True)
+        for i, k in enumerate(oks):
+            pb = BBox()
+            oracle.orc_kcf_predict(k, P(orc.crop_patch(oracle, frame, boxes[i], rows, cols)), C.byref(pb))
+            exp = (min(max(pb.l, 0), 1279), min(max(pb.t, 0), 719), min(max(pb.b, 0), 719), min(max(pb.r, 0), 1279), pb.type)
+            assert tuple(boxes_to_np(pred[i:i + 1])[0]) == exp, f"track {i}"
+            resp = c.get_response(ids[i]); ref = orc.arr(oracle.orc_kcf_response(k), nb)
+            assert resp.argmax() == ref.argmax()
+            assert abs(resp.max() - ref.max()) <= PEAK_RTOL * abs(ref.max())
+            boxes[i] = exp + (0.9,)
+        c.update_batch(ids, boxes)
+        for i, k in enumerate(oks):
+            oracle.orc_kcf_update(k, P(orc.crop_patch(oracle, frame, boxes[i], rows, cols)), P(orc.boxes_array([boxes[i]])))
+    for k in oks:
+        oracle.orc_kcf_delete(k)
+    c.close()
+
+
 def test_kcf_batch_from_frame_vs_oracle(mot, oracle):
     """64 tracks in one launch, crops taken on device from the bound frame (td.cpp:344-384,512-582)."""
     from multiple_object_tracking_amd import synth
