@@ -44,6 +44,8 @@ static int cmp_cand(double a, int ja, double b, int jb) { return a < b || (a == 
 static double* g_v_out = 0; static unsigned char* g_touch_out = 0; static double* g_theta_out = 0;   /* optional debug outputs: prices [nC], solver-touched columns [nC] */
 void lapm_debug_outputs(double* v_out, unsigned char* touch_out) { g_v_out = v_out; g_touch_out = touch_out; }
 void lapm_debug_theta(double* t) { g_theta_out = t; }
+static int* g_match_out = 0;                                          /* optional debug output: the solver's matching whatever the verdict */
+void lapm_debug_matching(int* m) { g_match_out = m; }
 
 int lapm_solve(const double* c, int nR, int nC, int K, int S, int* assignment, lapm_info* info)
 {
@@ -217,6 +219,7 @@ int lapm_solve(const double* c, int nR, int nC, int K, int S, int* assignment, l
         if (ncyc) status = 4;
         free(alive); free(hasout);
     }
+    if (g_match_out) for (int i = 0; i < nR; i++) g_match_out[i] = colOfRow[i];
     if (g_v_out) memcpy(g_v_out, v, sizeof(double) * (size_t)nC);
     if (g_touch_out) memcpy(g_touch_out, touchc, (size_t)nC);
     if (g_theta_out) memcpy(g_theta_out, theta, sizeof(double) * (size_t)nC);
