@@ -400,10 +400,12 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         __syncthreads();
         if (tid == 0) {
             L.hdr[LAP_H_LAST + 15] = mode == 0 ? 0 : (certified ? 1 : 2);   // what this frame used: 0 certificate, 1 sparse emulation, 2 dense emulation
-            if (a.ws.dense_hint) *reinterpret_cast<volatile int*>(a.ws.dense_hint) = certified ? 0 : 1;
+            const int outcome = L.hdr[LAP_H_LAST], dense_ran = L.hdr[LAP_H_DENSE];
+            if (dense_ran) { L.hdr[LAP_H_DSTAT + 3] += 1; if (mode == 0) L.hdr[LAP_H_DSTAT + 4] += 1; }
+            if (a.ws.dense_hint) *reinterpret_cast<volatile int*>(a.ws.dense_hint) = (certified ? 0 : 1) | ((dense_ran || outcome == 1 || outcome == 2) ? 2 : 0);
             if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
             // re-arm for the next launch (this workgroup is the last reader)
-            L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2; *L.cmaxkey = 0ull;
+            L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2; L.hdr[LAP_H_DENSE] = 0; *L.cmaxkey = 0ull;
         }
     }
     if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
@@ -873,6 +875,7 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
 }
 
 hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid);   // lap_kernels.hip
+hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s);                     // lap_dense.hip
 hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s);   // mk_sparse.hip
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
@@ -909,6 +912,19 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         if (lap) {
             e = launch_lap_front(a, gR, gC, s, ev_mid); if (e != hipSuccess) return e;
             ev_mid = nullptr;
+            // Dense solver (lap_dense.hip) for frames whose far matches defeat the sparse one (detector misses + false positives): its
+            // three launches return at once when the sparse solver succeeded, but they are not even submitted unless one of the last
+            // 512 launches needed them -- the final kernel's hint in pinned host memory, read without synchronisation; the first such
+            // frame of a stream goes to the order-exact emulation.  MOT_LAP_DENSE=0 never, =1 always.
+            static int dense_mode = -1;
+            if (dense_mode < 0) { const char* ev = getenv("MOT_LAP_DENSE"); dense_mode = ev ? (atoi(ev) ? 1 : 0) : 2; }
+            bool want_dense = dense_mode == 1;
+            if (dense_mode == 2 && ws.dense_hint) {
+                volatile int* h = ws.dense_hint;                       // [0] device-written hint bits, [1] host-side countdown
+                if (h[0] & 2) h[1] = 512; else if (h[1] > 0) h[1] = h[1] - 1;
+                want_dense = h[1] > 0;
+            }
+            if (want_dense) { e = launch_lap_dense(a, gR, gC, s); if (e != hipSuccess) return e; }
             e = launch_mk_sparse(a, gR, gC, s); if (e != hipSuccess) return e;
             hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a, 1);   // working matrix + bitmaps, only if the dense emulation must run
         }
@@ -937,7 +953,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // (whose launch alone costs more than the common case's whole final kernel)
     // ... unless the stream keeps needing it (detector misses + false positives force far matches no tier can certify): the final
     // kernel leaves a hint in pinned host memory, read here without synchronisation (stale by a frame or two: it only picks the grid)
-    const bool hinted = lap && ws.dense_hint && *reinterpret_cast<volatile int*>(ws.dense_hint) != 0;
+    const bool hinted = lap && ws.dense_hint && (*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0;
     const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life, lap ? 1 : 0);

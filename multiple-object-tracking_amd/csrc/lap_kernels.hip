@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
 // ---- stage 3 ----------------------------------------------------------------------------------------------------
 // the dense dual check + near-tight edges, 64 x 64 tiles; a tile's column data (boxes, prices, owners) are staged in LDS
 // once so that the sqrt chain of an element does not wait on global loads
-__global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a)
+__global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a, int again)
 {
     __shared__ bbox_t colb[64]; __shared__ double colv[64]; __shared__ int colo[64]; __shared__ int big;
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a)
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
     if (blockIdx.x * 64 >= nR || c0 >= nC) return;
     if (L.hdr[LAP_H_SOLVE] != 0) return;                               // nothing to check: the solver gave up / was not applicable
+    if (again && !L.hdr[LAP_H_DENSE]) return;                          // second pass: only behind the dense solver (lap_dense.hip)
     if (threadIdx.x == 0) big = 0;
     __syncthreads();
     if (threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
@@ -487,6 +488,12 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
     if (ev_mid && !early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a);
-    hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_lap_verify_again(const AssocArgs& a, int gR, int gC, hipStream_t s)
+{
+    hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a, 1);
     return hipGetLastError();
 }

@@ -120,6 +120,9 @@ enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 
        LAP_H_MODE = 4,        // verdict for the final kernel: 0 certified unique optimum (lap.colOfRow), 1 sparse emulation ran (lap.spAssign, valid
                               // iff LAP_H_SPVIOL == 0), 2 run the dense order-exact emulation
        LAP_H_SPVIOL = 5,      // mk_postcheck_kernel: an entry outside the candidate lists could have mattered
+       LAP_H_DENSE = 6,       // lap_dense_kernel ran in this launch (the sparse solver gave up / its prices failed the dense check): the dual check runs again
+       LAP_H_DSTAT = 42,      // [42..44] dense solver of the most recent launch: settled columns, free rows after the greedy start, device time (10 ns);
+                              // [45] launches in which it ran, [46] ... and were then certified (cumulative)
        LAP_H_LAST = 16,       // [16..31] statistics of the most recent launch: status, rounds, free rows, searches, commits, edges, cyclic nodes, device time (10 ns)
        LAP_H_CUM = 32 };      // [32..36] cumulative certificate outcomes (0 certified, 1..4 reasons), [40] sparse emulation accepted, [41] refused -> dense
 
@@ -133,8 +136,9 @@ struct AssocWs {
     int* status;              // [16]: step4, step5, sweeps, -, nR, nC, rowsAreTrackers, perRow, timers
     unsigned long long* ctl;  // control block + result buffers of the step-5 helper workgroups (MOT_ASSOC_CTL_WORDS u64)
     LapWs lap;                // fast-path workspace (lap.ccol == nullptr: not available)
-    int* dense_hint;          // pinned host int, written by the final kernel: 1 = this launch fell through to the dense emulation (a
-                              // scheduling hint for the NEXT launches -- read by the host without synchronisation, never a result)
+    int* dense_hint;          // pinned host int, written by the final kernel: bit 0 = this launch fell through to the dense emulation, bit 1 = the
+                              // sparse solver failed (gave up / infeasible prices): scheduling hints for the NEXT launches -- helper grid, dense
+                              // solver kernels -- read by the host without synchronisation, never a result
 };
 
 // host-side launchers implemented in the .hip files

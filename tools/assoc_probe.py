@@ -25,5 +25,6 @@ for f in range(nf):
     ms = c.profile_frame_device(frames[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
     a = c.assoc_stats(); l = c.lap_stats()
     print(f"f{f} nD={len(dets[f])} live={c.live_count()} stage_ms={np.round(ms, 3).tolist()} lap[outcome,rounds,free,searches,commits,edges,cyc,ticks]={l[:8].tolist()} sparse[status,aug,s5,events,us_s3,us_s5,us_total,used]={l[8:12].tolist() + [int(l[12]) // 100, int(l[13]) // 100, int(l[14]) // 100, int(l[15])]} "
+          f"dense_solver[steps,free,us,ran_total,certified_total]={[int(l[26]), int(l[27]), int(l[28]) // 100, int(l[29]), int(l[30])]} "
           f"munkres[s4,s5,sweeps]={a[:3].tolist()} mk_total_us={a[12] / 100:.0f} init_us={a[8] / 100:.0f} s3_us={a[9] / 100:.0f} s5_us={a[11] / 100:.0f}")
 print("cumulative outcomes", c.lap_stats()[16:28].tolist())
