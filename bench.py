@@ -44,15 +44,23 @@ def alg_bytes(size):
             "blend": 3 * 31 * nb * 8 + 3 * nb * 4 + 24}
 
 
-def gen_stream(n_tracks, size, n_frames, stream_id=0, det_sizes=None, first_frame_exact=True):
+def gen_stream(n_tracks, size, n_frames, stream_id=0, det_sizes=None, first_frame_exact=True, miss_pct=0, fp_pct=0, nms=False, counts=None):
+    """frames [n_frames][720][1280][3] u8 and detections [n_frames][n_tracks or cap] of a synthetic stream; with misses / false
+    positives / nms the number of detections varies per frame: pass a list as `counts` to receive them (rows are zero-padded)"""
     import mot_amd
     from multiple_object_tracking_amd import synth
-    scene = synth.Scene(n_tracks, size, stream_id=stream_id, det_sizes=det_sizes, first_frame_exact=det_sizes is not None and first_frame_exact)
+    scene = synth.Scene(n_tracks, size, stream_id=stream_id, det_sizes=det_sizes, first_frame_exact=det_sizes is not None and first_frame_exact,
+                        miss_pct=miss_pct, fp_pct=fp_pct, nms=nms)
+    varying = bool(miss_pct or fp_pct or nms)
+    cap = min(1024, n_tracks + n_tracks // 8 + 8) if varying else n_tracks
     frames = np.empty((n_frames, 720, 1280, 3), np.uint8)
-    dets = np.zeros((n_frames, n_tracks), mot_amd.BBOX_DTYPE)
+    dets = np.zeros((n_frames, cap), mot_amd.BBOX_DTYPE)
     for f, (frame, d) in enumerate(scene.frames(n_frames)):
         frames[f] = frame
-        dets[f] = mot_amd.boxes_array(d)
+        d = d[:cap]
+        dets[f, :len(d)] = mot_amd.boxes_array(d)
+        if counts is not None:
+            counts.append(len(d))
     return frames, dets
 
 
@@ -141,6 +149,9 @@ def main():
     ap.add_argument("--per-track-sizes", action="store_true",
                     help="with --det-sizes LO HI: every track keeps the template size of the detection that spawned it (the reference's "
                          "behaviour, kcf.cpp:148-152) -- one pool per size LO..HI in the device-resident loop; informative, not the headline config")
+    ap.add_argument("--miss-pct", type=int, default=0, help="detector noise: every object is missed with this probability (percent) in every frame")
+    ap.add_argument("--fp-pct", type=int, default=0, help="detector noise: number of false-positive boxes per frame, percent of --tracks")
+    ap.add_argument("--nms", action="store_true", help="no two detections of a frame share a centroid (what a detector's NMS guarantees)")
     ap.add_argument("--mode", choices=["sharded", "streams"], default="sharded",
                     help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded tid %% N, one all-gather per frame (BASELINE configs[3], strong scaling); "
                          "streams = N independent camera streams of --tracks tracks each, one per GPU, no collective (BASELINE configs[4], weak scaling)")
@@ -184,8 +195,10 @@ def main():
     mot_rank, mot_world = (0, 1) if streams else (rank, world)
     n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
     n_frames = 1 + args.warmup + args.steps + args.steady + n_prof
+    det_counts = []
     frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0, det_sizes=tuple(args.det_sizes) if args.det_sizes else None,
-                                  first_frame_exact=not args.per_track_sizes)
+                                  first_frame_exact=not args.per_track_sizes, miss_pct=args.miss_pct, fp_pct=args.fp_pct, nms=args.nms, counts=det_counts)
+    cap_t = min(1024, max(n_tracks, dets_h.shape[1]))                   # tracks come and go with detector noise
     dev_sizes = tuple(args.det_sizes) if (args.per_track_sizes and args.det_sizes) else None
     frames_d = torch.from_numpy(frames_h).cuda()
     dets_d = torch.from_numpy(dets_h.view(np.uint8).reshape(n_frames, -1)).cuda()
@@ -193,7 +206,7 @@ def main():
     det_bytes = dets_d.shape[1]
 
     stream = torch.cuda.Stream()
-    ctx = mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(n_tracks, 1), max_dets=max(n_tracks, 1),
+    ctx = mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(cap_t, 1), max_dets=max(cap_t, 1),
                              rank=mot_rank, world=mot_world, stream=stream.cuda_stream, dev_size=size, dev_sizes=dev_sizes)
 
     gathered = None
@@ -208,9 +221,9 @@ def main():
         fp = frames_d.data_ptr() + f * frame_bytes
         dp = dets_d.data_ptr() + f * det_bytes
         if mot_world == 1:
-            ctx.step_frame_device(fp, dp, n_tracks)
+            ctx.step_frame_device(fp, dp, det_counts[f])
             for _, cx in extra:
-                cx.step_frame_device(fp, dp, n_tracks)
+                cx.step_frame_device(fp, dp, det_counts[f])
         else:
             seg_ptr, spr = ctx.step_begin_device(fp)
             nonlocal gathered
@@ -222,7 +235,7 @@ def main():
                 gathered.copy_(par.all_gather_boxes(step.local.cpu()))
             else:
                 par.all_gather_boxes(step.local, gathered)         # the single collective of the frame (RCCL over xGMI)
-            ctx.step_finish_device(gathered.data_ptr(), dp, n_tracks)
+            ctx.step_finish_device(gathered.data_ptr(), dp, det_counts[f])
 
     with torch.cuda.stream(stream):
         f = 0
@@ -280,7 +293,7 @@ def main():
             for _ in range(n_prof):
                 fp = frames_d.data_ptr() + f * frame_bytes
                 dp = dets_d.data_ptr() + f * det_bytes
-                st5 = ctx.profile_frame_device(fp, dp, n_tracks)
+                st5 = ctx.profile_frame_device(fp, dp, det_counts[f])
                 acc += st5
                 assoc_ms.append(float(st5[1] + st5[3]))
                 used_by[int(ctx.lap_stats()[15]) % 3] += 1
@@ -308,6 +321,7 @@ def main():
                        **({"streams_per_gpu": args.streams_per_gpu, "note": "K independent contexts on K HIP streams of one GPU; value = all streams"} if extra else {}),
                        "tracks_total": n_tracks * (world if streams else 1) * (1 + len(extra)), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
                        "live_tracks_end": n_live, "patch": size, **({"det_sizes": args.det_sizes} if args.det_sizes else {}),
+                       **({"detector_noise": {"miss_pct": args.miss_pct, "fp_pct": args.fp_pct, "nms": bool(args.nms)}} if (args.miss_pct or args.fp_pct or args.nms) else {}),
                        **({"per_track_template_sizes": True} if dev_sizes else {}),
                        "parallelism": (f"{world} replicas, no collective" if streams else f"track-shard x{world}, 1 all-gather/frame") if world > 1 else "single GPU"},
         }

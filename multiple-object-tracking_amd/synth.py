@@ -44,7 +44,7 @@ def _int_sine(period: int, amp: int) -> np.ndarray:
 
 class Scene:
     def __init__(self, n_objects: int, size: int = 80, stream_id: int = 0, det_sizes: tuple[int, int] | None = None,
-                 miss_pct: int = 0, fp_pct: int = 0, first_frame_exact: bool = False):
+                 miss_pct: int = 0, fp_pct: int = 0, first_frame_exact: bool = False, nms: bool = False):
         self.n, self.size = n_objects, size
         self.det_sizes = det_sizes  # (lo, hi): detection boxes get a random square size in [lo, hi] around the object centre
         # first_frame_exact: frame 0's detections have exactly `size` (every track is spawned with the size x size template,
@@ -52,6 +52,9 @@ class Scene:
         # detections resized to it (td.cpp:528-537)
         self.first_frame_exact = first_frame_exact
         self.miss_pct, self.fp_pct = miss_pct, fp_pct
+        # nms: like a detector's non-maximum suppression, no two detections of a frame share a centroid (the later one is dropped).
+        # Coinciding centroids are what makes optima TIE in this synthetic scene (integer pixel grid, 1000 objects in 1280 x 720)
+        self.nms = nms
         seed = 0x5EED0000 + stream_id
         self.seed = seed
         rng = SplitMix64(seed)
@@ -115,6 +118,14 @@ class Scene:
                     l, t = rng.randint(0, FRAME_W - s), rng.randint(0, FRAME_H - s)
                     dets.append((l, t, t + s - 1, l + s - 1, rng.randint(0, 2), 0.9))
                     owner.append(-1)
+        if self.nms:
+            seen, kd, ko = set(), [], []
+            for dd, oo in zip(dets, owner):
+                key = ((dd[0] + dd[3]) >> 1, (dd[1] + dd[2]) >> 1)
+                if key in seen:
+                    continue
+                seen.add(key); kd.append(dd); ko.append(oo)
+            dets, owner = kd, ko
         # Fisher-Yates shuffle
         for i in range(len(dets) - 1, 0, -1):
             j = rng.randint(0, i)

@@ -272,3 +272,26 @@ def test_device_loop_per_track_sizes_two_ranks_on_one_gpu(mot, oracle):
     m.close()
     for c in ranks:
         c.close()
+
+
+def test_device_loop_detector_noise_dense_solver(mot, oracle):
+    """a stream with detector noise -- 4 % misses, 3 % false positives, no two detections on one centroid (NMS) -- forces far matches
+    in almost every frame: the sparse solver's prices fail there, the dense solver (lap_dense.hip) certifies most frames, the rest go
+    to the emulation.  Every frame must equal the oracle, and the dense solver must have certified some."""
+    from multiple_object_tracking_amd import synth
+    n, nframes = 300, 10
+    scene = synth.Scene(n, 80, stream_id=47, miss_pct=4, fp_pct=3, nms=True)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d[:384] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    c = mot.MotContext(max_tracks=384, max_dets=384)
+    m = orc.OracleMot(oracle, 0, 0, 384)
+    for f in range(nframes):
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        boxes, tids, ages = c.live_tracks()
+        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    st = c.lap_stats()
+    assert st[29] >= 3 and st[30] >= 2, st.tolist()                  # dense solver ran / was certified (the first noisy frame arms it)
+    m.close(); c.close()
