@@ -5,9 +5,9 @@
  *   stage 2  sparse solve  phase A: shortest-augmenting-path searches on the candidate graph, run in rounds: every free
  *                          row searches on the same snapshot of (prices, matching); a search commits only if it holds
  *                          the lock (lowest searcher id) of every column it scanned and of its end column.
- *                          phase B: rows phase A could not place (no free column inside the candidate graph within
- *                          LAPM_TS touched columns: false-positive detections, whose partner is a far-away free column)
- *                          are placed one by one by a search over candidate edges + edges to EVERY free column
+ *   stage 2b dense solve   when phase A cannot place a row inside the candidate graph (a false-positive detection, whose partner
+ *                          is a far-away free column) or its prices fail stage 3: Jonker-Volgenant over ALL entries
+ *                          (lap_dense.hip); the result goes through stages 3 and 4 like the sparse solver's
  *   stage 3  verify        dense pass over ALL entries: dual feasibility of the prices, and the list of near-tight edges
  *   stage 4  certificate   the optimum is unique with margin eps iff the near-tight digraph is acyclic
  * The reference's Munkres (trackers/hungarian/hungarian.cpp:29-368) returns SOME optimal assignment; which one depends
@@ -146,62 +146,69 @@ int lapm_solve(const double* c, int nR, int nC, int K, int S, int* assignment, l
         }
     }
 
-    /* ---- phase B: the rows phase A gave up on, one at a time; every tree row may end in ANY free column ---- */
-    if (!giveup) {
-        double* dist = malloc(sizeof(double) * (size_t)nC); int* pred = malloc(sizeof(int) * (size_t)nC); unsigned char* scn = malloc((size_t)nC);
-        for (int s0 = 0; s0 < nR && !giveup; s0++) {
-            if (colOfRow[s0] >= 0) continue;
-            info->hard++;
-            double us = DBL_MAX;
-            for (int k = 0; k < K; k++) { const double x = cv[s0 * K + k] - v[cj[s0 * K + k]]; if (x < us) us = x; }
-            for (int j = 0; j < nC; j++) if (rowOfCol[j] < 0) { const double x = c[s0 + (size_t)nR * j] - v[j]; if (x < us) us = x; }
-            for (int j = 0; j < nC; j++) { dist[j] = DBL_MAX; pred[j] = -1; scn[j] = 0; }
-            for (int k = 0; k < K; k++) { const int j = cj[s0 * K + k]; dist[j] = (cv[s0 * K + k] - v[j]) - us; pred[j] = s0; }
-            for (int j = 0; j < nC; j++) if (rowOfCol[j] < 0) { const double x = (c[s0 + (size_t)nR * j] - v[j]) - us; if (x < dist[j]) { dist[j] = x; pred[j] = s0; } }
-            double Delta = 0; int jend = -1;
-            for (;;) {
-                int b = -1; double best = DBL_MAX;
-                for (int j = 0; j < nC; j++) if (!scn[j] && dist[j] < best) { best = dist[j]; b = j; }
-                if (b < 0) { giveup = 1; break; }
-                Delta = best;
-                if (rowOfCol[b] < 0) { jend = b; break; }
-                scn[b] = 1; info->hard_scans++;
-                const int i = rowOfCol[b];
-                const double ui = mcost[i] - v[b];
-                for (int k = 0; k < K; k++) { const int j2 = cj[i * K + k]; if (j2 == b || scn[j2]) continue; const double nd = best + ((cv[i * K + k] - v[j2]) - ui); if (nd < dist[j2]) { dist[j2] = nd; pred[j2] = i; } }
-                for (int j2 = 0; j2 < nC; j2++) if (rowOfCol[j2] < 0) { const double nd = best + ((c[i + (size_t)nR * j2] - v[j2]) - ui); if (nd < dist[j2]) { dist[j2] = nd; pred[j2] = i; } }
-            }
-            if (giveup) break;
-            for (int j = 0; j < nC; j++) if (scn[j]) v[j] -= (Delta - dist[j]);
-            for (int j = jend;;) { const int i = pred[j]; const int pj = colOfRow[i]; colOfRow[i] = j; mcost[i] = c[i + (size_t)nR * j]; rowOfCol[j] = i; if (i == s0) break; j = pj; }
-        }
-        free(dist); free(pred); free(scn);
-    }
-    int status = 0;
-    if (giveup) status = 1;
-    /* ---- stage 3 ---- */
+    /* a row phase A could not place inside the candidate graph (a false positive whose partner is a far-away free column): the sparse
+     * solver gives up, like lap_solve_kernel */
+    for (int i = 0; i < nR; i++) if (colOfRow[i] < 0) giveup = 1;
+    int status = giveup ? 1 : 0;
     int nedges = 0; int* ea = malloc(sizeof(int) * LAPM_EDGES); int* eb = malloc(sizeof(int) * LAPM_EDGES);
     const int D = nR;
-    if (!status) {
-        double gamma = 0.0;
-        for (int i = 0; i < nR; i++) gamma += mcost[i] - cv[i * K];
-        const double n3 = (double)nC * nC * nC;
-        const double mag = cmax + gamma;
-        const double eps = (1e-15 * n3 > 1e-9 ? 1e-15 * n3 : 1e-9) * mag, tol = 1e-12 * mag;
-        info->eps = eps; info->gamma = gamma;
-        for (int i = 0; i < nR && !status; i++) {
-            const int m = colOfRow[i];
-            const double ui = c[i + (size_t)nR * m] - v[m];
-            for (int j = 0; j < nC; j++) {
-                if (j == m) continue;
-                const double r = (c[i + (size_t)nR * j] - v[j]) - ui;
-                if (!(r >= -tol)) { status = 2; break; }
-                if (r < eps) { if (nedges == LAPM_EDGES) { status = 3; break; } ea[nedges] = i; eb[nedges] = rowOfCol[j] >= 0 ? rowOfCol[j] : D; nedges++; }
+    for (int pass = 0; pass < 2; pass++) {
+        /* ---- stage 3 ---- */
+        nedges = 0;
+        if (!status) {
+            double gamma = 0.0;
+            for (int i = 0; i < nR; i++) gamma += c[i + (size_t)nR * colOfRow[i]] - cv[i * K];
+            const double n3 = (double)nC * nC * nC;
+            const double mag = cmax + gamma;
+            const double eps = (1e-15 * n3 > 1e-9 ? 1e-15 * n3 : 1e-9) * mag, tol = 1e-12 * mag;
+            info->eps = eps; info->gamma = gamma;
+            for (int i = 0; i < nR && !status; i++) {
+                const int m = colOfRow[i];
+                const double ui = c[i + (size_t)nR * m] - v[m];
+                for (int j = 0; j < nC; j++) {
+                    if (j == m) continue;
+                    const double r = (c[i + (size_t)nR * j] - v[j]) - ui;
+                    if (!(r >= -tol)) { status = 2; break; }
+                    if (r < eps) { if (nedges == LAPM_EDGES) { status = 3; break; } ea[nedges] = i; eb[nedges] = rowOfCol[j] >= 0 ? rowOfCol[j] : D; nedges++; }
+                }
+            }
+            for (int j = 0; j < nC && !status; j++) {
+                if (v[j] > 0.0 || (rowOfCol[j] < 0 && v[j] != 0.0)) status = 2;
+                else if (rowOfCol[j] >= 0 && nC > nR && -v[j] < eps) { if (nedges == LAPM_EDGES) status = 3; else { ea[nedges] = D; eb[nedges] = rowOfCol[j]; nedges++; } }
             }
         }
-        for (int j = 0; j < nC && !status; j++) {
-            if (v[j] > 0.0 || (rowOfCol[j] < 0 && v[j] != 0.0)) status = 2;
-            else if (rowOfCol[j] >= 0 && nC > nR && -v[j] < eps) { if (nedges == LAPM_EDGES) status = 3; else { ea[nedges] = D; eb[nedges] = rowOfCol[j]; nedges++; } }
+        if (pass == 1 || (status != 1 && status != 2)) break;
+        /* ---- the dense solver (lap_dense.hip): Jonker-Volgenant over ALL entries from the greedy start "every row takes its nearest
+         * column if it is the lowest claimant"; its result goes through the same stage 3 / 4 ---- */
+        {
+            double* u = malloc(sizeof(double) * (size_t)nR); double* dist = malloc(sizeof(double) * (size_t)nC);
+            int* pred = malloc(sizeof(int) * (size_t)nC); unsigned char* scn = malloc((size_t)nC);
+            for (int j = 0; j < nC; j++) { v[j] = 0.0; rowOfCol[j] = -1; }
+            for (int i = 0; i < nR; i++) { colOfRow[i] = -1; u[i] = cv[i * K]; }
+            for (int i = 0; i < nR; i++) { const int j = cj[i * K]; if (rowOfCol[j] < 0) { rowOfCol[j] = i; colOfRow[i] = j; } }
+            info->hard = 0; info->hard_scans = 0;
+            int failed = 0;
+            for (int s0 = 0; s0 < nR && !failed; s0++) {
+                if (colOfRow[s0] >= 0) continue;
+                info->hard++;
+                for (int j = 0; j < nC; j++) { dist[j] = (c[s0 + (size_t)nR * j] - u[s0]) - v[j]; pred[j] = s0; scn[j] = 0; }
+                int jend = -1; double dend = 0.0;
+                for (;;) {
+                    int b = -1; double best = DBL_MAX;
+                    for (int j = 0; j < nC; j++) if (!scn[j] && dist[j] < best) { best = dist[j]; b = j; }   /* lowest column on equal distances */
+                    if (b < 0) { failed = 1; break; }
+                    if (rowOfCol[b] < 0) { jend = b; dend = best; break; }
+                    scn[b] = 1; info->hard_scans++;
+                    const int i = rowOfCol[b];
+                    for (int j = 0; j < nC; j++) if (!scn[j]) { const double nd = ((best + c[i + (size_t)nR * j]) - u[i]) - v[j]; if (nd < dist[j]) { dist[j] = nd; pred[j] = i; } }
+                }
+                if (failed) break;
+                for (int j = 0; j < nC; j++) if (scn[j]) { const double delta = dend - dist[j]; u[rowOfCol[j]] += delta; v[j] -= delta; }
+                u[s0] += dend;
+                for (int j = jend;;) { const int i = pred[j]; const int pj = colOfRow[i]; colOfRow[i] = j; rowOfCol[j] = i; if (i == s0) break; j = pj; }
+            }
+            free(u); free(dist); free(pred); free(scn);
+            status = failed ? 1 : 0;
         }
     }
     info->nedges = nedges;

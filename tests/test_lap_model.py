@@ -139,3 +139,31 @@ def test_large_tracking_scene(model, oracle, n):
         assert np.array_equal(a, ra)
     else:
         assert st == 4, f"status {st}"                               # only a genuine tie may refuse a tracking scene
+
+
+def test_dense_solver_on_miss_and_false_positive_scenes(model):
+    """scenes with missed detections AND false positives force far matches: the sparse solver gives up or its prices fail the dense
+    check, the dense Jonker-Volgenant solver (CPU statement of csrc/lap_dense.hip) takes over, and its result passes through the same
+    dual check and uniqueness certificate -- certified must still imply equal to the oracle's Munkres"""
+    lib = orc.load_oracle()
+    rng = np.random.default_rng(77)
+    dense_certified = dense_ran = 0
+    for it in range(250):
+        n = int(rng.integers(20, 140))
+        cx = rng.integers(40, 1240, n); cy = rng.integers(40, 680, n); typ = np.arange(n) % 3
+        trk = [(int(cx[i] + rng.integers(-4, 5)) - 40, int(cy[i] + rng.integers(-4, 5)) - 40, int(cy[i]) + 39, int(cx[i]) + 39, int(typ[i]), 0.9) for i in range(n)]
+        det = [(int(cx[i] + rng.integers(-2, 3)) - 40, int(cy[i] + rng.integers(-2, 3)) - 40, int(cy[i]) + 39, int(cx[i]) + 39, int(typ[i]), 0.9)
+               for i in rng.permutation(n) if rng.integers(0, 100) >= 6]
+        for _ in range(max(1, n // 20)):
+            fx, fy = int(rng.integers(40, 1240)), int(rng.integers(40, 680))
+            det.append((fx - 40, fy - 40, fy + 39, fx + 39, int(rng.integers(0, 3)), 0.9))
+        nT, nD = len(trk), len(det)
+        d = orc.cost_matrix(lib, trk, det)
+        nr, nc = (nT, nD) if nT < nD else (nD, nT)                    # rows = the smaller side (td.cpp:388, 462-465)
+        st, a, info = solve(model, d, nr, nc)
+        dense_ran += info.hard > 0
+        if st == 0:
+            ref, _ = orc.assignment_optimal(lib, d, nr, nc)
+            assert np.array_equal(a, ref), (it, nr, nc, info.hard, info.hard_scans)
+            dense_certified += info.hard > 0
+    assert dense_ran > 150 and dense_certified > 100, (dense_ran, dense_certified)

@@ -8,6 +8,9 @@ python bench.py --tracks 512 --no-cpu-baseline > $O/bench_n512.json 2>/dev/null
 python bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline > $O/bench_n256_s148_multiscale.json 2>/dev/null
 python bench.py --tracks 256 --size 150 --det-sizes 120 180 --per-track-sizes --no-cpu-baseline > $O/bench_n256_per_track_sizes_120_180.json 2>/dev/null
 python bench.py --tracks 1024 --det-sizes 64 96 --per-track-sizes --no-cpu-baseline > $O/bench_n1024_per_track_sizes_64_96.json 2>/dev/null
+python bench.py --tracks 256 --miss-pct 4 --fp-pct 3 --nms --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_n256_detector_noise.json 2>/dev/null
+MOT_LAP_DENSE=0 python bench.py --tracks 256 --miss-pct 4 --fp-pct 3 --nms --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_n256_detector_noise_no_dense_solver.json 2>/dev/null
+python bench.py --tracks 1000 --miss-pct 4 --fp-pct 3 --nms --steps 20 --warmup 5 --steady 0 --profile-frames 10 --no-cpu-baseline > $O/bench_n1000_detector_noise.json 2>/dev/null
 MOT_DBG_WG=$O/wg_timeline_n1024.txt python tools/kcf_probe.py --frames 8 > $O/kcf_probe_n1024.log 2>&1
 python tools/wg_timeline.py $O/wg_timeline_n1024.txt >> $O/kcf_probe_n1024.log 2>&1
 python tools/kcf_probe.py --frames 8 --tracks 256 --size 148 --det-sizes 120 180 > $O/kcf_probe_n256_s148.log 2>&1

@@ -8,6 +8,7 @@ for n in 64 256 512; do cp $R/bench_n$n.json profiles/r02_bench_n$n.json; done
 cp $R/bench_n256_s148_multiscale.json profiles/r02_bench_n256_s148_multiscale.json
 cp $R/bench_n256_per_track_sizes_120_180.json profiles/r02_bench_n256_per_track_sizes_120_180.json
 cp $R/bench_n1024_per_track_sizes_64_96.json profiles/r02_bench_n1024_per_track_sizes_64_96.json
+for f in bench_n256_detector_noise bench_n256_detector_noise_no_dense_solver bench_n1000_detector_noise; do cp $R/$f.json profiles/r02_$f.json; done
 cp $R/kcf_probe_n1024.log profiles/r02_kcf_probe_n1024.log; cp $R/kcf_probe_n256_s148.log profiles/r02_kcf_probe_n256_s148.log
 cp $(newest "$R/kstats_default/runc/*_kernel_stats.csv") profiles/r02_kernel_stats_n1024.csv
 cp $(newest "$R/kstats_default/runc/*_domain_stats.csv") profiles/r02_domain_stats_n1024.csv
