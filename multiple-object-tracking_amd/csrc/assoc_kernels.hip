@@ -914,14 +914,17 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             ev_mid = nullptr;
             // Dense solver (lap_dense.hip) for frames whose far matches defeat the sparse one (detector misses + false positives): its
             // three launches return at once when the sparse solver succeeded, but they are not even submitted unless one of the last
-            // 512 launches needed them -- the final kernel's hint in pinned host memory, read without synchronisation; the first such
-            // frame of a stream goes to the order-exact emulation.  MOT_LAP_DENSE=0 never, =1 always.
+            // 512 launches needed them (the final kernel's hint in pinned host memory, read without synchronisation) or the number
+            // of detections has just changed.  MOT_LAP_DENSE=0 never, =1 always.
             static int dense_mode = -1;
             if (dense_mode < 0) { const char* ev = getenv("MOT_LAP_DENSE"); dense_mode = ev ? (atoi(ev) ? 1 : 0) : 2; }
             bool want_dense = dense_mode == 1;
             if (dense_mode == 2 && ws.dense_hint) {
-                volatile int* h = ws.dense_hint;                       // [0] device-written hint bits, [1] host-side countdown
-                if (h[0] & 2) h[1] = 512; else if (h[1] > 0) h[1] = h[1] - 1;
+                volatile int* h = ws.dense_hint;                       // [0] device-written hint bits, [1] host-side countdown, [2] last nD
+                // a detection count that changes from frame to frame is what detector noise looks like from the host: arm the dense
+                // solver at once, so that the first noisy frame of a stream does not have to go through the emulation
+                if ((h[0] & 2) || (h[2] > 0 && nD > 0 && h[2] != nD)) h[1] = 512; else if (h[1] > 0) h[1] = h[1] - 1;
+                if (nD > 0) h[2] = nD;
                 want_dense = h[1] > 0;
             }
             if (want_dense) { e = launch_lap_dense(a, gR, gC, s); if (e != hipSuccess) return e; }
