@@ -188,7 +188,9 @@ int mot_get_assoc_stats(mot_ctx* ctx, int* out16);
  *   sparse order-exact emulation (runs when not certified): [8] 0 ok / 1 minimum outside the candidate lists / 2 n.a.,
  *   [9] augmentations [10] step-5 passes [11] step-3 events [12..14] 10 ns ticks: steps 3+4, step 5, total;
  *   [15] what decided this launch: 0 certificate, 1 sparse emulation (accepted by its after-the-fact check), 2 dense emulation
- * [16..20] cumulative launch counts of this context by certificate outcome 0..4; [24] sparse emulation accepted, [25] refused */
+ * [16..20] cumulative launch counts of this context by certificate outcome 0..4; [24] sparse emulation accepted, [25] refused;
+ * [26..28] dense solver (frames whose far matches defeat the sparse one: detector misses + false positives) in the most recent launch:
+ *   settled columns, free rows after the greedy start, time in 10 ns ticks; [29] launches in which it ran, [30] ... and were certified */
 int mot_get_lap_stats(mot_ctx* ctx, int* out32);
 /* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
 int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);

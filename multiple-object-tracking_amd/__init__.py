@@ -293,7 +293,9 @@ class MotContext:
 
     def lap_stats(self) -> np.ndarray:
         """assignment fast path: [0..7] most recent launch (outcome, rounds, free rows, searches, commits, near-tight
-        edges, cyclic nodes, solver ticks), [16..20] cumulative launches by outcome (0 = certified, 4 = tied optima)"""
+        edges, cyclic nodes, solver ticks), [15] what decided it (0 certificate, 1 sparse emulation, 2 dense emulation), [16..20] cumulative
+        launches by outcome (0 = certified, 4 = tied optima), [26..30] dense solver: settled columns, free rows, ticks, launches it ran in,
+        launches then certified"""
         out = np.zeros(32, np.int32)
         self._chk(self.lib.mot_get_lap_stats(self._h, _vp(out)))
         return out
