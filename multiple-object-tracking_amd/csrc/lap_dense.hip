@@ -148,8 +148,11 @@ __global__ void __launch_bounds__(MK_THREADS) lap_dense_kernel(AssocArgs a)
     double g = 0.0;
     if (tid < nR) {
         const int j = S.colOfRow[tid];
-        L.u[tid] = S.u[tid];
-        if (j >= 0) g = C[(size_t)tid * nC + j] - rmin;
+        // u from the cost of the matched entry: tight by construction, like the sparse solver's (the search's own u has accumulated
+        // roundings); the dense check then decides about feasibility everywhere else
+        const double cm = j >= 0 ? C[(size_t)tid * nC + j] : 0.0;
+        L.u[tid] = j >= 0 ? cm - S.v[j] : S.u[tid];
+        if (j >= 0) g = cm - rmin;
     }
     L.v[tid] = S.v[tid]; L.colOfRow[tid] = S.colOfRow[tid]; L.rowOfCol[tid] = S.rowOfCol[tid];
 #pragma unroll
