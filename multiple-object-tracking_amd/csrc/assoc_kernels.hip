@@ -956,7 +956,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // (whose launch alone costs more than the common case's whole final kernel)
     // ... unless the stream keeps needing it (detector misses + false positives force far matches no tier can certify): the final
     // kernel leaves a hint in pinned host memory, read here without synchronisation (stale by a frame or two: it only picks the grid)
-    const bool hinted = lap && ws.dense_hint && (*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0;
+    const bool hinted = lap && ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0);   // (a noisy stream: the countdown above is armed)
     const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life, lap ? 1 : 0);
