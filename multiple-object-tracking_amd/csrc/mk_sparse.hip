@@ -238,9 +238,10 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
             };
             while (action == 0) {
                 if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
-                const unsigned cand = hzr & ~cC & vC & fm;
-                const unsigned cb = (unsigned)__ballot(cand != 0);     // (the upper half mirrors the lower one)
-                if (!cb) { if (found) { found = false; fm = ~0u; continue; } action = 2; break; }
+                unsigned cand = hzr & ~cC & vC & fm;
+                unsigned cb = (unsigned)__ballot(cand != 0);           // (the upper half mirrors the lower one)
+                if (!cb && found) { found = false; fm = ~0u; cand = hzr & ~cC & vC; cb = (unsigned)__ballot(cand != 0); }   // the sweep found something: one more from column 0 (:246-248)
+                if (!cb) { action = 2; break; }
                 // three or more candidate columns in front of the sweep?  (non-empty words are counted on the scalar side; the
                 // per-lane prefix counts of the batch path come later, only when they are needed)
                 int total = 0;
@@ -342,11 +343,18 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
                 // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
                 cR |= (l5 == (row >> 5)) ? (1u << (row & 31)) : 0u;
                 covR32[l5] = cR;
-                bool emptied = false;
-                if (lane < SPK && ((m >> lane) & 1)) { const unsigned bitv = 1u << ps; emptied = atomicAnd(&S.tlive[c2], ~bitv) == bitv; }
-                for (u64 eb = __ballot(emptied); eb; eb &= eb - 1) {   // columns that lost their last live zero (usually none or one)
-                    const int ce = __builtin_amdgcn_readlane(c2, __ffsll((long long)eb) - 1);
-                    hzr &= ~((l5 == (ce >> 5)) ? (1u << (ce & 31)) : 0u);
+                if ((m & (m - 1)) == 0) {
+                    // the row's only zero is the one in this column (the usual case): its slot is the first live one of the mask just
+                    // read, so nothing has to come back from the LDS -- the column is empty iff that was its only live bit
+                    if (lane == 0) atomicAnd(&S.tlive[col], ~(lv & (0u - lv)));
+                    if ((lv & (lv - 1)) == 0) hzr &= ~((l5 == (col >> 5)) ? (1u << (col & 31)) : 0u);
+                } else {
+                    bool emptied = false;
+                    if (lane < SPK && ((m >> lane) & 1)) { const unsigned bitv = 1u << ps; emptied = atomicAnd(&S.tlive[c2], ~bitv) == bitv; }
+                    for (u64 eb = __ballot(emptied); eb; eb &= eb - 1) {   // columns that lost their last live zero (usually none or one)
+                        const int ce = __builtin_amdgcn_readlane(c2, __ffsll((long long)eb) - 1);
+                        hzr &= ~((l5 == (ce >> 5)) ? (1u << (ce & 31)) : 0u);
+                    }
                 }
                 {
                     const unsigned sb = (l5 == (sc >> 5)) ? (1u << (sc & 31)) : 0u;
