@@ -64,8 +64,9 @@ def gen_stream(n_tracks, size, n_frames, stream_id=0, det_sizes=None, first_fram
     return frames, dets
 
 
-def _cpu_worker(args):
-    """one host core: an independent stream of `n` KCF tracks through the oracle's frame loop; returns (updates, seconds)"""
+def _cpu_worker(args, want_state=False):
+    """one host core: an independent stream of `n` KCF tracks through the oracle's frame loop; returns (updates, seconds, frames)
+    and, with want_state, the live list (boxes, tids) after the last frame -- the parity record the GPU run is checked against"""
     n, size, sid, frames_cap, budget = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
@@ -75,12 +76,14 @@ def _cpu_worker(args):
     scene = synth.Scene(n, size, stream_id=sid)
     gen = scene.frames(10 ** 6)
     m = orc.OracleMot(lib, 0, 0, max(n, 1))
-    frame, dets = next(gen); m.step(frame, dets)                     # frame 0 spawns the tracks (not steady state)
+    frame, dets = next(gen); last = m.step(frame, dets)              # frame 0 spawns the tracks (not steady state)
     t0 = time.perf_counter(); done = 0
     while done < frames_cap and time.perf_counter() - t0 < budget:
-        frame, dets = next(gen); m.step(frame, dets); done += 1
+        frame, dets = next(gen); last = m.step(frame, dets); done += 1
     dt = time.perf_counter() - t0
     m.close()
+    if want_state:
+        return n * done, dt, done, (last["live"], last["tids"])
     return n * done, dt, done
 
 
@@ -103,8 +106,9 @@ def cpu_baseline(n_tracks, size, budget_s=12.0):
         except OSError:
             libs = None
     # oracle port, one core, the first steady frames of the bench stream
-    upd_p, t_p, nf_p = _cpu_worker((n_tracks, size, 0, 3, budget_s * 0.4))
+    upd_p, t_p, nf_p, state_p = _cpu_worker((n_tracks, size, 0, 3, budget_s * 0.4), want_state=True)
     port = upd_p / t_p
+    out["_parity"] = {"frames": nf_p, "port": state_p}                # popped by main(): what the GPU must reproduce after frame nf_p
     if libs is not None:
         class Feed:
             def __init__(self, items): self.items = items
@@ -114,10 +118,11 @@ def cpu_baseline(n_tracks, size, budget_s=12.0):
         nf = max(1, nf_p)
         frames = [next(gen) for _ in range(nf + 1)]
         timing = []
-        orc.ref_frame_loop(0, Feed(frames), nf + 1, libs, timing)
+        trace = orc.ref_frame_loop(0, Feed(frames), nf + 1, libs, timing)
+        out["_parity"]["reference"] = (mot_amd.boxes_array([tuple(b) + (0.9,) for b in trace[-1]["live"]]), np.array(trace[-1]["tids"], np.uint32))
         t_used = sum(t for t, _ in timing[1:]); updates = sum(n for _, n in timing[1:])
         out.update({"value": updates / t_used, "unit": "tracker-updates/s", "cores": 1, "kind": "reference",
-                    "sample": f"{n_tracks} KCF tracks x {nf} frames after the spawn frame of the bench stream (crop+resize, predict, cost, Munkres, update), 1 thread",
+                    "sample": f"{n_tracks} KCF tracks x frames 1..{nf} of the bench stream (the spawn frame 0 excluded; the GPU window starts at frame 1 + warmup: same stream, later frames) -- crop+resize, predict, cost, Munkres, update, 1 thread",
                     "port_1core": port, "port_over_reference": port / (updates / t_used)})
     else:
         out.update({"value": port, "unit": "tracker-updates/s", "cores": 1, "kind": "port",
@@ -133,6 +138,49 @@ def cpu_baseline(n_tracks, size, budget_s=12.0):
                             "sample": f"{cores} independent streams of {per} KCF tracks (one per core), {min(f for _, _, f in res)}-{max(f for _, _, f in res)} frames each"}
     except Exception as e:                                            # never fail the bench line over the optional leg
         out["all_cores"] = {"error": str(e)[:200]}
+    return out
+
+
+def dropin_timing(device, n=16, reps=12):
+    """us per call of the reference's per-object interface (td.cpp:229-232) through libmot_dropin_kcf.so -- the literal drop-in
+    mode: every call is a batch of ONE (H2D of the 25.6 KB gray patch + one-workgroup launch + sync) -- next to the reference's
+    own tracker_predict / tracker_update (kcf.cpp:455-476) on one host core, same patches"""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    import mot_amd
+    os.environ.setdefault("MOT_DEVICE", str(device))
+    lib = C.CDLL(mot_amd.DROPIN_KCF_PATH)
+    new = getattr(lib, "_Z11tracker_newP11_bbox_pos_s"); new.restype = C.c_void_p; new.argtypes = [C.c_void_p]
+    pred = getattr(lib, "_Z15tracker_predictPvPfP11_bbox_pos_s"); pred.argtypes = [C.c_void_p] * 3
+    upd = getattr(lib, "_Z14tracker_updatePvPfP11_bbox_pos_s"); upd.argtypes = [C.c_void_p] * 3
+    dele = getattr(lib, "_Z14tracker_deletePv"); dele.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(7)
+    patches = [np.ascontiguousarray(rng.integers(0, 256, 6400).astype(np.float32)) for _ in range(n)]
+    boxes = [mot_amd.BBox(100 + 5 * i, 100, 179, 179 + 5 * i, i % 3, 0.9) for i in range(n)]
+
+    def run(new_f, pred_f, upd_f, del_f):
+        hs = [C.c_void_p(new_f(C.byref(b))) for b in boxes]
+        for h, p, b in zip(hs, patches, boxes):
+            upd_f(h, orc.P(p), C.byref(b))                              # first update (eta = 1), td.cpp:631-640
+        tp = tu = 0.0
+        for _ in range(reps):
+            for h, p, b in zip(hs, patches, boxes):
+                pb = mot_amd.BBox()
+                t0 = time.perf_counter(); pred_f(h, orc.P(p), C.byref(pb)); t1 = time.perf_counter()
+                upd_f(h, orc.P(p), C.byref(b)); t2 = time.perf_counter()
+                tp += t1 - t0; tu += t2 - t1
+        for h in hs:
+            del_f(h)
+        return tp / (reps * n) * 1e6, tu / (reps * n) * 1e6
+    run(new, pred, upd, dele)                                          # warm-up (context creation, first launches)
+    p_us, u_us = run(new, pred, upd, dele)
+    out = {"tracker_predict_us": p_us, "tracker_update_us": u_us, "calls": n * reps, "patch": "80x80 float gray (caller memory)",
+           "note": "per-object interface = batch of one per call; the batch ABI (mot_step_frame_device) is the measured path"}
+    if orc.ref_available():
+        k = orc.load_ref("kcf")
+        rp, ru = run(lambda b: k.refkcf_new(b), k.refkcf_predict, k.refkcf_update, k.refkcf_delete)
+        out.update({"reference_tracker_predict_us": rp, "reference_tracker_update_us": ru, "reference_cores": 1})
     return out
 
 
@@ -161,6 +209,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=20)
     ap.add_argument("--steady", type=int, default=40, help="frames of a second timed window right behind the first (reported as steady_state; 0 = off)")
+    ap.add_argument("--h2d", type=int, default=40,
+                    help="frames of a third timed window in which every frame (2.76 MB, pinned host memory) and its detection list are "
+                         "uploaded inside the timed region, on a copy stream, double-buffered against the previous frame (td.cpp:326-333: the "
+                         "tracker thread receives each frame from the capture side); reported as h2d_inclusive, never as value; 0 = off")
+    ap.add_argument("--no-dropin", action="store_true", help="skip timing the per-object drop-in interface (tracker_predict / tracker_update through libmot_dropin_kcf.so)")
     ap.add_argument("--debug-assoc", action="store_true", help="print Munkres step counters / phase times per profiled frame to stderr")
     args = ap.parse_args()
 
@@ -190,11 +243,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    red_dev = "cpu" if backend == "gloo" else "cuda"                 # where the scalar reductions of the timing live
     n_tracks, size = args.tracks, args.size
     streams = args.mode == "streams" and world > 1
     mot_rank, mot_world = (0, 1) if streams else (rank, world)
     n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
-    n_frames = 1 + args.warmup + args.steps + args.steady + n_prof
+    n_h2d = args.h2d if (world == 1 and args.streams_per_gpu == 1) else 0
+    n_frames = 1 + args.warmup + args.steps + args.steady + n_prof + n_h2d
     det_counts = []
     frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0, det_sizes=tuple(args.det_sizes) if args.det_sizes else None,
                                   first_frame_exact=not args.per_track_sizes, miss_pct=args.miss_pct, fp_pct=args.fp_pct, nms=args.nms, counts=det_counts)
@@ -256,12 +311,12 @@ def main():
         t1 = time.perf_counter()
         elapsed = t1 - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         n_live = ctx.live_count() + sum(cx.live_count() for _, cx in extra)
         if streams:                                                  # every rank tracks its own stream: whole-job units = sum over ranks
-            t = torch.tensor([n_live], dtype=torch.int64, device="cuda")
+            t = torch.tensor([n_live], dtype=torch.int64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             n_live = int(t.item())
 
@@ -279,7 +334,7 @@ def main():
                 dist.barrier()
             ts = time.perf_counter() - ts0
             if world > 1:
-                t = torch.tensor([ts], dtype=torch.float64, device="cuda")
+                t = torch.tensor([ts], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ts = float(t.item())
             steady = {"value": n_live * args.steady / ts, "ms_per_step": ts / args.steady * 1e3, "frames": args.steady,
@@ -303,6 +358,45 @@ def main():
                     print("kcf predict phases us", (np.diff(pa) / 100.0).round(1).tolist(), "update", (np.diff(ub) / 100.0).round(1).tolist(), file=sys.stderr)
                 f += 1
             stage = acc / n_prof
+
+        # third timed window: the frame and its detections arrive from pinned host memory INSIDE the timed region (SURVEY 8d:
+        # "frame-level costs (H2D of the frame ...) are included in wall time").  Copy stream + two device buffers: the upload of
+        # frame f + 1 overlaps the kernels of frame f; a buffer is reused only after the frame that read it has finished.
+        h2d = None
+        if n_h2d:
+            f0 = f
+            pin_f = torch.from_numpy(frames_h[f0:f0 + n_h2d]).pin_memory()
+            pin_d = torch.from_numpy(dets_h[f0:f0 + n_h2d].view(np.uint8).reshape(n_h2d, -1)).pin_memory()
+            bufs_f = [torch.empty(frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            bufs_d = [torch.empty(det_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            copy_stream = torch.cuda.Stream()
+            ev_up = [torch.cuda.Event() for _ in range(2)]; ev_done = [torch.cuda.Event() for _ in range(2)]
+            stream.synchronize(); torch.cuda.synchronize()
+
+            def upload(k):
+                b = k & 1
+                with torch.cuda.stream(copy_stream):
+                    if k >= 2:
+                        copy_stream.wait_event(ev_done[b])                 # the frame that used this buffer is finished
+                    bufs_f[b].copy_(pin_f[k].reshape(-1), non_blocking=True)
+                    bufs_d[b].copy_(pin_d[k], non_blocking=True)
+                    ev_up[b].record(copy_stream)
+
+            th0 = time.perf_counter()
+            upload(0)
+            for k in range(n_h2d):
+                b = k & 1
+                if k + 1 < n_h2d:
+                    upload(k + 1)
+                stream.wait_event(ev_up[b])
+                ctx.step_frame_device(bufs_f[b].data_ptr(), bufs_d[b].data_ptr(), det_counts[f0 + k])
+                ev_done[b].record(stream)
+            stream.synchronize(); torch.cuda.synchronize()
+            th = time.perf_counter() - th0
+            f += n_h2d
+            h2d = {"h2d": "included", "value": ctx.live_count() * n_h2d / th, "unit": "tracker-updates/s", "ms_per_step": th / n_h2d * 1e3, "frames": n_h2d,
+                   "first_frame": f0, "bytes_per_frame": frame_bytes + det_counts[f0] * 24,
+                   "how": "pinned host frames, async copy on a copy stream, two device buffers (upload of frame f+1 overlaps the kernels of frame f)"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -328,6 +422,8 @@ def main():
         ab = alg_bytes(size)
         if steady is not None:
             out["steady_state"] = steady
+        if h2d is not None:
+            out["h2d_inclusive"] = h2d
         if stage is not None:
             # the lifecycle step is the tail of the final association kernel; stage[3] is only the gap between two event records
             kern = {"kcf_predict": stage[0], "association (row scan, LAP solver, dual check, sparse / dense Munkres, lifecycle)": stage[1] + stage[3], "kcf_update": stage[4]}
@@ -338,18 +434,20 @@ def main():
             dom = max(cands, key=lambda k: cands[k][0])
             per_launch = cands[dom][1] * n_live
             achieved = per_launch / (cands[dom][0] * 1e-3) / 1e9
-            traffic = None; tj = {}
-            for cand_file in ("r02_traffic.json", "r01_traffic.json"):
+            traffic = None; tj = {}; traffic_src = None
+            for cand_file in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", cand_file)
                 if os.path.exists(tpath):
                     try:
                         tj = json.load(open(tpath))
                         traffic = tj.get(("kcf_predict" if dom == "kcf_predict" else "kcf_update_blend" if split else "kcf_update") + f"_bytes_per_launch_n{n_tracks}")
+                        if traffic is not None:
+                            traffic_src = f"profiles/{cand_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (tools/collect_profiles.sh), not measured by this run"
                     except Exception:
                         traffic = None
                     break
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "alg_bytes_per_launch": per_launch, "avg_launch_ms": cands[dom][0],
                                "note": "stage time between HIP events on the launch stream incl. the dispatch gap"}
             other = [k for k in cands if k != dom][0]
@@ -366,9 +464,45 @@ def main():
                                     "frames": len(assoc_ms), "first_frame": 1 + args.warmup + args.steps + args.steady}
             out["kernel_ms"] = {k: float(v) for k, v in kern.items()}
             out["hbm_frac_whole_frame"] = (ab["predict"] + ab["update"]) * n_live / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        parity_fail = False
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n_tracks, size)
+            cb = cpu_baseline(n_tracks, size)
+            par_rec = cb.pop("_parity", None)
+            default_stream = not (args.det_sizes or args.miss_pct or args.fp_pct or args.nms or args.per_track_sizes)
+            if par_rec and default_stream and par_rec["frames"] >= 1:
+                # parity check with every measurement: a fresh context runs frames 0..K of the SAME stream through the
+                # device-resident loop; its live list (boxes, types, track ids) must equal what the CPU legs just computed
+                K = par_rec["frames"]
+                vctx = mot_amd.MotContext(tracker_kind=mot_amd.TRACKER_KCF, device=local_rank, max_tracks=max(cap_t, 1), max_dets=max(cap_t, 1),
+                                          stream=stream.cuda_stream, dev_size=size)
+                with torch.cuda.stream(stream):
+                    for k in range(K + 1):
+                        vctx.step_frame_device(frames_d.data_ptr() + k * frame_bytes, dets_d.data_ptr() + k * det_bytes, det_counts[k])
+                    vb, vt, _ = vctx.live_tracks()
+                vctx.close()
+                res = {}
+                for name in ("port", "reference"):
+                    if name in par_rec:
+                        eb, et = par_rec[name]
+                        res[name] = bool(len(eb) == len(vb) and np.array_equal(np.asarray(et, np.uint32), vt)
+                                         and all(np.array_equal(eb[k2], vb[k2]) for k2 in ("l", "t", "b", "r", "type")))
+                out["parity_checked"] = {"ok": all(res.values()), "frames": f"0..{K}", "tracks": int(len(vb)), "equal_to": res,
+                                         "what": "live boxes (l,t,b,r,type) and track ids of the device-resident loop after frame K vs the oracle port"
+                                                 + (" and the reference-built loop" if "reference" in res else "") + " of the cpu_baseline leg, bit-equal"}
+                parity_fail = not out["parity_checked"]["ok"]
+            else:
+                out["parity_checked"] = None
+            if not args.no_dropin and size == 80:
+                try:
+                    cb["dropin"] = dropin_timing(local_rank)
+                except Exception as e:                                  # informative leg: never fail the line over it
+                    cb["dropin"] = {"error": str(e)[:200]}
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
+        if parity_fail:
+            print("bench.py: PARITY CHECK FAILED -- the number above is not valid", file=sys.stderr)
+            ctx.close()
+            raise SystemExit(3)
     for _, cx in extra:
         cx.close()
     ctx.close()

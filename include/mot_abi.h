@@ -49,6 +49,25 @@ typedef struct _bbox_pos_s {
 } bbox_t;
 #endif
 
+/* Bit-identical to top/cnntype.h:43-47: what the detector thread hands the tracker thread per frame
+ * (td.cpp:330-333: `bbox_chain_t* pdetected = bbox_proc[prc_rptr]; ndetected = pdetected->nbox`).
+ * 3076 bytes: nbox + 128 boxes. */
+#ifndef MOT_BBOX_CHAIN_T_DEFINED
+#define MOT_BBOX_CHAIN_T_DEFINED
+#define MOT_CHAIN_MAX_BOXES 128
+typedef struct _bbox_chain_s {
+    int nbox;
+    bbox_t bbox[MOT_CHAIN_MAX_BOXES];
+} bbox_chain_t;
+#endif
+#if defined(__cplusplus)
+static_assert(sizeof(bbox_t) == 24, "bbox_t must match top/cnntype.h:36-41");
+static_assert(sizeof(bbox_chain_t) == 3076, "bbox_chain_t must match top/cnntype.h:43-47");
+#elif defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
+_Static_assert(sizeof(bbox_t) == 24, "bbox_t must match top/cnntype.h:36-41");
+_Static_assert(sizeof(bbox_chain_t) == 3076, "bbox_chain_t must match top/cnntype.h:43-47");
+#endif
+
 /* top/cnntype.h:5-6 */
 #define MOT_FRAME_W 1280
 #define MOT_FRAME_H 720
@@ -143,6 +162,12 @@ int mot_cost_matrix(mot_ctx* ctx, const bbox_t* trk, int nT, const bbox_t* det, 
 int mot_step_frame(mot_ctx* ctx, const bbox_t* dets, int nD,
                    bbox_t* predicted, int* assigned_trackers, int* n_before,
                    bbox_t* live_boxes, unsigned* live_tids, int* n_live);
+
+/* The same iteration fed the way td.cpp feeds it: the detector's bbox_chain_t of this frame (td.cpp:326-333).
+ * nbox outside 0..128 is MOT_ERR_ARG (the reference reads bbox[] unchecked). */
+int mot_step_frame_chain(mot_ctx* ctx, const bbox_chain_t* detected,
+                         bbox_t* predicted, int* assigned_trackers, int* n_before,
+                         bbox_t* live_boxes, unsigned* live_tids, int* n_live);
 
 /* Split form for multi-GPU: begin = predict the local shard into a device
  * buffer laid out for one all-gather; finish = association + update + lifecycle.

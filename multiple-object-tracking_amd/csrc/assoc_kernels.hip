@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         __syncthreads();                                               // the assignment vector is complete (same workgroup wrote it)
         // a helper hand-off that timed out leaves a partial starring: never commit it to the tracker state -- the frame is
         // dropped (live list and models untouched) and the context latches a device error that every read-back reports
-        if (S.flag[7]) { if (tid == 0) life.S.err[4] = stat[15]; }
+        if (S.flag[7]) { if (tid == 0) { life.S.err[4] = stat[15]; *life.S.upd_count = 0; } }   // the update launch queued behind this kernel becomes a no-op (its lists are last frame's)
         else dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, reinterpret_cast<int*>(S.bm) + 4096);
     }
 }

@@ -42,6 +42,15 @@ struct LiveInfo {                    // tracker_info_t (td.cpp:271-290)
     int id; unsigned tid; int age, visible, invisible; bbox_t bbox;
 };
 
+// roctx ranges around the host-side enqueue of every stage (tracing).  Opt-in (MOT_ROCTX=1): the marker
+// library (librocprofiler-sdk-roctx, what `rocprofv3 --marker-trace` records) is dlopen'ed on first use, so the product has
+// no link-time dependency on a profiler and pays one predictable branch per stage when tracing is off.
+struct RoctxRange {
+    explicit RoctxRange(const char* name);
+    ~RoctxRange();
+    bool on;
+};
+
 struct DevLoop;                      // device-resident frame loop state (mot_devloop.hip)
 void devloop_destroy(DevLoop*);
 

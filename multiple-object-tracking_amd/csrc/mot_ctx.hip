@@ -2,6 +2,7 @@
 // (include/mot_abi.h).  There is no CPU compute path in this file: every stage
 // is a HIP kernel launch; when no device is available the calls fail.
 #include "mot_ctx.h"
+#include <dlfcn.h>
 
 #include "sse_tables.inc"
 
@@ -21,6 +22,30 @@ int fail(int code, const char* fmt, ...)
 
 namespace mot_impl {
 int ensure_device(mot_ctx* c) { HIPCHK(hipSetDevice(c->cfg.device)); return MOT_OK; }
+
+namespace {
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool tried = false; };
+RoctxApi& roctx_api()
+{
+    static RoctxApi api;
+    if (!api.tried) {
+        api.tried = true;
+        const char* ev = getenv("MOT_ROCTX");
+        if (ev && atoi(ev) != 0) {
+            void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                api.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                api.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (!api.push || !api.pop) { api.push = nullptr; api.pop = nullptr; }
+            }
+        }
+    }
+    return api;
+}
+} // namespace
+RoctxRange::RoctxRange(const char* name) { RoctxApi& a = roctx_api(); on = a.push != nullptr; if (on) a.push(name); }
+RoctxRange::~RoctxRange() { if (on) roctx_api().pop(); }
 } // namespace mot_impl
 
 namespace {
@@ -227,6 +252,7 @@ int new_tracks_common(mot_ctx* c, const bbox_t* boxes, int n, int* ids_out)
 int run_batch(mot_ctx* c, bool predict, const int* ids, int n, const float* const* patches,
               const bbox_t* boxes_in, bbox_t* boxes_out, int clamp)
 {
+    RoctxRange range_(predict ? "mot.predict_batch" : "mot.update_batch");
     int rc = ensure_device(c); if (rc) return rc;
     rc = check_n(c, n); if (rc) return rc;
     if (n == 0) return MOT_OK;
@@ -293,6 +319,7 @@ int do_delete(mot_ctx* c, const int* ids, int n)
 
 int assign_device(mot_ctx* c, const bbox_t* trk, int nT, const bbox_t* det, int nD, int* assigned_trackers, int* assigned_detected, double* cost_out)
 {
+    RoctxRange range_("mot.assign");
     if (nT > c->cfg.max_tracks || nD > c->cfg.max_dets || nT > 1024 || nD > 1024) return fail(MOT_ERR_CAPACITY, "assign: %d tracks x %d detections exceeds capacity", nT, nD);
     for (int i = 0; i < nT; i++) assigned_trackers[i] = -1;            // td.cpp:472-479
     for (int j = 0; j < nD; j++) assigned_detected[j] = -1;
@@ -622,6 +649,14 @@ int mot_step_frame(mot_ctx* c, const bbox_t* dets, int nD, bbox_t* predicted, in
     if (c->cfg.world != 1) return fail(MOT_ERR_STATE, "sharded context: use mot_step_begin / all-gather / mot_step_finish");
     int rc = mot_step_begin(c, nullptr, nullptr); if (rc) return rc;
     return mot_step_finish(c, nullptr, dets, nD, predicted, assigned_trackers, n_before, live_boxes, live_tids, n_live);
+}
+
+int mot_step_frame_chain(mot_ctx* c, const bbox_chain_t* detected, bbox_t* predicted, int* assigned_trackers, int* n_before,
+                         bbox_t* live_boxes, unsigned* live_tids, int* n_live)
+{   // td.cpp:330-333: ndetected = pdetected->nbox, boxes = pdetected->bbox
+    if (!c || !detected) return fail(MOT_ERR_ARG, "null argument");
+    if (detected->nbox < 0 || detected->nbox > MOT_CHAIN_MAX_BOXES) return fail(MOT_ERR_ARG, "bbox_chain_t.nbox = %d outside 0..%d", detected->nbox, MOT_CHAIN_MAX_BOXES);
+    return mot_step_frame(c, detected->bbox, detected->nbox, predicted, assigned_trackers, n_before, live_boxes, live_tids, n_live);
 }
 
 // ---- introspection ----------------------------------------------------------

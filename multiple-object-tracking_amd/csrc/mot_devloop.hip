@@ -77,6 +77,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     if (S.kind == MOT_TRACKER_KCF && c->cfg.dev_size_lo > 0) {
         // per-track template sizes: one pool per square size; all descriptors in a device table, one HBM scratch for all
         S.cls_lo = c->cfg.dev_size_lo; S.ncls = c->cfg.dev_size_hi - c->cfg.dev_size_lo + 1;
+        if (S.ncls == 1) S.rows = S.cols = S.cls_lo;                     // lo == hi: the single-template path, with THAT template (not dev_rows x dev_cols)
         std::vector<KcfPool> tab((size_t)S.ncls);
         size_t maxf = 0; unsigned maxlds = 0; int use0 = -1;
         for (int k = 0; k < S.ncls; k++) {
@@ -161,6 +162,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
 
 int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, const void* dets_dev = nullptr, int nD = 0)
 {
+    RoctxRange range_("mot.frame.predict");
     DLState& S = d->S;
     if (d->begun) return fail(MOT_ERR_STATE, "mot_step_begin_device called twice");
     if (S.kind == MOT_TRACKER_KCF && !frame_dev) return fail(MOT_ERR_ARG, "null frame");
@@ -194,6 +196,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
 
 int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev, int nD, hipEvent_t* ev)
 {
+    RoctxRange range_("mot.frame.assoc_update");
     DLState& S = d->S;
     if (!d->begun) return fail(MOT_ERR_STATE, "mot_step_finish_device without mot_step_begin_device");
     d->begun = false;

@@ -295,3 +295,23 @@ def test_device_loop_detector_noise_dense_solver(mot, oracle):
     st = c.lap_stats()
     assert st[29] >= 3 and st[30] >= 2, st.tolist()                  # dense solver ran / was certified (the first noisy frame arms it)
     m.close(); c.close()
+
+
+def test_device_loop_single_size_class_lo_equals_hi(mot, oracle):
+    """dev_size_lo == dev_size_hi != dev_rows (round-2 advisor finding): one size class means the single-template path with THAT
+    template -- detections of size lo must spawn and be tracked in a lo x lo template, not be dropped against dev_rows = 80"""
+    from multiple_object_tracking_amd import synth
+    n, size, nframes = 40, 64, 5
+    scene = synth.Scene(n, size, stream_id=46, miss_pct=5, fp_pct=3)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    c = mot.MotContext(max_tracks=128, max_dets=128, dev_size=80, dev_sizes=(size, size))
+    m = orc.OracleMot(oracle, 0, 0, 128)
+    for f in range(nframes):
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        boxes, tids, ages = c.live_tracks()
+        assert len(tids) > 0 and np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    m.close(); c.close()

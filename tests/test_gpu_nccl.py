@@ -71,3 +71,21 @@ def test_two_ranks_rccl_all_gather():
     for p in procs:
         p.join(timeout=120)
     assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)
+
+
+def test_bench_sharded_branch_two_ranks_one_gpu():
+    """bench.py's sharded branch (begin -> all-gather -> finish, max over ranks, rank-0 JSON line) with two ranks on ONE GPU:
+    MOT_BENCH_BACKEND=gloo stages the all-gather through the host, so the code path the driver's N > 1 runs take executes on the
+    single-GPU test box too (RCCL itself refuses two ranks on one device).  A smoke test, never a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, MOT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--tracks", "96", "--steady", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "strong" and j["config"]["live_tracks_end"] == 96
+    assert j["smoke_backend"].startswith("gloo") and j["value"] > 0

@@ -47,8 +47,13 @@ while time.time() - t0 < budget:
     st = c.lap_stats()
     used[int(st[15]) % 3] += 1
     if not ok or cost != rc:
-        np.savez("gpurun_out/assign_stress_fail.npz", trk=mot_amd.boxes_array(trk), det=mot_amd.boxes_array(det))
-        print("MISMATCH", n, nT, nD, st[:16].tolist()); sys.exit(1)
+        # never overwrite: every failing problem becomes a regression fixture (tests/golden/make_assoc_regressions.py appends it)
+        os.makedirs("gpurun_out", exist_ok=True)
+        k = 0
+        while os.path.exists(f"gpurun_out/assign_stress_fail_{seed}_{k}.npz"):
+            k += 1
+        np.savez(f"gpurun_out/assign_stress_fail_{seed}_{k}.npz", trk=mot_amd.boxes_array(trk), det=mot_amd.boxes_array(det))
+        print("MISMATCH", n, nT, nD, st[:16].tolist(), f"-> gpurun_out/assign_stress_fail_{seed}_{k}.npz"); sys.exit(1)
     n_cases += 1
 st = c.lap_stats()
 print(f"assign_stress OK: {n_cases} problems, decided by certificate / sparse emulation / dense emulation = {used}; dense solver ran in {int(st[29])} launches, {int(st[30])} of them certified")
