@@ -354,6 +354,9 @@ def main():
                 used_by[int(ctx.lap_stats()[15]) % 3] += 1
                 if args.debug_assoc:
                     print("assoc", ctx.assoc_stats().tolist(), file=sys.stderr)
+                    ls = ctx.lap_stats()
+                    print(f"lap frame {f}: chain {assoc_ms[-1] * 1e3:.0f} us | cert outcome {ls[0]} solver rounds {ls[1]} free {ls[2]} ticks {ls[7]} | "
+                          f"sparse status {ls[8]} aug {ls[9]} s5 {ls[10]} events {ls[11]} t_s3 {ls[12] / 100:.1f} us t_s5 {ls[13] / 100:.1f} us total {ls[14] / 100:.1f} us | decided {ls[15]}", file=sys.stderr)
                     pa, ub = ctx.debug_kcf_phases(True)
                     print("kcf predict phases us", (np.diff(pa) / 100.0).round(1).tolist(), "update", (np.diff(ub) / 100.0).round(1).tolist(), file=sys.stderr)
                 f += 1

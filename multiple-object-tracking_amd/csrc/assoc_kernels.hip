@@ -360,6 +360,46 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
     __syncthreads();
 }
 
+// Working matrix d = cost - row minimum (hungarian.cpp:83-89) and the zero bitmaps in both orientations, computed by the Munkres
+// workgroup itself (thread = row, rows <= columns): what assoc_sub_kernel does chip-wide.  Behind the fast path the dense
+// emulation is the rare last resort, so its preparation is not launched per frame any more (one early-exit launch less on every
+// frame); a stream that keeps needing it gets the chip-wide kernel back through the host-side hint.  ~0.4 ms at 1024 x 1024.
+__device__ void mk_prepare_dense(const AssocArgs& a, int nR, int nC, bool rowsTrk)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = tid, wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
+    const double rmin = r < nR ? dunkey(a.linemin[r]) : 0.0;            // the row scan left the row minima here
+    u64 zw = 0;
+    for (int c = 0; c < nC; c++) {
+        bool z = false;
+        if (r < nR) {
+            const double d = elem_cost(a, r, c, nR, rowsTrk) - rmin;
+            a.ws.dist[(size_t)r + (size_t)nR * c] = d;
+            z = fabs(d) < DBL_EPSILON;
+        }
+        const u64 bal = __ballot(z);
+        if (lane == 0 && wave < wordsR) a.ws.zc[(size_t)c * wordsR + wave] = bal;
+        if (z) zw |= 1ull << (c & 63);
+        if ((c & 63) == 63 || c == nC - 1) { if (r < nR) a.ws.zr[(size_t)r * wordsC + (c >> 6)] = zw; zw = 0; }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// what the last kernel of a fast-path chain leaves behind: statistics, the scheduling hints for the host, re-armed header
+__device__ inline void lap_final_bookkeeping(const AssocArgs& a, int mode, bool certified)
+{
+    const LapWs& L = a.ws.lap;
+    L.hdr[LAP_H_LAST + 15] = mode == 0 ? 0 : (certified ? 1 : 2);   // what this frame used: 0 certificate, 1 sparse emulation, 2 dense emulation
+    const int outcome = L.hdr[LAP_H_LAST], dense_ran = L.hdr[LAP_H_DENSE];
+    if (dense_ran) { L.hdr[LAP_H_DSTAT + 3] += 1; if (mode == 0) L.hdr[LAP_H_DSTAT + 4] += 1; }
+    if (a.ws.dense_hint) *reinterpret_cast<volatile int*>(a.ws.dense_hint) = (certified ? 0 : 1) | ((dense_ran || outcome == 1 || outcome == 2) ? 2 : 0);
+    if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
+    // re-arm for the next launch (this workgroup is the last reader)
+    L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2;
+    L.hdr[LAP_H_DENSE] = 0; L.hdr[LAP_H_DONE] = 0; L.hdr[LAP_H_CERT] = 0; *L.cmaxkey = 0ull;
+}
+
 // HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
 // HELP = true : launched with 1 + MK_HELPERS workgroups; workgroups 1.. run mk_helper_loop.
 // lap_mode: the fast path (lap_kernels.hip) ran in front of this launch; if its certificate holds (lap_certify.h) the
@@ -379,7 +419,21 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     const int nhelp = HELP ? ((int)gridDim.x - 1) / MK_XCDS : 0;                   // 0: everything in this workgroup
     // Workgroups are dealt to the 8 XCDs round-robin by index, so blocks 0, 8, 16, ... share the controller's XCD: the hand-offs
     // then stay behind one L2 (-0.4 us per step 5; placement only affects speed, never correctness).  The other blocks exit.
-    if (HELP && blockIdx.x > 0) { if (blockIdx.x % MK_XCDS == 0 && nR > 0 && nC > 0) mk_helper_loop(a, S, nR, nC); return; }
+    // an earlier kernel of the chain (the solver's fused tail / the sparse emulation) has already decided AND committed this frame
+    // (lifecycle step included): bookkeeping only.  (The live count, and with it nR / nC, already belong to the next frame.)
+    const bool committed = lap_mode && a.ws.lap.hdr[LAP_H_DONE] != 0;
+    if (HELP && blockIdx.x > 0) { if (blockIdx.x % MK_XCDS == 0 && nR > 0 && nC > 0 && !committed) mk_helper_loop(a, S, nR, nC); return; }
+    if (committed) {
+        const int mode = a.ws.lap.hdr[LAP_H_MODE];
+        __syncthreads();
+        if (tid == 0) { lap_final_bookkeeping(a, mode, true); stat[15] = 0; stat[0] = -1; stat[1] = 0; stat[2] = 0; stat[12] = (int)(wall_clock64() - t_begin); }
+        if (tid < MK_MAXN) a.linemin[tid] = ~0ull;
+        if (HELP && uwave == 0 && a.ws.ctl) {                            // helpers are spinning on the cover-mask granules: release them
+            if (lane == 0) ctl_st(a.ws.ctl + CTL_EPOCH, (u64)((unsigned)ctl_ld(a.ws.ctl + CTL_EPOCH) + 1));
+            ctl_st(a.ws.ctl + CTL_COV + lane, (u64)MK_TAG_EXIT << 32);
+        }
+        return;
+    }
     if (nR <= 0 || nC <= 0) {
         if (tid == 0) { *a.ws.cost = 0.0; stat[15] = 0; }
         for (int r = tid; r < max(nR, 0); r += MK_THREADS) a.ws.assignment[r] = -1;
@@ -398,15 +452,8 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         if (mode == 0) { certified = true; given = L.colOfRow; }
         else if (mode == 1 && !spviol) { certified = true; given = L.spAssign; }
         __syncthreads();
-        if (tid == 0) {
-            L.hdr[LAP_H_LAST + 15] = mode == 0 ? 0 : (certified ? 1 : 2);   // what this frame used: 0 certificate, 1 sparse emulation, 2 dense emulation
-            const int outcome = L.hdr[LAP_H_LAST], dense_ran = L.hdr[LAP_H_DENSE];
-            if (dense_ran) { L.hdr[LAP_H_DSTAT + 3] += 1; if (mode == 0) L.hdr[LAP_H_DSTAT + 4] += 1; }
-            if (a.ws.dense_hint) *reinterpret_cast<volatile int*>(a.ws.dense_hint) = (certified ? 0 : 1) | ((dense_ran || outcome == 1 || outcome == 2) ? 2 : 0);
-            if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
-            // re-arm for the next launch (this workgroup is the last reader)
-            L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2; L.hdr[LAP_H_DENSE] = 0; *L.cmaxkey = 0ull;
-        }
+        if (tid == 0) lap_final_bookkeeping(a, mode, certified);
+        if (!certified && (want_cost & 4)) mk_prepare_dense(a, nR, nC, rowsTrk);   // the chip-wide preparation was not launched
     }
     if (tid < MK_MAXN) a.linemin[tid] = ~0ull;                         // re-arm the line minima for the next launch's assoc_min_kernel (no memset per frame)
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
@@ -874,9 +921,9 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
     return hipGetLastError();
 }
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid);   // lap_kernels.hip
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life);   // lap_kernels.hip
 hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s);                     // lap_dense.hip
-hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s);   // mk_sparse.hip
+hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, const LifeArgs& life);   // mk_sparse.hip
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
                         const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid, const LifeArgs* life_in)
@@ -903,6 +950,9 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         lap_min = (e0 && atoi(e0) == 0) ? (1 << 30) : (e1 ? (atoi(e1) > 1 ? atoi(e1) : 1) : MK_LAP_MIN_LINES);
     }
     const bool lap = ws.lap.ccol && maxR > 0 && maxR <= maxC && lines >= lap_min;
+    // scheduling hint left by the final kernel of earlier launches in pinned host memory, read without synchronisation (stale by a
+    // frame or two: it only picks grids, never results): the stream keeps needing the dense emulation / the dense solver
+    bool hinted_now = false, prep_in_kernel = false;                  // (evaluated behind the countdown update below)
     // small problems: the Munkres workgroup computes cost, minima and bitmaps itself (mk_fused_cost)
     const bool fused = lines <= MK_FUSE_LINES && !lap;
     hipError_t e = hipSuccess;
@@ -910,7 +960,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
         if (lap) {
-            e = launch_lap_front(a, gR, gC, s, ev_mid); if (e != hipSuccess) return e;
+            e = launch_lap_front(a, gR, gC, s, ev_mid, life); if (e != hipSuccess) return e;
             ev_mid = nullptr;
             // Dense solver (lap_dense.hip) for frames whose far matches defeat the sparse one (detector misses + false positives): its
             // three launches return at once when the sparse solver succeeded, but they are not even submitted unless one of the last
@@ -928,8 +978,14 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
                 want_dense = h[1] > 0;
             }
             if (want_dense) { e = launch_lap_dense(a, gR, gC, s); if (e != hipSuccess) return e; }
-            e = launch_mk_sparse(a, gR, gC, s); if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a, 1);   // working matrix + bitmaps, only if the dense emulation must run
+            e = launch_mk_sparse(a, gR, gC, s, life); if (e != hipSuccess) return e;
+            // working matrix + bitmaps for the dense emulation: chip-wide (lazy: every workgroup checks the verdict and leaves) for caller
+            // matrices and for streams whose recent frames needed it; otherwise the final kernel prepares them itself if it has to
+            hinted_now = ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0);
+            static int helpers_forced = -1;
+            if (helpers_forced < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers_forced = (ev && atoi(ev)) ? 1 : 0; }
+            prep_in_kernel = !a.user && !hinted_now && !helpers_forced;
+            if (!prep_in_kernel) hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a, 1);
         }
         else {
             hipLaunchKernelGGL(assoc_min_kernel, dim3(gR, gC), dim3(256), 0, s, a);
@@ -956,9 +1012,9 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // (whose launch alone costs more than the common case's whole final kernel)
     // ... unless the stream keeps needing it (detector misses + false positives force far matches no tier can certify): the final
     // kernel leaves a hint in pinned host memory, read here without synchronisation (stale by a frame or two: it only picks the grid)
-    const bool hinted = lap && ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0);   // (a noisy stream: the countdown above is armed)
-    const bool big = ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
+    const bool hinted = hinted_now;                                    // (a noisy stream: the countdown above is armed)
+    const bool big = !prep_in_kernel && ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
-    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0), life, lap ? 1 : 0);
+    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0) | (prep_in_kernel ? 4 : 0), life, lap ? 1 : 0);
     return hipGetLastError();
 }

@@ -14,13 +14,15 @@ namespace assoc {
 
 // scratch: >= LAP_EDGES unsigned + 2 * (MK_MAXN + 64) bytes of LDS.  Returns 0 (workgroup-uniform) iff certified, else the
 // reason: 1 solver gave up / not applicable, 2 infeasible dual, 3 too many near-tight edges, 4 tied optima.
-__device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scratch, int* flag2)
+// in_lds: the caller (the fused dual check of lap_solve_kernel) has already put the edge list into scratch[0..ne) and passes ne / viol / solve
+// itself; otherwise they come from the header and the list from L.edges (written by lap_verify_kernel in an earlier launch).
+__device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scratch, int* flag2, bool in_lds = false, int ne_in = 0, int viol_in = 0, int solve_in = 0)
 {
     const int tid = threadIdx.x;
     unsigned* ed = scratch;
     unsigned char* alive = reinterpret_cast<unsigned char*>(scratch + LAP_EDGES);
     unsigned char* hasout = alive + MK_MAXN + 64;
-    const int solve = L.hdr[LAP_H_SOLVE], viol = L.hdr[LAP_H_VIOL], ne = L.hdr[LAP_H_NEDGES], bad = L.hdr[LAP_H_BAD];
+    const int solve = in_lds ? solve_in : L.hdr[LAP_H_SOLVE], viol = in_lds ? viol_in : L.hdr[LAP_H_VIOL], ne = in_lds ? ne_in : L.hdr[LAP_H_NEDGES], bad = L.hdr[LAP_H_BAD];
     int reason = 0;                                                     // 0 certified, 1 solver gave up / n.a., 2 infeasible dual, 3 too many near-tight edges, 4 tie
     if (solve != 0 || bad) reason = 1; else if (viol) reason = 2; else if (ne > LAP_EDGES) reason = 3;
     int ncyc = 0;
@@ -32,7 +34,7 @@ __device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scra
             const int lane = tid;
             unsigned* aw = reinterpret_cast<unsigned*>(alive); unsigned* hw = reinterpret_cast<unsigned*>(hasout);
             for (int i = lane; i < (MK_MAXN + 64) / 4; i += 64) { aw[i] = 0; hw[i] = 0; }
-            for (int e = lane; e < ne; e += 64) { const unsigned x = L.edges[e]; ed[e] = x; alive[x >> 16] = 1; }
+            for (int e = lane; e < ne; e += 64) { const unsigned x = in_lds ? ed[e] : L.edges[e]; ed[e] = x; alive[x >> 16] = 1; }
             for (int it = 1;; it++) {
                 for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; if (alive[x >> 16] && alive[x & 0xFFFF]) hasout[x >> 16] = (unsigned char)it; }
                 bool ch = false;
@@ -49,7 +51,7 @@ __device__ inline int lap_certify(const LapWs& L, int nR, int nC, unsigned* scra
         ncyc = flag2[1] ? 2 : 0;                                        // (a count is only kept by the block path below)
         if (ncyc) reason = 4;
     } else if (!reason) {
-        for (int e = tid; e < ne; e += MK_THREADS) ed[e] = L.edges[e];
+        if (!in_lds) for (int e = tid; e < ne; e += MK_THREADS) ed[e] = L.edges[e];
         for (int i = tid; i <= nR; i += MK_THREADS) alive[i] = 1;
         __syncthreads();
         // peel nodes without an edge into the still-alive set; what survives lies on or leads into a cycle

@@ -21,6 +21,9 @@
 // order-exact emulation runs as before.  lap_model.c (CPU model, test infrastructure) is the CPU model of this file; tests/test_lap_model.py
 // fuzzes "certified => equal to the reference" on CPU, tests/test_gpu_parity.py on the device.
 #include "assoc_common.h"
+#include "lap_certify.h"
+#include "lap_grid.h"
+#include "dl_lifecycle.h"
 
 using namespace assoc;
 
@@ -157,8 +160,18 @@ struct LapShared {
     unsigned short flist[MK_MAXN];
     int wave_tot[MK_THREADS / 64];
     int flag[8];
+    double margins[2];                   // eps, tol for the fused dual check
 };
 static_assert(sizeof(LapShared) <= MOT_LDS_LIMIT, "lap_solve_kernel LDS");
+// fused tail (box costs): the candidate costs `cc` are dead once the solver is done; their 64 KB hold the certificate's scratch
+// (edge list + peel flags), the lifecycle step's scratch and a uniform grid over the column boxes
+struct LapFused {
+    unsigned certify[LAP_EDGES + (2 * (MK_MAXN + 64) + 3) / 4];
+    int life[DL_LIFE_SCRATCH_INTS];
+    ColGrid grid;
+    int ne, viol;
+};
+static_assert(sizeof(LapFused) <= sizeof(double) * MK_MAXN * LAP_K, "fused tail overlays the candidate costs");
 static_assert(LAP_TS <= 32 && LAP_K <= 16 && (LAP_K & (LAP_K - 1)) == 0, "search state: one touched column per lane, candidates in the low lanes");
 
 __device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-uniform
@@ -167,7 +180,14 @@ __device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-
     return __longlong_as_double((long long)readlane64(b, src));
 }
 
-__global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
+// fused != 0 (box costs, not a caller matrix): the dual check, the uniqueness certificate and -- device loop, certified frame --
+// the lifecycle step run in THIS workgroup right behind the solver instead of in three more launches.  The dual check is
+// spatial: prices are <= 0 (checked per column), so the reduced cost of (i, j) is at least c[i][j] - u_i, and only the columns
+// whose box lies within (u_i + eps) * 1280 px of row i's -- looked up in a uniform grid over the column boxes -- can be
+// near-tight or infeasible; cross-class entries cost >= 1.0 and matter only for a row with u_i + eps >= 1, which scans every
+// column.  Same arithmetic per examined entry as lap_verify_kernel (the dense pass stays for caller matrices and behind the
+// dense solver).
+__global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int fused, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
     LapShared& S = *reinterpret_cast<LapShared*>(lap_raw);
@@ -397,11 +417,81 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a)
         L.dhdr[0] = fmax(1e-9, 1e-15 * n3) * mag;                      // eps: see the header of lap_model.c (CPU model, test infrastructure)
         L.dhdr[1] = 1e-12 * mag;                                       // tol
         L.dhdr[2] = gamma; L.dhdr[3] = cmax;
+        S.margins[0] = L.dhdr[0]; S.margins[1] = L.dhdr[1];
         L.hdr[LAP_H_SOLVE] = status;
         L.hdr[LAP_H_LAST + 1] = rounds; L.hdr[LAP_H_LAST + 2] = free0; L.hdr[LAP_H_LAST + 3] = searches; L.hdr[LAP_H_LAST + 4] = ctot;
         L.hdr[LAP_H_LAST + 7] = (int)(wall_clock64() - t_begin);
         L.hdr[49] = (int)(t_init - t_begin); L.hdr[50] = (int)t_sr; L.hdr[51] = (int)t_cm; L.hdr[52] = (int)(wall_clock64() - t_loop);   // (debug: phase ticks)
     }
+    if (!fused || a.user) return;
+    // ================= fused tail: dual check (spatial) -> certificate -> lifecycle =================
+    __syncthreads();                                                   // margins are in LDS; every read of `cc` lies behind us
+    if (status) return;                                                // the solver gave up: the dense solver / the emulation decide (LAP_H_CERT stays 0)
+    const long long t_tail = wall_clock64();
+    LapFused& F = *reinterpret_cast<LapFused*>(S.cc);
+    const double eps = S.margins[0], tol = S.margins[1];
+    if (tid == 0) { F.ne = 0; F.viol = 0; }
+    const bool big = grid_build(F.grid, a, nR, nC, rowsTrk, S.wave_tot);   // (ends with a barrier)
+    bbox_t rb = {}; int rcx = 0, rcy = 0;
+    if (tid < nR) { rb = rowsTrk ? a.trk[tid] : a.det[tid]; rcx = (rb.l + rb.r) >> 1; rcy = (rb.t + rb.b) >> 1; }
+    // ---- rows: every entry that can be infeasible or near-tight ----
+    bool viol = false;
+    auto examine = [&](int j, double cst, double ui, int mi) {
+        if (j == mi) return;
+        const double red = (cst - S.v[j]) - ui;
+        if (!(red >= -tol)) viol = true;
+        else if (red < eps) {
+            const int e = atomicAdd(&F.ne, 1);
+            const int owner = S.rowOfCol[j];
+            if (e < LAP_EDGES) F.certify[e] = ((unsigned)tid << 16) | (unsigned)(owner >= 0 ? owner : nR);
+        }
+    };
+    if (tid < nR) {
+        const int mi = S.colOfRow[tid];
+        if (mi < 0 || mi >= nC || S.rowOfCol[mi] != tid) viol = true;      // the matching itself: every row owns exactly the column that names it
+        else {
+            const double ui = S.mcost[tid] - S.v[mi];                     // == L.u[tid]
+            const double reach = ui + eps;
+            if (big || !(reach < 1.0)) {
+                for (int j = 0; j < nC; j++) {
+                    const bbox_t cb = rowsTrk ? a.det[j] : a.trk[j];
+                    examine(j, rowsTrk ? pair_cost(rb, cb) : pair_cost(cb, rb), ui, mi);
+                }
+            } else {
+                // >= reach * 1280 + 1: a same-class column farther away costs more than reach (cross-class: cost >= 1 > u_i + eps)
+                const int Ri = (int)(reach * (double)MOT_FRAME_W) + 2;
+                grid_query(F.grid, rcx, rcy, rb.type, Ri, [&](int j, int d2) { examine(j, cost_of_d2(d2, false), ui, mi); });
+            }
+        }
+    }
+    // ---- columns: prices <= 0, exactly 0 on free columns; "a free column could take this column's row" ----
+    if (tid < nC) {
+        const double vc = S.v[tid];
+        const int owner = S.rowOfCol[tid];
+        if (!(vc <= 0.0) || (owner < 0 && vc != 0.0)) viol = true;
+        else if (owner >= 0 && nC > nR && -vc < eps) {
+            const int e = atomicAdd(&F.ne, 1);
+            if (e < LAP_EDGES) F.certify[e] = ((unsigned)nR << 16) | (unsigned)owner;
+        }
+    }
+    const int anyviol = __syncthreads_or(viol) ? 1 : 0;
+    const int ne = F.ne;
+    __syncthreads();
+    const int reason = lap_certify(L, nR, nC, F.certify, S.flag, true, ne, anyviol, 0);
+    __syncthreads();
+    if (tid == 0) {
+        L.hdr[LAP_H_VIOL] = anyviol; L.hdr[LAP_H_NEDGES] = ne;
+        L.hdr[LAP_H_CERT] = reason + 1;
+        if (reason == 0) L.hdr[LAP_H_MODE] = 0;
+        L.hdr[55] = (int)(wall_clock64() - t_tail);                      // (debug: dual check + certificate ticks)
+    }
+    if (reason != 0 || !life.enabled) return;
+    // certified and in the device loop: commit the frame here (td.cpp:472-644); the rest of the chain returns at once
+    if (tid < nR) a.ws.assignment[tid] = S.colOfRow[tid];
+    __threadfence_block();
+    __syncthreads();
+    dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, F.life);
+    if (tid == 0) { L.hdr[LAP_H_DONE] = 1; L.hdr[56] = (int)(wall_clock64() - t_tail); }
 }
 
 // ---- stage 3 ----------------------------------------------------------------------------------------------------
@@ -456,6 +546,9 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a, int again)
             }
         }
     }
+    // the matching itself (first column tile only): every row owns exactly the column that names it -- two rows on one column
+    // would pass the dual check and the acyclicity certificate, and be committed as two tracks adopting one detection
+    if (blockIdx.y == 0 && wave == 0 && r < nR && (mr < 0 || mr >= nC || (int)L.rowOfCol[mr] != r)) viol = true;
     // per column (first row tile only): prices <= 0, exactly 0 on free columns; "a free column could take this column's row"
     if (blockIdx.x == 0 && threadIdx.x < 64 && c0 + (int)threadIdx.x < nC) {
         const double vc = colv[threadIdx.x];
@@ -471,7 +564,7 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a, int again)
 
 } // namespace
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid)
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life)
 {
     static int attr_dev = -1;                                          // per-device function attribute
     int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
@@ -487,8 +580,12 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     if (ev_mid && early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
     if (ev_mid && !early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a);
-    hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a, 0);
+    // box costs: solver + dual check + certificate (+ lifecycle) in one workgroup; caller matrices keep the dense dual check
+    static int fuse = -1;
+    if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
+    const int fused = (fuse && !a.user) ? 1 : 0;
+    hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a, fused, life);
+    if (!fused) hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a, 0);
     return hipGetLastError();
 }
 

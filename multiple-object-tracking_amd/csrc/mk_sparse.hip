@@ -20,8 +20,11 @@
 //     and hz = {c : tlive[c] != 0} as a bit mask: "the next uncovered column with an uncovered zero" is one masked
 //     find-first-bit, "its first uncovered zero row" one LDS round trip, and covering a row one LDS atomic per zero of
 //     that row; after an augmentation (all rows uncovered, :324-330) tlive = tzero.
+#include <stddef.h>
 #include "assoc_common.h"
 #include "lap_certify.h"
+#include "lap_grid.h"
+#include "dl_lifecycle.h"
 
 using namespace assoc;
 
@@ -31,7 +34,7 @@ namespace {
 #define SP_TLS 32               /* slots per column in the transposed lists; a column wanted by more rows: not applicable */
 
 struct SpShared {
-    double Scol[MK_MAXN];                    // S_j
+    double Scol[MK_MAXN];                    // S_j   (member order keeps `tl` 8-byte aligned: it is filled and read as uint2)
     u64 hkey;                                // step 5: order-preserving key of the minimum (LDS atomicMin, one per wavefront)
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
     unsigned tzero[MK_MAXN];                 // per column: which of its slots hold a zero
@@ -51,13 +54,21 @@ struct SpShared {
     int flag[8];
 };
 static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
+static_assert(offsetof(SpShared, tl) % 8 == 0, "transposed lists are accessed as uint2");
 static_assert(SPK <= 16 && (SPK & (SPK - 1)) == 0 && (SP_TLS & (SP_TLS - 1)) == 0, "candidate index is packed into 4 bits; lane masks");
 static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certify scratch");
+// after the run the transposed lists are dead: their 64 KB hold the column grid of the fused after-the-fact check and the
+// lifecycle step's scratch
+struct SpPost { ColGrid grid; int life[DL_LIFE_SCRATCH_INTS]; double red[MK_THREADS / 64]; };
+static_assert(sizeof(SpPost) <= sizeof(unsigned short) * SP_TLS * MK_MAXN, "post-check overlay");
 
 __device__ __forceinline__ bool bit_of(const u64* m, int i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
 __device__ __forceinline__ void lds_clear_bit64(u64* words, int i) { atomicAnd(reinterpret_cast<unsigned*>(words) + (i >> 5), ~(1u << (i & 31))); }
 
-__global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int mk_batch)
+// post_fused (box costs): the after-the-fact check runs in this workgroup as a disc query per row over a grid of the column boxes
+// (same bound per examined entry as mk_postcheck_kernel; an entry that is not examined satisfies it a fortiori, see below), and -- device
+// loop -- an accepted run is committed here (lifecycle step), so a tie frame needs no further kernel of the chain.
+__global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int mk_batch, int post_fused, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_raw[];
     SpShared& S = *reinterpret_cast<SpShared*>(sp_raw);
@@ -68,7 +79,10 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
     if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }
     // ---- the fast path's verdict first: a certified unique optimum needs no emulation at all ----
     const int bad = L.hdr[LAP_H_BAD];
-    const int reason = lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(sp_raw), S.flag);
+    if (L.hdr[LAP_H_DONE]) return;                                     // certified and committed by the solver's workgroup (fused tail, lap_kernels.hip)
+    // the solver's workgroup may already have evaluated the certificate (box costs); behind the dense solver it is evaluated again here
+    const int pre = L.hdr[LAP_H_DENSE] ? 0 : L.hdr[LAP_H_CERT];
+    const int reason = pre ? pre - 1 : lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(sp_raw), S.flag);
     __syncthreads();
     const long long t_cert = wall_clock64();
     if (reason == 0) { if (tid == 0) L.hdr[LAP_H_MODE] = 0; return; }
@@ -99,26 +113,55 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
     for (int k = 0; k < SPK; k++) S.cj[k * MK_MAXN + r] = myc[k];
     S.zmask[r] = (unsigned short)zm;
     __syncthreads();
-    {   // transposed lists: fill (any order), then sort each column's list by row (rows sit in the high bits)
+    {   // transposed lists: fill (any order), then sort each column's list by row.  The longest list bounds a per-column
+        // insertion sort (up to 32 entries of one thread: 20 us of dependent LDS round trips in a crowded scene); instead every
+        // ENTRY finds its rank by counting the smaller rows of its list -- all reads, then a barrier, then all writes.
         const int mycnt = tid < nC ? S.cnt[tid] : 0;
         if (mycnt > SP_TLS) S.flag[0] = 1;
         __syncthreads();
         if (S.flag[0]) { if (tid == 0) { L.hdr[LAP_H_MODE] = 2; L.hdr[LAP_H_LAST + 8] = 2; } return; }
         S.cnt[tid] = 0;
+        {   // every slot starts as "no entry" (0xFFFF sorts behind every row): 64 KB, 8-byte stores (the array is 8-byte aligned)
+            uint2* t8 = reinterpret_cast<uint2*>(S.tl);
+            const uint2 ff = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (int i = tid; i < SP_TLS * MK_MAXN * 2 / 8; i += MK_THREADS) t8[i] = ff;
+        }
         __syncthreads();
         if (r < nR) {
 #pragma unroll
             for (int k = 0; k < SPK; k++) if (myc[k] != 0xFFFF) { const int p = atomicAdd(&S.cnt[myc[k]], 1); S.tl[myc[k] * SP_TLS + p] = (unsigned short)((r << 4) | k); }
         }
         __syncthreads();
-        if (tid < nC) {
-            unsigned short* t = S.tl + tid * SP_TLS;
-            for (int i = 1; i < mycnt; i++) { const unsigned short x = t[i]; int j = i - 1; while (j >= 0 && t[j] > x) { t[j + 1] = t[j]; j--; } t[j + 1] = x; }
-            unsigned zb = 0;
-            for (int i = 0; i < mycnt; i++) { const int e = t[i]; S.pos[(e & 15) * MK_MAXN + (e >> 4)] = (unsigned char)i; if ((S.zmask[e >> 4] >> (e & 15)) & 1) zb |= 1u << i; }
-            for (int i = mycnt; i < SP_TLS; i++) t[i] = 0xFFFF;
-            S.tzero[tid] = zb; S.tlive[tid] = zb;                      // all rows uncovered
-        } else S.tlive[tid] = 0;
+        // rank of an entry = entries of its list with a smaller packed value ((row << 4) | k: a row lists a column once, so the order is
+        // the row order); four slots per LDS read, empty slots (0xFFFF) never count
+        unsigned char rank[SPK];
+        if (r < nR) {
+#pragma unroll
+            for (int k = 0; k < SPK; k++) {
+                rank[k] = 0;
+                if (myc[k] != 0xFFFF) {
+                    const uint2* t2 = reinterpret_cast<const uint2*>(S.tl + myc[k] * SP_TLS);
+                    const unsigned me = (unsigned)((r << 4) | k);
+                    const int m4 = (S.cnt[myc[k]] + 3) >> 2;
+                    int rk = 0;
+                    for (int i = 0; i < m4; i++) {
+                        const uint2 q = t2[i];
+                        rk += ((q.x & 0xFFFFu) < me) + ((q.x >> 16) < me) + ((q.y & 0xFFFFu) < me) + ((q.y >> 16) < me);
+                    }
+                    rank[k] = (unsigned char)rk;
+                }
+            }
+        }
+        __syncthreads();
+        if (r < nR) {
+#pragma unroll
+            for (int k = 0; k < SPK; k++) if (myc[k] != 0xFFFF) {
+                S.tl[myc[k] * SP_TLS + rank[k]] = (unsigned short)((r << 4) | k); S.pos[k * MK_MAXN + r] = rank[k];
+                if ((zm >> k) & 1) atomicOr(&S.tzero[myc[k]], 1u << rank[k]);      // zero masks of the columns, from the entries' side
+            }
+        }
+        __syncthreads();
+        S.tlive[tid] = S.tzero[tid];                                   // all rows uncovered
         __syncthreads();
     }
     const long long t_lists = wall_clock64();
@@ -432,6 +475,53 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int 
         L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);
         L.hdr[58] = n_bat; L.hdr[59] = n_seq;                             // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
     }
+    if (!post_fused || a.user || status != 0) return;
+    // ================= fused after-the-fact check (see the header): every entry OUTSIDE the lists must satisfy
+    //     (c[i][j] - rowmin_i) - S_j > margin.
+    // Outside entries cost at least lc_i (the row's last candidate) and S_j <= Smax, so a row with (lc_i - rowmin_i) - Smax > margin
+    // is done without looking at any column (rounding is monotone: the bound holds for the float64 expressions themselves).  Otherwise
+    // only columns with cost <= rowmin_i + Smax + margin can fail: same-class boxes within that radius (grid query; the radius carries
+    // a whole pixel = 7.8e-4 cost units of slack), cross-class ones (cost >= 1) only if the radius reaches 1 -- then every column is examined.
+    const long long t_post = wall_clock64();
+    __syncthreads();                                                   // every read of the transposed lists lies behind us
+    SpPost& P = *reinterpret_cast<SpPost*>(S.tl);
+    const bool big = grid_build(P.grid, a, nR, nC, rowsTrk, S.wave_tot);
+    {
+        const double m = wave_min_f64_dpp(tid < nC ? -S.Scol[tid] : 0.0);
+        if (lane == 0) P.red[wave] = -m;
+    }
+    __syncthreads();
+    double Smax = P.red[0];
+    for (int w = 1; w < MK_THREADS / 64; w++) Smax = fmax(Smax, P.red[w]);
+    const double margin = 1e-9 * (1.0 + L.dhdr[3]);                    // as mk_postcheck_kernel
+    bool pviol = false;
+    if (r < nR && myc[SPK - 1] != 0xFFFF) {                            // (a row with fewer than LAP_K columns has every entry in its list)
+        const int lj = myc[SPK - 1];
+        const double rmin = L.ccost[(size_t)r * SPK], lc = L.ccost[(size_t)r * SPK + SPK - 1];
+        if (!((lc - rmin) - Smax > margin)) {
+            const bbox_t rb = rowsTrk ? a.trk[r] : a.det[r];
+            auto examine = [&](int j, double cst) {
+                const bool outside = cst > lc || (cst == lc && j > lj);
+                if (outside && !(cst - rmin - S.Scol[j] > margin)) pviol = true;
+            };
+            const double reach = rmin + Smax + margin;
+            if (big || !(reach < 0.99)) {
+                for (int j = 0; j < nC; j++) { const bbox_t cb = rowsTrk ? a.det[j] : a.trk[j]; examine(j, rowsTrk ? pair_cost(rb, cb) : pair_cost(cb, rb)); }
+            } else {
+                const int Ri = (int)(reach * (double)MOT_FRAME_W) + 2;
+                grid_query(P.grid, (rb.l + rb.r) >> 1, (rb.t + rb.b) >> 1, rb.type, Ri, [&](int j, int d2) { examine(j, cost_of_d2(d2, false)); });
+            }
+        }
+    }
+    const int spviol = __syncthreads_or(pviol) ? 1 : 0;
+    if (tid == 0) { L.hdr[LAP_H_SPVIOL] = spviol; L.hdr[57] = (int)(wall_clock64() - t_post); }
+    if (spviol || !life.enabled) return;
+    // accepted and in the device loop: commit the frame here (td.cpp:472-644); the final kernel only does its bookkeeping
+    if (tid < nR) a.ws.assignment[tid] = S.starColOfRow[tid];
+    __threadfence_block();
+    __syncthreads();
+    dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, P.life);
+    if (tid == 0) L.hdr[LAP_H_DONE] = 1;
 }
 
 // every entry outside the candidate lists against the final S_j (see the header); grid of 64 x 64 tiles
@@ -486,7 +576,7 @@ __global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
 
 } // namespace
 
-hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s)
+hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, const LifeArgs& life)
 {
     static int attr_dev = -1;
     int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
@@ -497,7 +587,11 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s)
     }
     static int batch = -1;                                             // MOT_MK_BATCH=0: one event per iteration of the sparse emulation's event loop
     if (batch < 0) { const char* ev = getenv("MOT_MK_BATCH"); batch = (ev && atoi(ev) == 0) ? 0 : 1; }
-    hipLaunchKernelGGL(mk_sparse_kernel, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch);
-    hipLaunchKernelGGL(mk_postcheck_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+    // box costs: the after-the-fact check (and the lifecycle step) run inside the emulation's workgroup; caller matrices keep the dense pass
+    static int fuse = -1;
+    if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
+    const int post_fused = (fuse && !a.user) ? 1 : 0;
+    hipLaunchKernelGGL(mk_sparse_kernel, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
+    if (!post_fused) hipLaunchKernelGGL(mk_postcheck_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -121,6 +121,9 @@ enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 
                               // iff LAP_H_SPVIOL == 0), 2 run the dense order-exact emulation
        LAP_H_SPVIOL = 5,      // mk_postcheck_kernel: an entry outside the candidate lists could have mattered
        LAP_H_DENSE = 6,       // lap_dense_kernel ran in this launch (the sparse solver gave up / its prices failed the dense check): the dual check runs again
+       LAP_H_DONE = 7,        // the frame is decided AND committed: a kernel of this launch chain has already run the lifecycle step (device loop) --
+                              // every later kernel of the chain returns at once; re-armed by the final kernel
+       LAP_H_CERT = 8,        // 1 + the certificate's outcome when the solver's own workgroup already evaluated it (fused dual check, lap_kernels.hip); 0: not yet
        LAP_H_DSTAT = 42,      // [42..44] dense solver of the most recent launch: settled columns, free rows after the greedy start, device time (10 ns);
                               // [45] launches in which it ran, [46] ... and were then certified (cumulative)
        LAP_H_LAST = 16,       // [16..31] statistics of the most recent launch: status, rounds, free rows, searches, commits, edges, cyclic nodes, device time (10 ns)
