@@ -430,10 +430,20 @@ def main():
         if stage is not None:
             # the lifecycle step is the tail of the final association kernel; stage[3] is only the gap between two event records
             kern = {"kcf_predict": stage[0], "association (row scan, LAP solver, dual check, sparse / dense Munkres, lifecycle)": stage[1] + stage[3], "kcf_update": stage[4]}
-            split = os.environ.get("MOT_SPLIT_UPDATE", "1") != "0"
+            split = os.environ.get("MOT_SPLIT_UPDATE", "1") != "0" and not dev_sizes
+            # deferred blend (default with the split update): the model update of frame f (kf, alpha, model lerp: everything of
+            # tracker_update but its feature half) runs as the prologue of frame f + 1's predict kernel -- that launch then moves the
+            # predict's bytes plus the update's model bytes; what is left on the main stream behind the association is a small launch
+            # for the tracks that keep their predicted box
+            defer = split and os.environ.get("MOT_DEFER_BLEND", "1") != "0"
             # roofline: the HBM-bound kernel with the largest device time.  With the split update the update stage on the main stream is
             # the blend launch (its feature half runs beside the association on the side stream)
-            cands = {"kcf_predict": (stage[0], ab["predict"]), ("kcf_update (blend launch)" if split else "kcf_update"): (stage[4], ab["blend"] if split else ab["update"])}
+            if defer:
+                crop = size * size * 3
+                cands = {"kcf_predict (+ deferred model update of the previous frame)": (stage[0], ab["predict"] + ab["update"] - crop),
+                         "kcf_update (tracks that keep their predicted box; none on this stream)": (max(stage[4], 1e-6), 0)}
+            else:
+                cands = {"kcf_predict": (stage[0], ab["predict"]), ("kcf_update (blend launch)" if split else "kcf_update"): (stage[4], ab["blend"] if split else ab["update"])}
             dom = max(cands, key=lambda k: cands[k][0])
             per_launch = cands[dom][1] * n_live
             achieved = per_launch / (cands[dom][0] * 1e-3) / 1e9
@@ -443,7 +453,9 @@ def main():
                 if os.path.exists(tpath):
                     try:
                         tj = json.load(open(tpath))
-                        traffic = tj.get(("kcf_predict" if dom == "kcf_predict" else "kcf_update_blend" if split else "kcf_update") + f"_bytes_per_launch_n{n_tracks}")
+                        traffic = tj.get(("kcf_predict" if dom.startswith("kcf_predict") else "kcf_update_blend" if split else "kcf_update") + f"_bytes_per_launch_n{n_tracks}")
+                        if defer and "deferred_blend" not in tj:
+                            traffic = None                              # counter passes of a build without the deferred blend: not this kernel
                         if traffic is not None:
                             traffic_src = f"profiles/{cand_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (tools/collect_profiles.sh), not measured by this run"
                     except Exception:

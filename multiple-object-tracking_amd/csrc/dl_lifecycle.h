@@ -26,6 +26,10 @@ struct DLState {
     int* loc_cls; int* upd_cls;   // class of every predict / update item
     int* nfree_c; int* free_c;    // [ncls] fill of, [ncls][cap] the per-class free slot stacks
     const KcfPool* pools;         // [ncls] device table of pool descriptors
+    // deferred blend (KCF, split update, single template): an assigned or spawning track does not enter the update list; the lifecycle
+    // step sets its pos / scale (kcf.cpp:470-472) and notes in pend_det[slot] which detection's spectrum the slot adopts, and the NEXT
+    // frame's predict kernel blends it into the model before correlating (kcf_predict_body)
+    int defer; int* pend_det;
 };
 
 __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* wave_tot, int& total)
@@ -101,7 +105,12 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
         keep = !lost;
         mine = ((int)(tid % (unsigned)S.world) == S.rank);
         if (mine) {
-            if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; if (multi) S.upd_cls[q] = tcls; }
+            if (keep && S.defer && j >= 0) {                               // tracker_update's bookkeeping now, its model blend in the next predict
+                S.pend_det[slot] = j;
+                kp.pos[slot] = bb;
+                kp.scale[slot] = make_float2(((float)(bb.r - bb.l + 1)) / ((float)kp.cols), ((float)(bb.b - bb.t + 1)) / ((float)kp.rows));
+            }
+            else if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; if (multi) S.upd_cls[q] = tcls; }
             else if (multi) { const int q = atomicAdd(&cntc[tcls], 1); S.free_c[(size_t)tcls * S.cap + q] = slot; }
             else { const int q = atomicAdd(&cnt[1], 1); S.free_slots[q] = slot; }   // tracker_delete (td.cpp:599)
         }
@@ -139,8 +148,8 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
                 if (S.kind == MOT_TRACKER_KCF) {
                     const KcfPool& sp = multi ? S.pools[scls] : kp;
                     sp.pos[ns] = db; sp.scale[ns] = make_float2(1.f, 1.f); sp.first_update[ns] = 1;     // kcf.cpp:200-210
-                    const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = ns; S.upd_boxes[q] = db; S.upd_det[q] = t;   // first update, td.cpp:631-640
-                    if (multi) S.upd_cls[q] = scls;
+                    if (S.defer) S.pend_det[ns] = t;                                   // first update (eta = 1, td.cpp:631-640) in the next predict
+                    else { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = ns; S.upd_boxes[q] = db; S.upd_det[q] = t; if (multi) S.upd_cls[q] = scls; }   // first update, td.cpp:631-640
                 } else {
                     const double v[6] = { (double)db.l, (double)db.t, (double)db.r, (double)db.b, 0.0, 0.0 }; // kalman.cpp:152-157
                     for (int q = 0; q < 6; q++) kal.x[(size_t)ns * 6 + q] = v[q];

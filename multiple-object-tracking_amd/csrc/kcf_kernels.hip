@@ -907,6 +907,39 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     const int slot = l.slots[item];
     if (l.dbg && threadIdx.x == 0 && item < 4096) l.dbg[32 + 3 * item] = wall_clock64();
     const bbox_t pos = p.pos[slot];                                    // kcf_t::pos == tracker_info.bbox (td.cpp:351-354)
+    // Deferred blend: tracker_update of the PREVIOUS frame (kcf.cpp:441-453: kf, alpha, model lerp) for this track, from the spectrum
+    // its adopted detection box got in that frame's feature launch -- the same arithmetic, in the same order, as the blend launch it
+    // replaces (kcf_update_body, blend-only path); pure HBM streaming that overlaps the feature phases of the neighbouring workgroups.
+    if (l.pend_det) {
+        const int dj = l.pend_det[slot];
+        if (dj >= 0) {
+            const int tot = MOT_NCHAN * p.nbins;
+            const float2* dspec = l.pend_spec + (size_t)dj * tot;
+            float2* xmw = p.xm + (size_t)slot * tot;
+            const int first = p.first_update[slot];
+            const float factor = first ? 1.0f : p.eta, keep = 1.0f - factor;       // kcf.cpp:443
+            for (int b = tid; b < p.nbins; b += nt) {                   // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
+                float kf = 0.f;
+                for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
+                const float kq = kf * p.norm;
+                const float a = p.yf_re[b] / (kq + p.lambda);
+                const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
+                p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
+            }
+            for (int i0 = 0; i0 < tot; i0 += 8 * nt) {                  // kcf_update_xf (kcf.cpp:380-395): 16 loads in flight per thread
+                float2 a8[8], m8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const int i = min(i0 + tid + j * nt, tot - 1); a8[j] = dspec[i]; m8[j] = first ? make_float2(0.f, 0.f) : xmw[i]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int i = i0 + tid + j * nt;
+                    if (i < tot) { float2 m = m8[j]; m.x = keep * m.x + factor * a8[j].x; m.y = keep * m.y + factor * a8[j].y; xmw[i] = m; }
+                }
+            }
+            __syncthreads();                                           // the blended model is visible to the whole workgroup (loads below)
+            if (tid == 0) { l.pend_det[slot] = -1; p.first_update[slot] = 0; }
+        }
+    }
     // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
     // they land while the features are computed
     const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
@@ -1121,6 +1154,11 @@ template <bool kLds>
 __global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (l.grid_stride) {                                               // few items, count known on the device only: a small grid loops
+        const int cnt = min(n, l.count ? *l.count : n);
+        for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kLds>(p, l, item, smem); __syncthreads(); }
+        return;
+    }
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
@@ -1260,12 +1298,13 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     // exclusive_cu: ask for more than half of a CU's LDS so that no second workgroup (of this or of a concurrently running
     // KCF kernel) is placed on the same CU
     if (exclusive_cu && lds < MOT_LDS_LIMIT / 2 + 2048) lds = MOT_LDS_LIMIT / 2 + 2048;
+    const int grid = l.grid_stride ? (n < 128 ? n : 128) : n;         // grid_stride: the workgroups loop over up to n items (device-side count)
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_update_kernel<true>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+        hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(grid), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
     } else {
         hipError_t e = set_lds_attr(kcf_update_kernel<false>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
+        hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(grid), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
     }
     return hipGetLastError();
 }

@@ -82,6 +82,11 @@ struct KcfLaunch {
     float2* spec_out;         // feature-only launch: [n][31][nbins] spectra of boxes_in[item] are written here, no model update
     const float2* det_spec;   // blend launch: spectra written by a feature-only launch ...
     const int* det_index;     // ... and [n] the detection whose spectrum item uses (-1: compute from boxes_in[item] as usual)
+    // deferred blend (device loop, split update): the model blend of frame f runs as the prologue of frame f + 1's predict.  pend_det[slot]
+    // >= 0: the slot adopts spectrum pend_spec[pend_det[slot]] (written by frame f's feature launch) before it is correlated; reset to -1
+    int* pend_det;            // [cap] by SLOT, or null
+    const float2* pend_spec;  // spectra of the previous frame's detections
+    int grid_stride;          // update kernel: workgroups loop over the items (grid smaller than the device-side count allows)
     int slab_base;            // HBM-slab templates: item i works in slab (slab_base + i) -- a launch that may run beside another KCF launch gets slabs of its own
     // size classes (device loop with per-track template sizes): item i uses pools[cls[i]]; one shared scratch with a common stride
     const KcfPool* pools;     // device table of pool descriptors, or null (single pool passed by value)

@@ -44,7 +44,8 @@ struct DevLoop {
     hipEvent_t ev[8]{}; bool ev_ok = false;
     // split update (KCF): the spectra of all detection boxes are computed on a second, low-priority stream while the
     // association runs; the per-track update then only blends them into the model
-    DevBuf<float2> det_spec; hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
+    DevBuf<float2> det_spec; DevBuf<int> pend; size_t spec_stride = 0; unsigned frame_no = 0; bool defer = false;   // det_spec: two buffers, by frame parity
+    hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
 };
 
@@ -150,7 +151,16 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             HIPCHK(hipEventCreateWithFlags(&d->ev_upd, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
             HIPCHK(hipEventRecord(d->ev_upd, c->stream));
-            HIPCHK(d->det_spec.alloc((size_t)md * MOT_NCHAN * kp.nbins));
+            // Deferred blend (default; MOT_DEFER_BLEND=0 restores the blend launch): the model update of frame f rides in frame f + 1's
+            // predict kernel.  The spectra of frame f must then outlive the feature launch of frame f + 1: two buffers, by frame parity.
+            const char* dv = getenv("MOT_DEFER_BLEND");
+            d->defer = !(dv && atoi(dv) == 0);
+            d->spec_stride = (size_t)md * MOT_NCHAN * kp.nbins;
+            HIPCHK(d->det_spec.alloc(d->spec_stride * (d->defer ? 2 : 1)));
+            if (d->defer) {
+                HIPCHK(d->pend.alloc((size_t)cap)); HIPCHK(hipMemset(d->pend.p, 0xFF, sizeof(int) * cap));
+                S.defer = 1; S.pend_det = d->pend.p;
+            }
             d->split = true;
         }
     }
@@ -167,6 +177,9 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     if (d->begun) return fail(MOT_ERR_STATE, "mot_step_begin_device called twice");
     if (S.kind == MOT_TRACKER_KCF && !frame_dev) return fail(MOT_ERR_ARG, "null frame");
     d->frame = frame_dev;
+    d->frame_no++;
+    float2* spec_cur = d->det_spec.p + (d->defer ? (size_t)(d->frame_no & 1) * d->spec_stride : 0);            // this frame's detection spectra
+    const float2* spec_prev = d->det_spec.p + (d->defer ? (size_t)((d->frame_no - 1) & 1) * d->spec_stride : 0);   // ... the previous frame's
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
     if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
     d->feat_early = false;
@@ -179,7 +192,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
         // detector output): in-order execution makes this event subsume the previous frame's update (ev_upd) as well
         HIPCHK(hipEventRecord(d->ev_in, c->stream));
         HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
-        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = d->det_spec.p; lf.slab_base = S.cap;
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = spec_cur; lf.slab_base = S.cap;
         HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
         HIPCHK(hipEventRecord(d->ev_feat, d->side));
         d->feat_early = true;
@@ -187,6 +200,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
+        if (d->defer) { l.pend_det = S.pend_det; l.pend_spec = spec_prev; }
         HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
     } else HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
@@ -207,6 +221,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const bbox_t* dets = (const bbox_t*)dets_dev;
     KcfPool kp{}; if (S.kind == MOT_TRACKER_KCF) kp = c->pools[d->pool]->dev;
     const bool split = d->split && S.kind == MOT_TRACKER_KCF && nD > 0;
+    float2* spec_cur = d->det_spec.p + (d->defer ? (size_t)(d->frame_no & 1) * d->spec_stride : 0);
     // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
     LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
     HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (split && !d->feat_early) ? d->ev_mid : nullptr, &life));
@@ -214,7 +229,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
         // features of every detection box, on the side stream, from the moment the Munkres kernel has been handed to the
         // dispatcher (so its 17 workgroups are placed first); the frame and the boxes are inputs of this call
         HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
-        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->frame; lf.boxes_in = dets; lf.spec_out = d->det_spec.p; lf.slab_base = S.cap;
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->frame; lf.boxes_in = dets; lf.spec_out = spec_cur; lf.slab_base = S.cap;
         HIPCHK(launch_kcf_update(kp, lf, nD, d->side));
         HIPCHK(hipEventRecord(d->ev_feat, d->side));
     }
@@ -224,8 +239,14 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
-        if (split) { HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = d->det_spec.p; l.det_index = S.upd_det; }
-        HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
+        if (split) { HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = spec_cur; l.det_index = S.upd_det; }
+        if (d->defer) {
+            // only tracks that keep their PREDICTED box (unmatched, not lost: td.cpp:550-581) are left in the update list -- few or none,
+            // count known on the device only: a small grid loops over them.  (The stream still orders the next predict behind the
+            // feature launch: its blend prologue reads this frame's spectra.)
+            l.grid_stride = 1;
+            HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
+        } else HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
         if (split) HIPCHK(hipEventRecord(d->ev_upd, c->stream));
     } else HIPCHK(launch_kalman_update(c->kal, S.upd_slots, S.upd_count, upd_max, S.upd_boxes, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[4], c->stream));
