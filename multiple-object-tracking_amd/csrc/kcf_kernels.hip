@@ -1175,6 +1175,32 @@ __global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB,
     kcf_update_body<kLds>(p, l, item, smem);
 }
 
+// Feature-only launch of the split update (device loop): crop -> FHOG -> 31 spectra of every DETECTION box, written to l.spec_out.
+// A kernel of its own: inside kcf_update_kernel the model prefetch and the blend paths it never takes cost it 300 spilled VGPRs
+// (1 KB of scratch per lane) -- and this launch is the one that shares the chip with the association chain every frame.
+template <bool kLds>
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
+    float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
+    const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const bbox_t box = l.boxes_in[item];
+    features_prepare<!kLds>(p, l, item, box, r, tid, nt, stage);
+    const float2* S = reinterpret_cast<const float2*>(r.B);
+    float2* so = l.spec_out + (size_t)item * MOT_NCHAN * p.nbins;
+    half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
+    for (int i = tid; i < MOT_HALF0 * p.nbins; i += nt) so[i] = S[i];
+    __syncthreads();
+    half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
+    so += (size_t)MOT_HALF0 * p.nbins;
+    for (int i = tid; i < (MOT_NCHAN - MOT_HALF0) * p.nbins; i += nt) so[i] = S[i];
+}
+
 template <bool kLds>
 __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
@@ -1299,6 +1325,11 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     // KCF kernel) is placed on the same CU
     if (exclusive_cu && lds < MOT_LDS_LIMIT / 2 + 2048) lds = MOT_LDS_LIMIT / 2 + 2048;
     const int grid = l.grid_stride ? (n < 128 ? n : 128) : n;         // grid_stride: the workgroups loop over up to n items (device-side count)
+    if (l.spec_out) {                                                  // feature-only launch: the lean kernel
+        if (p.use_lds) { hipError_t e = set_lds_attr(kcf_features_kernel<true>, lds); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_features_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_features_kernel<false>, lds); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_features_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n); }
+        return hipGetLastError();
+    }
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_update_kernel<true>, lds); if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(grid), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
