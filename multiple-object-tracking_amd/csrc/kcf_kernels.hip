@@ -272,7 +272,7 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // ---------------------------------------------------------------------------
 // NPRE (HBM-slab templates): the footprint columns are loaded four at a time, all in flight at once, because there every
 // load is an L2 round trip; the LDS-resident kernels load column by column.
-template <int NPRE>
+template <int NPRE, bool LDSACC = true>   // LDSACC: the accumulators live in LDS (false only for the FHOG-only test kernel of templates beyond the LDS)
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
                            float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt)
 {
@@ -283,7 +283,7 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
         uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
         // HBM-slab templates accumulate in a per-thread LDS scratch (the read-modify-write chain would otherwise run at L2
         // latency) and copy the finished cell out
-        float* __restrict__ Rc = scratch ? scratch + R1W(tid, 0) : R1 + R1W(cell, 0);   // bin o at Rc[o * 64]
+        float* __restrict__ Rc = NPRE ? scratch + R1W(tid, 0) : R1 + R1W(cell, 0);   // bin o at Rc[o * 64]; always LDS (HBM-slab templates: the staging area)
 #pragma unroll
         for (int o = 0; o < MOT_NORI; o++) Rc[o * 64] = 0.0f;
         const int x_lo = max(0, 4 * (int)cx - 2), x_hi = min(w0 - 1, 4 * (int)cx + 5);
@@ -321,7 +321,8 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 const uint32_t ba = pba[g], bb = pbb[g];
                 const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
                 // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
-                // same orientation sees the earlier sum
+                // same orientation sees the earlier sum.  (ds_add_f32 -- one LDS float add per pixel, no return value, bit-identical
+                // sums -- was measured in round 3: the predict launch went from 100 to 215 us; the LDS atomic path is that slow.)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
@@ -338,7 +339,7 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 Rc[o * 64] = v;
             }
         }
-        if (scratch) {
+        if (NPRE) {
             // in the slab R1 is orientation-major, R1[o * nb + cell]: a wave's store covers 64 neighbouring cells (cell-major
             // rows of 19 floats cost the texture addresser one cache line per lane and access)
 #pragma unroll
@@ -848,7 +849,7 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* c
 }
 
 // Everything up to R1 (region A) and the norm matrix: shared by predict / update.
-template <bool SLAB>
+template <bool SLAB, bool LDSR1 = true>
 __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt, float* stage = nullptr)
 {
 #define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
@@ -872,7 +873,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
-    phase_hist<SLAB ? 4 : 0>(p, Mq, bins, r.A, stage, tid, nt);              // R1 overlays the patch
+    phase_hist<SLAB ? 4 : 0, LDSR1>(p, Mq, bins, r.A, stage, tid, nt);       // R1 overlays the patch
     __syncthreads();
     DBG_STAMP(3);
     phase_energy<SLAB>(p, r.A, r.E, tid, nt);
@@ -1210,7 +1211,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_fhog_kernel(const KcfPool
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     const Regions r = carve(p, base);
     bbox_t box = l.boxes_in ? l.boxes_in[item] : bbox_t{0, 0, p.rows - 1, p.cols - 1, 0, 0.f};
-    features_prepare<false>(p, l, item, box, r, threadIdx.x, blockDim.x);
+    features_prepare<false, kLds>(p, l, item, box, r, threadIdx.x, blockDim.x);
     half_spectrum<0, false>(p, l, item, r, threadIdx.x, blockDim.x, false);
     __syncthreads();
     half_spectrum<1, false>(p, l, item, r, threadIdx.x, blockDim.x, false);
