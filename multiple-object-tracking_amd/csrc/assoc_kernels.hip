@@ -310,7 +310,10 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
 __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, bool rowsTrk)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int r = tid & (MK_FUSE_MAX - 1), part = tid >> 8;
+    // thread = (row, column class); as many column classes as the row count leaves room for (64 rows: 16 classes of 4 columns each,
+    // instead of 4 classes with three quarters of the workgroup idle -- the float64 sqrt chains are what this phase costs)
+    const int RP = nR <= 64 ? 64 : (nR <= 128 ? 128 : MK_FUSE_MAX), NPART = MK_THREADS / RP;
+    const int r = tid & (RP - 1), part = tid / RP;
     const bool perRow = nR <= nC;
     const int wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
     u64* lm = S.bm;                                                    // [256] keys of the line minima
@@ -330,7 +333,7 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
         return rowsTrk ? pair_cost(rowb, colb[c]) : pair_cost(colb[c], rowb);
     };
     u64 best = ~0ull;                                                  // pass 1 (hungarian.cpp:69-81 / :107-119)
-    for (int c = part; c < nC; c += MK_THREADS / MK_FUSE_MAX) {
+    for (int c = part; c < nC; c += NPART) {
         const u64 kk = r < nR ? dkey(cost(c)) : ~0ull;
         if (perRow) { if (kk < best) best = kk; }
         else {
@@ -343,7 +346,7 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
     if (perRow && r < nR && best != ~0ull) atomicMin(&lm[r], best);
     __syncthreads();
     const double rmin = (perRow && r < nR) ? dunkey(lm[r]) : 0.0;      // pass 2
-    for (int c = part; c < nC; c += MK_THREADS / MK_FUSE_MAX) {
+    for (int c = part; c < nC; c += NPART) {
         bool z = false;
         if (r < nR) {
             const double v = cost(c);

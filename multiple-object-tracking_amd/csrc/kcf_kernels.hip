@@ -1180,12 +1180,8 @@ __global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB,
 // A kernel of its own: inside kcf_update_kernel the model prefetch and the blend paths it never takes cost it 300 spilled VGPRs
 // (1 KB of scratch per lane) -- and this launch is the one that shares the chip with the association chain every frame.
 template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
+__device__ __forceinline__ void kcf_features_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int item = blockIdx.x;
-    if (item >= n) return;
-    if (l.count && item >= *l.count) return;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
     const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
@@ -1200,6 +1196,34 @@ __global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB,
     half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
     so += (size_t)MOT_HALF0 * p.nbins;
     for (int i = tid; i < (MOT_NCHAN - MOT_HALF0) * p.nbins; i += nt) so[i] = S[i];
+}
+
+template <bool kLds>
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int item = blockIdx.x;
+    if (item >= n) return;
+    if (l.count && item >= *l.count) return;
+    kcf_features_body<kLds>(p, l, item, smem);
+}
+
+// Small frames (predict + feature workgroups fit the chip together): ONE launch carries both -- workgroups [0, n_pred) predict the
+// tracks, workgroups [n_pred, n_pred + n_feat) compute the detection spectra of the split update.  No side stream, no event pair, no
+// cross-stream wait: at 64 tracks those cost more than the kernels' own work.
+template <bool kLds>
+__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < n_pred) {
+        const int item = blockIdx.x;
+        if (lp.count && item >= *lp.count) return;
+        kcf_predict_body<kLds>(p, lp, item, smem);
+    } else {
+        const int item = (int)blockIdx.x - n_pred;
+        if (item >= n_feat) return;
+        kcf_features_body<kLds>(p, lf, item, smem);
+    }
 }
 
 template <bool kLds>
@@ -1312,6 +1336,20 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     return hipGetLastError();
 }
 
+hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp, int n_pred, const KcfLaunch& lf, int n_feat, hipStream_t s)
+{
+    if (n_pred + n_feat <= 0) return hipSuccess;
+    const size_t lds = kcf_lds_bytes(p);
+    if (p.use_lds) {
+        hipError_t e = set_lds_attr(kcf_predict_features_kernel<true>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_predict_features_kernel<true>, dim3(n_pred + n_feat), dim3(MOT_KCF_THREADS), lds, s, p, lp, lf, n_pred, n_feat);
+    } else {
+        hipError_t e = set_lds_attr(kcf_predict_features_kernel<false>, lds); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kcf_predict_features_kernel<false>, dim3(n_pred + n_feat), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, lp, lf, n_pred, n_feat);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu)
 {
     if (n <= 0) return hipSuccess;
@@ -1325,7 +1363,8 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     // exclusive_cu: ask for more than half of a CU's LDS so that no second workgroup (of this or of a concurrently running
     // KCF kernel) is placed on the same CU
     if (exclusive_cu && lds < MOT_LDS_LIMIT / 2 + 2048) lds = MOT_LDS_LIMIT / 2 + 2048;
-    const int grid = l.grid_stride ? (n < 128 ? n : 128) : n;         // grid_stride: the workgroups loop over up to n items (device-side count)
+    // grid_stride: the workgroups loop over up to n items (device-side count, usually zero): a grid of n / 8 workgroups, 4 .. 128
+    const int grid = l.grid_stride ? (n / 8 < 4 ? (n < 4 ? n : 4) : (n / 8 > 128 ? 128 : n / 8)) : n;
     if (l.spec_out) {                                                  // feature-only launch: the lean kernel
         if (p.use_lds) { hipError_t e = set_lds_attr(kcf_features_kernel<true>, lds); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_features_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n); }
         else { hipError_t e = set_lds_attr(kcf_features_kernel<false>, lds); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_features_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n); }

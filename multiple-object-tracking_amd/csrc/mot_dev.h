@@ -151,6 +151,7 @@ struct AssocWs {
 
 // host-side launchers implemented in the .hip files
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
+hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp, int n_pred, const KcfLaunch& lf, int n_feat, hipStream_t s);   // one launch: predict items, then feature-only items
 hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu = false);
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
 hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s);

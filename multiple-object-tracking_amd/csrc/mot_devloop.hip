@@ -47,6 +47,7 @@ struct DevLoop {
     DevBuf<float2> det_spec; DevBuf<int> pend; size_t spec_stride = 0; unsigned frame_no = 0; bool defer = false;   // det_spec: two buffers, by frame parity
     hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
+    bool feat_joined = false;     // ... inside the predict launch itself (no side stream, no event to wait for)
 };
 
 void devloop_destroy(DevLoop* d)
@@ -185,23 +186,32 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     d->feat_early = false;
     static int early_max = -1;
     if (early_max < 0) { const char* ev = getenv("MOT_SPLIT_EARLY_MAX"); early_max = ev ? atoi(ev) : MOT_SPLIT_EARLY_MAX; }
-    if (d->split && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= early_max) {
-        // small frames leave most CUs idle during the predict: the detection features run beside it (they only need the
-        // frame and the boxes); the spectra buffer is free once the previous frame's update has finished
-        // the side stream is ordered behind everything the caller has enqueued on the context stream so far (frame upload,
-        // detector output): in-order execution makes this event subsume the previous frame's update (ev_upd) as well
-        HIPCHK(hipEventRecord(d->ev_in, c->stream));
-        HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
-        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = spec_cur; lf.slab_base = S.cap;
-        HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
-        HIPCHK(hipEventRecord(d->ev_feat, d->side));
-        d->feat_early = true;
-    }
+    d->feat_joined = false;
+    const bool early = d->split && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= early_max;
+    static int joined_on = -1;
+    if (joined_on < 0) { const char* ev = getenv("MOT_JOINED_LAUNCH"); joined_on = (ev && atoi(ev) == 0) ? 0 : 1; }
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
         if (d->defer) { l.pend_det = S.pend_det; l.pend_spec = spec_prev; }
-        HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = spec_cur; lf.slab_base = S.cap;
+        if (early && joined_on) {
+            // small frames leave most CUs idle during the predict: the detection features (they only need the frame and the boxes) ride in
+            // the SAME launch as extra workgroups -- no side stream, no events (MOT_JOINED_LAUNCH=0: side-stream launch as in round 2)
+            HIPCHK(launch_kcf_predict_features(c->pools[d->pool]->dev, l, S.spr, lf, nD, c->stream));
+            d->feat_early = true; d->feat_joined = true;
+        } else {
+            if (early) {
+                // the side stream is ordered behind everything the caller has enqueued on the context stream so far (frame upload,
+                // detector output): in-order execution makes this event subsume the previous frame's update (ev_upd) as well
+                HIPCHK(hipEventRecord(d->ev_in, c->stream));
+                HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
+                HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
+                HIPCHK(hipEventRecord(d->ev_feat, d->side));
+                d->feat_early = true;
+            }
+            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
+        }
     } else HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
     d->begun = true;
@@ -239,7 +249,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
-        if (split) { HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = spec_cur; l.det_index = S.upd_det; }
+        if (split) { if (!d->feat_joined) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = spec_cur; l.det_index = S.upd_det; }
         if (d->defer) {
             // only tracks that keep their PREDICTED box (unmatched, not lost: td.cpp:550-581) are left in the update list -- few or none,
             // count known on the device only: a small grid loops over them.  (The stream still orders the next predict behind the
