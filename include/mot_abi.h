@@ -191,11 +191,38 @@ int mot_step_finish_device(mot_ctx* ctx, const void* gathered_boxes_dev, const v
 int mot_live_count(mot_ctx* ctx, int* n_live);
 int mot_live_tracks(mot_ctx* ctx, bbox_t* boxes, unsigned* tids, int* ages, int* n_live);
 
+/* ---- detector post-processing (detectors/yolo3.cpp:141-356, 490-547) --------------
+ * From the three raw output tensors of the YOLOv3 network (device memory, NHWC [grid << s][grid << s][3 * (5 + classes)], s = 0, 1, 2)
+ * to the detection list the tracker thread consumes: sigmoid / exp decode against obj_thresh, letterbox correction, per-class NMS
+ * (the reference's own exchange sort and suppression loop, order-exact), clamp + validity filter.  The boxes are written to
+ * dets_dev_out (at most cap) in the reference's emit order and their number to *n_dev_out (device int), ready for
+ * mot_step_frame_device; with host_chain_out the reference's bbox_chain_t is filled as well (synchronises; at most 128 boxes).
+ * The network itself stays the caller's (north_star: "detectors/yolo3 stays a stub"). */
+typedef struct {            /* bit-identical to top/cnntype.h:49-54 */
+    float obj_thresh;
+    float nms_thresh;
+    int anchors[18];
+} yolo3_options_t;
+int mot_yolo_postprocess(mot_ctx* ctx, const float* head0_dev, const float* head1_dev, const float* head2_dev, int tensor_h, int tensor_w,
+                         int num_classes, int image_h, int image_w, const yolo3_options_t* opt, bbox_t* dets_dev_out, int cap, int* n_dev_out,
+                         bbox_chain_t* host_chain_out);
+
+/* ---- overlay: the tracker thread's drawing step (td.cpp:647-733) ----------------
+ * Three nested rectangle outlines per track (drawRect, top/drawlib.c:97-151) in colormap[hashcolor(tid) & 255] (td.cpp:295-304,
+ * 620, 655-699), drawn into a 1280x720x3 frame in device memory, later tracks over earlier ones.  mot_overlay_draw takes host
+ * arrays (any context); mot_overlay_live draws the live list of the device-resident loop without any copy.  Enqueued on the
+ * context's stream; the frame must not be the input of a frame step that is still in flight. */
+int mot_overlay_draw(mot_ctx* ctx, void* frame_dev, const bbox_t* boxes, const unsigned* tids, int n);
+int mot_overlay_live(mot_ctx* ctx, void* frame_dev);
+
 /* ---- introspection for parity tests --------------------------------------- */
 int mot_get_response(mot_ctx* ctx, int id, float* out, int* f_rows, int* f_cols); /* kcf_t::response (kcf.cpp:58) */
 int mot_get_model(mot_ctx* ctx, int id, float* xm_out /* 31*f_cols*(f_rows/2+1)*2 */, float* alpha_out);
 int mot_get_kalman_state(mot_ctx* ctx, int id, double* x6, double* P36);
 int mot_get_pos(mot_ctx* ctx, int id, bbox_t* pos);
+/* device-resident loop: kcf_t::response (kcf.cpp:58) of the i-th LIVE track (order of mot_live_tracks) as left by the most recent
+ * predict -- the 1e-4 peak check at full track counts */
+int mot_live_response(mot_ctx* ctx, int live_index, float* out, int* f_rows, int* f_cols);
 /* debug: enable / read the per-phase time stamps (100 MHz ticks) of workgroup 0 of the device-loop KCF kernels:
  * [0] start [1] crop [2] gradient [3] histogram [4] norm [5] channels [6] DFT [7] end */
 int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long long* update8);

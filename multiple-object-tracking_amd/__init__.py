@@ -255,6 +255,45 @@ class MotContext:
         self._chk(self.lib.mot_live_tracks(self._h, _vp(boxes), _vp(tids), _vp(ages), C.byref(n)))
         return boxes[:n.value].copy(), tids[:n.value].copy(), ages[:n.value].copy()
 
+    # ---- detector post-processing (detectors/yolo3.cpp:141-356, 490-547) ----
+    def yolo_postprocess(self, head_ptrs, tensor_h, tensor_w, num_classes, image_h, image_w, obj_thresh, nms_thresh, anchors, dets_dev, cap, n_dev, want_chain=False):
+        """head_ptrs: device pointers of the three raw output tensors; dets_dev / n_dev: device pointers for the boxes and their count.
+        Returns the reference's bbox_chain_t (nbox, boxes) when want_chain (synchronises), else None."""
+        class Opt(C.Structure):
+            _fields_ = [("obj_thresh", C.c_float), ("nms_thresh", C.c_float), ("anchors", C.c_int * 18)]
+
+        class Chain(C.Structure):
+            _fields_ = [("nbox", C.c_int), ("bbox", BBox * 128)]
+        o = Opt(); o.obj_thresh, o.nms_thresh = obj_thresh, nms_thresh
+        for i, a in enumerate(anchors):
+            o.anchors[i] = int(a)
+        ch = Chain() if want_chain else None
+        self._chk(self.lib.mot_yolo_postprocess(self._h, C.c_void_p(head_ptrs[0]), C.c_void_p(head_ptrs[1]), C.c_void_p(head_ptrs[2]), tensor_h, tensor_w,
+                                                num_classes, image_h, image_w, C.byref(o), C.c_void_p(dets_dev), cap, C.c_void_p(n_dev),
+                                                C.byref(ch) if want_chain else None))
+        if not want_chain:
+            return None
+        out = np.zeros(ch.nbox, BBOX_DTYPE)
+        for i in range(ch.nbox):
+            b = ch.bbox[i]; out[i] = (b.l, b.t, b.b, b.r, b.type, b.score)
+        return out
+
+    # ---- overlay (td.cpp:647-733) ----
+    def overlay_draw(self, frame_dev: int, boxes, tids):
+        b = boxes_array(boxes); t = np.ascontiguousarray(tids, np.uint32)
+        self._chk(self.lib.mot_overlay_draw(self._h, C.c_void_p(frame_dev), _vp(b), _vp(t), len(b)))
+
+    def overlay_live(self, frame_dev: int):
+        self._chk(self.lib.mot_overlay_live(self._h, C.c_void_p(frame_dev)))
+
+    def live_response(self, live_index: int) -> np.ndarray:
+        """response map of the i-th live track of the device-resident loop (most recent predict)"""
+        fr, fc = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_live_response(self._h, int(live_index), None, C.byref(fr), C.byref(fc)))
+        out = np.zeros(fr.value * fc.value, np.float32)
+        self._chk(self.lib.mot_live_response(self._h, int(live_index), _vp(out), C.byref(fr), C.byref(fc)))
+        return out
+
     # ---- introspection ----
     def get_response(self, tid: int) -> np.ndarray:
         fr, fc = C.c_int(0), C.c_int(0)

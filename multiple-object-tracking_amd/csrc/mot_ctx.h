@@ -53,6 +53,8 @@ struct RoctxRange {
 
 struct DevLoop;                      // device-resident frame loop state (mot_devloop.hip)
 void devloop_destroy(DevLoop*);
+struct YoloWs;                       // detector post-processing workspace (yolo_post.hip)
+void yolo_destroy(YoloWs*);
 
 } // namespace mot_impl
 
@@ -76,6 +78,9 @@ struct mot_ctx {
     mot_impl::DevBuf<bbox_t> d_gather; int slots_per_rank = 0; bool step_open = false;
     // device-resident mode
     mot_impl::DevLoop* devloop = nullptr;
+    mot_impl::YoloWs* yolo = nullptr;
+    // overlay (td.cpp:647-733): per-pixel "last track to draw here" stamps, tagged with a per-call epoch
+    mot_impl::DevBuf<unsigned> ov_stamp; unsigned ov_epoch = 0; mot_impl::DevBuf<bbox_t> ov_boxes; mot_impl::DevBuf<unsigned> ov_tids;
     // timers / debug
     std::vector<hipEvent_t> events;
     mot_impl::DevBuf<long long> dbg; bool dbg_on = false;
@@ -85,4 +90,5 @@ namespace mot_impl {
 int ensure_device(mot_ctx* c);
 int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch = false);   // shared_scratch: no HBM slab of its own (the caller points gscratch at a shared one)
 int devloop_check(mot_ctx* c);   // mot_devloop.hip
+int overlay_run(mot_ctx* c, void* frame_dev, const bbox_t* boxes_dev, const unsigned* tids_dev, const int* n_dev, int n_max);   // overlay_kernels.hip
 }

@@ -425,6 +425,7 @@ int mot_ctx_destroy(mot_ctx* c)
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->devloop) devloop_destroy(c->devloop);
+    if (c->yolo) yolo_destroy(c->yolo);
     delete c;
     return MOT_OK;
 }
@@ -657,6 +658,19 @@ int mot_step_frame_chain(mot_ctx* c, const bbox_chain_t* detected, bbox_t* predi
     if (!c || !detected) return fail(MOT_ERR_ARG, "null argument");
     if (detected->nbox < 0 || detected->nbox > MOT_CHAIN_MAX_BOXES) return fail(MOT_ERR_ARG, "bbox_chain_t.nbox = %d outside 0..%d", detected->nbox, MOT_CHAIN_MAX_BOXES);
     return mot_step_frame(c, detected->bbox, detected->nbox, predicted, assigned_trackers, n_before, live_boxes, live_tids, n_live);
+}
+
+int mot_overlay_draw(mot_ctx* c, void* frame_dev, const bbox_t* boxes, const unsigned* tids, int n)
+{
+    if (!c || !frame_dev || n < 0 || (n && (!boxes || !tids))) return fail(MOT_ERR_ARG, "bad argument");
+    if (n > 2047) return fail(MOT_ERR_CAPACITY, "overlay of %d tracks (at most 2047 per call)", n);
+    int rc = ensure_device(c); if (rc) return rc;
+    if (n == 0) return MOT_OK;
+    if (c->ov_boxes.n < (size_t)n) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(c->ov_boxes.alloc((size_t)n)); HIPCHK(c->ov_tids.alloc((size_t)n)); }
+    HIPCHK(hipMemcpyAsync(c->ov_boxes.p, boxes, sizeof(bbox_t) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ov_tids.p, tids, sizeof(unsigned) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                           // caller arrays may be reused after return
+    return overlay_run(c, frame_dev, c->ov_boxes.p, c->ov_tids.p, nullptr, n);
 }
 
 // ---- introspection ----------------------------------------------------------

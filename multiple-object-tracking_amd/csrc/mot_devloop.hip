@@ -337,6 +337,33 @@ int mot_live_count(mot_ctx* c, int* n_live)
     return MOT_OK;
 }
 
+int mot_overlay_live(mot_ctx* c, void* frame_dev)
+{
+    if (!c || !frame_dev) return fail(MOT_ERR_ARG, "null argument");
+    if (!c->devloop) return fail(MOT_ERR_STATE, "mot_overlay_live needs the device-resident loop (host-orchestrated contexts: mot_overlay_draw)");
+    int rc = ensure_device(c); if (rc) return rc;
+    const DLState& S = c->devloop->S;
+    return overlay_run(c, frame_dev, S.bbox, S.tid, S.nlive, S.cap);
+}
+
+int mot_live_response(mot_ctx* c, int live_index, float* out, int* f_rows, int* f_cols)
+{
+    if (!c || !c->devloop) return fail(MOT_ERR_STATE, "mot_live_response needs the device-resident loop");
+    const DLState& S = c->devloop->S;
+    if (S.kind != MOT_TRACKER_KCF || S.ncls > 1) return fail(MOT_ERR_STATE, "mot_live_response: single-template KCF loop only");
+    const KcfPool& p = c->pools[c->devloop->pool]->dev;
+    if (f_rows) *f_rows = p.hb; if (f_cols) *f_cols = p.wb;
+    if (!out) return MOT_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int n = 0, slot = -1;
+    HIPCHK(hipMemcpy(&n, S.nlive, sizeof(int), hipMemcpyDeviceToHost));
+    if (live_index < 0 || live_index >= n) return fail(MOT_ERR_ARG, "live index %d out of range (%d live tracks)", live_index, n);
+    HIPCHK(hipMemcpy(&slot, S.slot + live_index, sizeof(int), hipMemcpyDeviceToHost));
+    if (slot < 0) return fail(MOT_ERR_ARG, "live track %d is owned by another rank", live_index);
+    HIPCHK(hipMemcpy(out, p.response + (size_t)slot * p.nb, sizeof(float) * p.nb, hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
 int mot_live_tracks(mot_ctx* c, bbox_t* boxes, unsigned* tids, int* ages, int* n_live)
 {
     if (!c) return fail(MOT_ERR_ARG, "null ctx");

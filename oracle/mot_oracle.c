@@ -877,3 +877,162 @@ int orc_mot_step(orc_mot* m, const uint8_t* frame, const orc_bbox_t* dets, int n
     for (int i = 0; i < m->n; i++) { if (live_boxes) live_boxes[i] = m->info[i].bbox; if (live_tids) live_tids[i] = m->info[i].tid; }
     return m->n;
 }
+
+/* ---------------------------------------------------------------------------
+ * overlay: drawRect (top/drawlib.c:97-151), hashcolor (top/td.cpp:295-304), the colour table and the drawing loop of the
+ * tracker thread (td.cpp:647-733).  Pixels outside the 1280 x 720 frame are skipped (the reference writes unchecked).
+ * ------------------------------------------------------------------------- */
+#define ORC_FRAME_W 1280   /* top/cnntype.h:5-6 */
+#define ORC_FRAME_H 720
+static void orc_put(uint8_t* fbuf, int y, int x, uint8_t R, uint8_t G, uint8_t B)
+{
+    if (x < 0 || x >= ORC_FRAME_W || y < 0 || y >= ORC_FRAME_H) return;
+    uint8_t* p = fbuf + ((size_t)y * ORC_FRAME_W + x) * 3;            /* PIXEL_AT, drawlib.c:9 */
+    p[0] = R; p[1] = G; p[2] = B;                                      /* drawlib.c:136,147: R first, whatever the frame's channel order */
+}
+
+void orc_draw_rect(uint8_t* fbuf, int left, int top, int right, int bottom, uint32_t rgb)
+{
+    const uint8_t R = (rgb >> 16) & 0xff, G = (rgb >> 8) & 0xff, B = rgb & 0xff;   /* :106-108 */
+    if (top > bottom) { int t = top; top = bottom; bottom = t; }     /* :112-124 */
+    if (left > right) { int t = left; left = right; right = t; }
+    for (int x = left; x <= right; x++) { orc_put(fbuf, top, x, R, G, B); orc_put(fbuf, bottom, x, R, G, B); }   /* :132-137 */
+    for (int y = top; y <= bottom; y++) { orc_put(fbuf, y, left, R, G, B); orc_put(fbuf, y, right, R, G, B); }   /* :145-151 */
+}
+
+uint32_t orc_hashcolor(uint32_t a)
+{   /* td.cpp:295-304 */
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+
+const uint32_t* orc_colormap(void)
+{   /* td.cpp:655-697: the 16 system colours, the 6 x 6 x 6 cube on levels {00,5f,87,af,d7,ff}, 24 greys 08 + 10 k -- with the two
+     * greys the reference spells 0x606060 and 0x666666 (entries 241, 242) */
+    static uint32_t map[256]; static int done = 0;
+    if (!done) {
+        static const uint32_t sys[16] = { 0x000000, 0x800000, 0x008000, 0x808000, 0x000080, 0x800080, 0x008080, 0xc0c0c0,
+                                          0x808080, 0xff0000, 0x00ff00, 0xffff00, 0x0000ff, 0xff00ff, 0x00ffff, 0xffffff };
+        static const uint32_t lv[6] = { 0x00, 0x5f, 0x87, 0xaf, 0xd7, 0xff };
+        for (int i = 0; i < 16; i++) map[i] = sys[i];
+        for (int r = 0; r < 6; r++) for (int g = 0; g < 6; g++) for (int b = 0; b < 6; b++) map[16 + 36 * r + 6 * g + b] = (lv[r] << 16) | (lv[g] << 8) | lv[b];
+        for (int k = 0; k < 24; k++) { const uint32_t v = 8 + 10 * k; map[232 + k] = (v << 16) | (v << 8) | v; }
+        map[241] = 0x606060; map[242] = 0x666666;
+        done = 1;
+    }
+    return map;
+}
+
+void orc_overlay(uint8_t* frame, const orc_bbox_t* boxes, const unsigned* tids, int n)
+{
+    const uint32_t* cm = orc_colormap();
+    for (int j = 0; j < n; j++) {                                      /* td.cpp:647-733 */
+        const uint32_t color = cm[orc_hashcolor(tids[j]) & 255];       /* td.cpp:620,699 */
+        const orc_bbox_t b = boxes[j];
+        orc_draw_rect(frame, b.l, b.t, b.r, b.b, color);
+        orc_draw_rect(frame, b.l + 1, b.t + 1, b.r - 1, b.b - 1, color);
+        orc_draw_rect(frame, b.l + 2, b.t + 2, b.r - 2, b.b - 2, color);
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * detector post-processing (detectors/yolo3.cpp:141-356, 490-530), float arithmetic as written there.  PARITY UNPINNED (see header).
+ * ------------------------------------------------------------------------- */
+typedef struct { float x, y, u, w; int c; float s; } orc_pre;          /* predecode_t, yolo3.cpp:95-99 */
+typedef struct { int xmin, ymin, xmax, ymax, classes; float objectness; } orc_det;   /* detection_t, :101-108 */
+
+static int orc_decode(orc_pre* boxes, int n, int cap, const float* out, const int* anchors, float obj_thresh, int tensor_h, int tensor_w,
+                      int grid_h, int grid_w, int nc)
+{   /* decode_netout :141-201 */
+    const int per = 5 + nc, nb_box = 3 * per;
+    for (int i = 0; i < grid_h * grid_w; i++) {
+        const int row = i / grid_w, col = i % grid_w;
+        const float* cell = out + (size_t)i * nb_box;
+        for (int b = 0; b < 3; b++) {
+            const float* v = cell + b * per;
+            const float objectness = 1 / (1 + expf(-v[4]));
+            for (int j = 0; j < nc; j++) {
+                const float scores = (1 / (1 + expf(-v[5 + j]))) * objectness;
+                if (scores >= obj_thresh && n < cap) {
+                    orc_pre p;
+                    p.x = (col + (1 / (1 + expf(-v[0])))) / grid_w;
+                    p.y = (row + (1 / (1 + expf(-v[1])))) / grid_h;
+                    p.u = anchors[2 * b + 0] * expf(v[2]) / tensor_w;
+                    p.w = anchors[2 * b + 1] * expf(v[3]) / tensor_h;
+                    p.s = scores; p.c = j;
+                    boxes[n++] = p;
+                }
+            }
+        }
+    }
+    return n;
+}
+
+int orc_yolo_postprocess(const float* head0, const float* head1, const float* head2, int tensor_h, int tensor_w, int nc,
+                         int image_h, int image_w, const orc_yolo_opt* opt, orc_bbox_t* out, int cap)
+{
+    const int CAND = 16384;
+    orc_pre* pre = (orc_pre*)malloc(sizeof(orc_pre) * CAND);
+    orc_det* cb = (orc_det*)malloc(sizeof(orc_det) * CAND);
+    orc_det* cls = (orc_det*)malloc(sizeof(orc_det) * CAND);
+    int* idx = (int*)malloc(sizeof(int) * CAND); int* sup = (int*)malloc(sizeof(int) * CAND);
+    const int grid_h = tensor_h / 32, grid_w = tensor_w / 32;            /* :405-406 */
+    int n = 0;
+    n = orc_decode(pre, n, CAND, head0, opt->anchors + 12, opt->obj_thresh, tensor_h, tensor_w, grid_h << 0, grid_w << 0, nc);   /* :512-514 */
+    n = orc_decode(pre, n, CAND, head1, opt->anchors + 6, opt->obj_thresh, tensor_h, tensor_w, grid_h << 1, grid_w << 1, nc);
+    n = orc_decode(pre, n, CAND, head2, opt->anchors + 0, opt->obj_thresh, tensor_h, tensor_w, grid_h << 2, grid_w << 2, nc);
+    /* correct_yolo_boxes :203-254 (an empty list yields one zero box there; it is dropped again by the emit loop's class filter) */
+    float new_w, new_h;
+    if (((float)tensor_w / (float)image_w) < ((float)tensor_h / (float)image_h)) { new_w = (float)tensor_w; new_h = roundf((float)image_h * tensor_w / (float)image_w); }
+    else { new_h = (float)tensor_h; new_w = roundf((float)image_w * tensor_h / (float)image_h); }
+    for (int i = 0; i < n; i++) {
+        const float x_offset = (float)((tensor_w - new_w) / 2.0 / tensor_w), x_scale = (float)new_w / tensor_w;
+        const float y_offset = (float)((tensor_h - new_h) / 2.0 / tensor_h), y_scale = (float)new_h / tensor_h;
+        const float x = (pre[i].x - x_offset) / x_scale * (float)image_w, y = (pre[i].y - y_offset) / y_scale * (float)image_h;
+        const float w = (pre[i].u) / x_scale * (float)image_w, h = (pre[i].w) / y_scale * (float)image_h;
+        cb[i].xmin = (int)(x - w / 2); cb[i].xmax = (int)(x + w / 2); cb[i].ymin = (int)(y - h / 2); cb[i].ymax = (int)(y + h / 2);
+        cb[i].objectness = pre[i].s; cb[i].classes = pre[i].c;
+    }
+    /* do_nms :279-356 + emit :519-547.  Quirk kept: `is_suppressed` (:286) is declared OUTSIDE the class loop and only ever grows by
+     * push_back(0), while it is indexed with the class-local indices 0..m-1 -- so a flag set while an earlier class was processed is
+     * still set for the box with the same local index of a later class. */
+    int nout = 0;
+    for (int i = 0; i < CAND; i++) sup[i] = 0;
+    for (int c = 0; c < nc; c++) {
+        int m = 0;
+        for (int j = 0; j < n; j++) if (cb[j].classes == c) cls[m++] = cb[j];
+        for (int i = 0; i < m; i++) idx[i] = i;
+        for (int i = 0; i < m; i++)                                     /* sort :256-277: in-place exchange, strict '>' */
+            for (int j = i + 1; j < m; j++)
+                if (cls[idx[j]].objectness > cls[idx[i]].objectness) { const int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+        for (int i = 0; i < m; i++) {
+            if (sup[idx[i]]) continue;
+            for (int j = i + 1; j < m; j++) {
+                const orc_det* A = &cls[idx[j]]; const orc_det* B = &cls[idx[i]];
+                const float maxX = (float)(A->xmax < B->xmax ? A->xmax : B->xmax), maxY = (float)(A->ymax < B->ymax ? A->ymax : B->ymax);
+                const float minX = (float)(A->xmin > B->xmin ? A->xmin : B->xmin), minY = (float)(A->ymin > B->ymin ? A->ymin : B->ymin);
+                const float oW = maxX - minX + 1, oH = maxY - minY + 1;
+                if ((oW > 0) & (oH > 0)) {
+                    const float a1 = (float)((A->xmax - A->xmin + 1) * (A->ymax - A->ymin + 1)), a2 = (float)((B->xmax - B->xmin + 1) * (B->ymax - B->ymin + 1));
+                    const float iou = (oW * oH) / (a1 + a2 - oW * oH);
+                    if (iou > opt->nms_thresh) sup[idx[j]] = 1;
+                }
+            }
+        }
+        for (int i = 0; i < m; i++) {
+            if (sup[idx[i]]) continue;
+            orc_det d = cls[idx[i]];
+            d.ymin = d.ymin > 0 ? d.ymin : 0; d.xmin = d.xmin > 0 ? d.xmin : 0;                     /* :523-526 */
+            d.ymax = d.ymax < image_h - 1 ? d.ymax : image_h - 1; d.xmax = d.xmax < image_w - 1 ? d.xmax : image_w - 1;
+            if (d.ymin > d.ymax || d.xmin > d.xmax || d.ymin < 0 || d.xmin < 0 || d.xmax >= image_w || d.ymax >= image_h) continue;   /* :528-536 */
+            if (nout < cap) { out[nout].t = d.ymin; out[nout].l = d.xmin; out[nout].b = d.ymax; out[nout].r = d.xmax; out[nout].type = d.classes; out[nout].score = d.objectness; nout++; }
+        }
+    }
+    free(pre); free(cb); free(cls); free(idx); free(sup);
+    return nout;
+}

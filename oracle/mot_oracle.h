@@ -100,6 +100,23 @@ int orc_mot_ntracks(const orc_mot*);
 orc_kcf*    orc_mot_kcf(orc_mot*, int i);
 orc_kalman* orc_mot_kalman(orc_mot*, int i);
 
+/* ---- overlay: top/drawlib.c:97-151 drawRect, top/td.cpp:295-304 hashcolor, td.cpp:647-733 three nested
+ * outlines per live track in colormap[hashcolor(tid) & 255] (td.cpp:620,655-699).  drawRect writes the bytes R, G, B of its
+ * "RGB" argument to memory offsets 0, 1, 2 of a pixel of the BGR frame -- reproduced as is. ---- */
+void orc_draw_rect(uint8_t* fbuf, int left, int top, int right, int bottom, uint32_t rgb);
+uint32_t orc_hashcolor(uint32_t a);
+const uint32_t* orc_colormap(void);                                  /* 256 entries */
+void orc_overlay(uint8_t* frame_bgr, const orc_bbox_t* boxes, const unsigned* tids, int n);
+
+/* ---- detector post-processing: detectors/yolo3.cpp:141-356 (decode_netout, correct_yolo_boxes, sort, do_nms) and the
+ * emit loop of tensorRunB (:490-530).  PARITY UNPINNED: yolo3.cpp includes <Windows.h> and TensorFlow headers and cannot be compiled
+ * here, and the reference holds no test vectors for it -- this restatement follows the source by reading only.  Three heads of raw
+ * network output, NHWC [grid_h << s][grid_w << s][3 * (5 + classes)], s = 0, 1, 2, anchors + 12 / + 6 / + 0 (:512-514).
+ * Returns the number of boxes written (at most cap). ---- */
+typedef struct { float obj_thresh; float nms_thresh; int anchors[18]; } orc_yolo_opt;   /* top/cnntype.h:49-54 */
+int orc_yolo_postprocess(const float* head0, const float* head1, const float* head2, int tensor_h, int tensor_w, int num_classes,
+                         int image_h, int image_w, const orc_yolo_opt* opt, orc_bbox_t* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,3 +315,31 @@ def test_device_loop_single_size_class_lo_equals_hi(mot, oracle):
         assert len(tids) > 0 and np.array_equal(tids, ref["tids"]), f"frame {f} tids"
         assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
     m.close(); c.close()
+
+
+def test_device_loop_response_peaks_1024(mot, oracle):
+    """north_star's KCF tolerance at the BENCHED size: after 4 frames of the 1024-track stream every live track's response map
+    (kcf_t::response of the last predict; deferred blend, split update and joined launches all behind it) has its peak within 1e-4
+    relative of the oracle's and the same arg-max"""
+    from multiple_object_tracking_amd import synth
+    n, nframes = 1024, 4
+    scene = synth.Scene(n, 80, stream_id=0)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    m = orc.OracleMot(oracle, 0, 0, 1024)
+    for f in range(nframes):
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+    boxes, tids, ages = c.live_tracks()
+    assert np.array_equal(tids, ref["tids"]) and np.array_equal(bnp(boxes), bnp(ref["live"]))
+    worst = 0.0
+    for i in range(0, len(tids), 3):                                    # every third track: 342 response maps
+        got = c.live_response(i)
+        exp = orc.arr(oracle.orc_kcf_response(m.kcf(i)), got.size)
+        assert int(np.argmax(got)) == int(np.argmax(exp)), f"track {i}: arg-max"
+        rel = abs(float(got.max()) - float(exp.max())) / abs(float(exp.max()))
+        worst = max(worst, rel)
+    assert worst <= 1e-4, worst
+    m.close(); c.close()
