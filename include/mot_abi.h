@@ -188,6 +188,11 @@ int mot_step_finish(mot_ctx* ctx, const void* gathered_boxes_dev, const bbox_t* 
 int mot_step_frame_device(mot_ctx* ctx, const void* frame_dev, const void* dets_dev /* bbox_t[nD] */, int nD);
 int mot_step_begin_device(mot_ctx* ctx, const void* frame_dev, void** local_boxes_dev, int* slots_per_rank);
 int mot_step_finish_device(mot_ctx* ctx, const void* gathered_boxes_dev, const void* dets_dev, int nD);
+/* The sharded frame as ONE native call (multi-GPU hosts written in C/C++, e.g. a td.cpp-style tracker thread per GPU): predict of the
+ * local shard, ONE in-place ncclAllGather of the predicted bbox_t segments (RCCL over xGMI; `nccl_comm` is the caller's ncclComm_t
+ * for this rank, created with world = cfg.world ranks), replicated association + lifecycle, local updates -- all enqueued on the
+ * context's stream, no host synchronisation.  librccl is bound at run time (dlopen), so single-GPU builds and hosts need no RCCL. */
+int mot_step_frame_sharded(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD, void* nccl_comm);
 int mot_live_count(mot_ctx* ctx, int* n_live);
 int mot_live_tracks(mot_ctx* ctx, bbox_t* boxes, unsigned* tids, int* ages, int* n_live);
 

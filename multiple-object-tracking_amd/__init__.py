@@ -239,6 +239,10 @@ class MotContext:
     def step_finish_device(self, gathered_dev: int, dets_dev: int, n_dets: int):
         self._chk(self.lib.mot_step_finish_device(self._h, C.c_void_p(gathered_dev), C.c_void_p(dets_dev), n_dets))
 
+    def step_frame_sharded(self, frame_dev: int, dets_dev: int, n_dets: int, nccl_comm: int):
+        """one sharded frame as a single native call: predict, in-place ncclAllGather (RCCL) on the context's stream, association, update"""
+        self._chk(self.lib.mot_step_frame_sharded(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets, C.c_void_p(nccl_comm)))
+
     def profile_frame_device(self, frame_dev: int, dets_dev: int, n_dets: int) -> np.ndarray:
         ms = np.zeros(5, np.float32)
         self._chk(self.lib.mot_profile_frame_device(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets, _vp(ms)))

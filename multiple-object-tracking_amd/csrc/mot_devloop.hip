@@ -12,6 +12,7 @@
 // lifecycle are replicated (deterministic) on every rank.
 #include "mot_ctx.h"
 #include "dl_lifecycle.h"
+#include <dlfcn.h>
 
 using namespace mot_impl;
 
@@ -305,6 +306,40 @@ int mot_step_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_de
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
     rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
+    return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
+}
+
+// ---- native RCCL leg ----------------------------------------------------------------------------------------------
+namespace {
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, void* /* ncclComm_t */, hipStream_t);
+nccl_all_gather_fn rccl_all_gather()
+{
+    static nccl_all_gather_fn fn = nullptr; static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) fn = reinterpret_cast<nccl_all_gather_fn>(dlsym(h, "ncclAllGather"));
+    }
+    return fn;
+}
+} // namespace
+
+int mot_step_frame_sharded(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, void* nccl_comm)
+{
+    if (!c || !nccl_comm) return fail(MOT_ERR_ARG, "null argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    nccl_all_gather_fn all_gather = rccl_all_gather();
+    if (!all_gather) return fail(MOT_ERR_DEVICE, "librccl.so.1 / ncclAllGather not available: %s", dlerror() ? dlerror() : "symbol missing");
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
+    // the frame's single collective: every rank's segment of predicted boxes, in place (send = recv + rank * count), on the SAME stream
+    // as the kernels on both sides of it -- stream order is the only synchronisation
+    const DLState& S = d->S;
+    const size_t count = (size_t)S.spr * sizeof(bbox_t);
+    const int ncclChar = 0;
+    const int nr = all_gather(reinterpret_cast<const char*>(S.gather) + (size_t)S.rank * count, S.gather, count, ncclChar, nccl_comm, c->stream);
+    if (nr != 0) { d->begun = false; return fail(MOT_ERR_DEVICE, "ncclAllGather failed (ncclResult_t %d)", nr); }
     return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
 }
 

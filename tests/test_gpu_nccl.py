@@ -89,3 +89,82 @@ def test_bench_sharded_branch_two_ranks_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "strong" and j["config"]["live_tracks_end"] == 96
     assert j["smoke_backend"].startswith("gloo") and j["value"] > 0
+
+
+class _NcclId(__import__("ctypes").Structure):
+    _fields_ = [("internal", __import__("ctypes").c_char * 128)]
+
+
+def _rccl():
+    import ctypes as C
+    lib = C.CDLL("librccl.so.1")
+    lib.ncclGetUniqueId.argtypes = [C.POINTER(_NcclId)]
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclId, C.c_int]
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def _native_worker(rank, world, idq, resq):
+    import ctypes as C
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mot_amd
+    import orc
+    from multiple_object_tracking_amd import synth
+    torch.cuda.set_device(rank)
+    lib = _rccl()
+    uid = _NcclId()
+    if rank == 0:
+        assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+        for _ in range(world - 1):
+            idq.put(bytes(uid.internal))
+    else:
+        uid.internal = idq.get(timeout=120)
+    comm = C.c_void_p()
+    assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    n, nframes = 96, 6
+    scene = synth.Scene(n, 80, stream_id=62, miss_pct=5, fp_pct=3)
+    ctx = mot_amd.MotContext(max_tracks=128, max_dets=128, device=rank, rank=rank, world=world)
+    oracle = orc.OracleMot(orc.load_oracle(), 0, 0, 128)
+    ok = True
+    for frame, dets in scene.frames(nframes):
+        fd = torch.from_numpy(frame).cuda()
+        da = mot_amd.boxes_array(dets) if len(dets) else np.zeros(1, mot_amd.BBOX_DTYPE)
+        dd = torch.from_numpy(da.view(np.uint8)).cuda()
+        torch.cuda.synchronize()
+        ctx.step_frame_sharded(fd.data_ptr(), dd.data_ptr(), len(dets), comm.value)   # predict, ncclAllGather, association, update: one call
+        ref = oracle.step(frame, dets)
+        boxes, tids, _ = ctx.live_tracks()
+        ok &= bool(np.array_equal(tids, ref["tids"]))
+        ok &= all(np.array_equal(boxes[k], ref["live"][k]) for k in ("l", "t", "b", "r", "type"))
+    ctx.close(); oracle.close()
+    lib.ncclCommDestroy(comm)
+    resq.put((rank, ok))
+
+
+def test_native_rccl_entry_point_one_rank():
+    """mot_step_frame_sharded on the single-GPU box: a ONE-rank RCCL communicator -- binds librccl at run time, issues the real
+    ncclAllGather on the context's stream between predict and association, results equal the oracle"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    idq, resq = ctx.Queue(), ctx.Queue()
+    p = ctx.Process(target=_native_worker, args=(0, 1, idq, resq))
+    p.start()
+    res = resq.get(timeout=600)
+    p.join(timeout=120)
+    assert res == (0, True)
+
+
+def test_native_rccl_entry_point_two_ranks():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    idq, resq = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, idq, resq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [resq.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(res) == [(0, True), (1, True)]
