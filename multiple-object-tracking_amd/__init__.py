@@ -239,6 +239,10 @@ class MotContext:
     def step_finish_device(self, gathered_dev: int, dets_dev: int, n_dets: int):
         self._chk(self.lib.mot_step_finish_device(self._h, C.c_void_p(gathered_dev), C.c_void_p(dets_dev), n_dets))
 
+    def step_frame_host(self, host_frame_ptr: int, host_dets_ptr: int, n_dets: int):
+        """frame + detections from (pinned) host memory: upload on the context's copy stream, double-buffered against the previous frame"""
+        self._chk(self.lib.mot_step_frame_host(self._h, C.c_void_p(host_frame_ptr), C.c_void_p(host_dets_ptr), n_dets))
+
     def step_frame_sharded(self, frame_dev: int, dets_dev: int, n_dets: int, nccl_comm: int):
         """one sharded frame as a single native call: predict, in-place ncclAllGather (RCCL) on the context's stream, association, update"""
         self._chk(self.lib.mot_step_frame_sharded(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets, C.c_void_p(nccl_comm)))

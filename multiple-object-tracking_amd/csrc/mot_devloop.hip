@@ -47,6 +47,8 @@ struct DevLoop {
     // association runs; the per-track update then only blends them into the model
     DevBuf<float2> det_spec; DevBuf<int> pend; size_t spec_stride = 0; unsigned frame_no = 0; bool defer = false;   // det_spec: two buffers, by frame parity
     hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
+    // mot_step_frame_host: copy stream + two device buffers (frame, detections); up[b]: upload of buffer b done, done[b]: the frame that read it finished
+    hipStream_t copy = nullptr; DevBuf<uint8_t> hbuf[2]; DevBuf<bbox_t> dbuf[2]; hipEvent_t ev_up[2]{}, ev_done[2]{}; unsigned host_no = 0; bool host_ok = false;
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
     bool feat_joined = false;     // ... inside the predict launch itself (no side stream, no event to wait for)
 };
@@ -60,6 +62,7 @@ void devloop_destroy(DevLoop* d)
     if (d->ev_upd) (void)hipEventDestroy(d->ev_upd);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->side) (void)hipStreamDestroy(d->side);
+    if (d->host_ok) { for (int b = 0; b < 2; b++) { (void)hipEventDestroy(d->ev_up[b]); (void)hipEventDestroy(d->ev_done[b]); } (void)hipStreamDestroy(d->copy); }
     delete d;
 }
 
@@ -341,6 +344,44 @@ int mot_step_frame_sharded(mot_ctx* c, const void* frame_dev, const void* dets_d
     const int nr = all_gather(reinterpret_cast<const char*>(S.gather) + (size_t)S.rank * count, S.gather, count, ncclChar, nccl_comm, c->stream);
     if (nr != 0) { d->begun = false; return fail(MOT_ERR_DEVICE, "ncclAllGather failed (ncclResult_t %d)", nr); }
     return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
+}
+
+int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_dets, int nD)
+{
+    if (!c || !host_bgr || nD < 0 || (nD && !host_dets)) return fail(MOT_ERR_ARG, "bad argument");
+    if (c->cfg.world != 1) return fail(MOT_ERR_STATE, "sharded context: upload the frame yourself and use mot_step_frame_sharded");
+    if (nD > c->cfg.max_dets) return fail(MOT_ERR_CAPACITY, "%d detections exceed max_dets %d", nD, c->cfg.max_dets);
+    int rc = ensure_device(c); if (rc) return rc;
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    const size_t fbytes = (size_t)MOT_FRAME_W * MOT_FRAME_H * 3;
+    if (!d->host_ok) {
+        HIPCHK(hipStreamCreateWithFlags(&d->copy, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(d->hbuf[b].alloc(fbytes)); HIPCHK(d->dbuf[b].alloc((size_t)c->cfg.max_dets));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_up[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&d->ev_done[b], hipEventDisableTiming));
+        }
+        d->host_ok = true;
+    }
+    const int b = (int)(d->host_no & 1);
+    static int h2d_mode = -1;                                          // MOT_H2D_MODE=1: uploads on the context's own stream (no overlap, no cross-stream events)
+    if (h2d_mode < 0) { const char* ev = getenv("MOT_H2D_MODE"); h2d_mode = ev ? atoi(ev) : 0; }
+    if (h2d_mode == 1) {
+        HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, c->stream));
+        if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
+    } else {
+        if (d->host_no >= 2) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_done[b], 0));   // the frame that read this buffer has finished
+        HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, d->copy));
+        if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, d->copy));
+        HIPCHK(hipEventRecord(d->ev_up[b], d->copy));
+        HIPCHK(hipStreamWaitEvent(c->stream, d->ev_up[b], 0));
+    }
+    rc = dl_begin(c, d, d->hbuf[b].p, nullptr, d->dbuf[b].p, nD); if (rc) return rc;
+    rc = dl_finish(c, d, nullptr, d->dbuf[b].p, nD, nullptr); if (rc) return rc;
+    // with the deferred blend the NEXT frame's predict still reads nothing of this frame's buffers (spectra live in their own buffers),
+    // so the buffer is free once this frame's stream work is done
+    HIPCHK(hipEventRecord(d->ev_done[b], c->stream));
+    d->host_no++;
+    return MOT_OK;
 }
 
 int mot_profile_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, float* stage_ms5)
