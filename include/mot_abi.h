@@ -186,6 +186,13 @@ int mot_step_finish(mot_ctx* ctx, const void* gathered_boxes_dev, const bbox_t* 
  * frame's kernels are only enqueued.  Lifecycle (delete/spawn) is executed on
  * device as well.  mot_live_count() synchronises and returns the track count. */
 int mot_step_frame_device(mot_ctx* ctx, const void* frame_dev, const void* dets_dev /* bbox_t[nD] */, int nD);
+/* The same step with one frame of look-ahead: when the NEXT frame and its detection list are already in device memory (the reference's
+ * detector thread runs ahead of the tracker thread through 64-slot rings, td.cpp:56-80,218-223), their detection features -- which
+ * depend on that frame and its boxes only -- are computed beside THIS frame's association chain.  Results are identical to
+ * mot_step_frame_device; the next call must pass the same pointers and count to benefit (anything else is computed as usual).
+ * next_frame_dev / next_dets_dev may be null (end of stream).  Both frames' memory must stay valid until their step has executed. */
+int mot_step_frame_device_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
+                                const void* next_frame_dev, const void* next_dets_dev, int next_nD);
 int mot_step_begin_device(mot_ctx* ctx, const void* frame_dev, void** local_boxes_dev, int* slots_per_rank);
 int mot_step_finish_device(mot_ctx* ctx, const void* gathered_boxes_dev, const void* dets_dev, int nD);
 /* The same frame step fed from HOST memory (td.cpp:326-333: the tracker thread receives each frame and its detection list from the

@@ -231,6 +231,11 @@ class MotContext:
     def step_frame_device(self, frame_dev: int, dets_dev: int, n_dets: int):
         self._chk(self.lib.mot_step_frame_device(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets))
 
+    def step_frame_device_ahead(self, frame_dev: int, dets_dev: int, n_dets: int, next_frame_dev: int, next_dets_dev: int, next_n_dets: int):
+        """mot_step_frame_device with one frame of look-ahead (next_* = 0: none)"""
+        self._chk(self.lib.mot_step_frame_device_ahead(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets,
+                                                       C.c_void_p(next_frame_dev) if next_frame_dev else None, C.c_void_p(next_dets_dev) if next_dets_dev else None, next_n_dets))
+
     def step_begin_device(self, frame_dev: int):
         ptr, spr = C.c_void_p(), C.c_int(0)
         self._chk(self.lib.mot_step_begin_device(self._h, C.c_void_p(frame_dev), C.byref(ptr), C.byref(spr)))

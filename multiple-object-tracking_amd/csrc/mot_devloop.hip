@@ -45,10 +45,18 @@ struct DevLoop {
     hipEvent_t ev[8]{}; bool ev_ok = false;
     // split update (KCF): the spectra of all detection boxes are computed on a second, low-priority stream while the
     // association runs; the per-track update then only blends them into the model
-    DevBuf<float2> det_spec; DevBuf<int> pend; size_t spec_stride = 0; unsigned frame_no = 0; bool defer = false;   // det_spec: two buffers, by frame parity
+    // det_spec: three spectra buffers in rotation -- the previous frame's (read by this frame's blend prologue), this frame's, and the
+    // NEXT frame's when the caller passes it ahead (mot_step_frame_device_ahead): its detection features are then computed beside this
+    // frame's association chain and are ready long before anything needs them.  ev_spec[b]: buffer b has been written (side stream);
+    // spec_side[b]: ... by the side stream (else inside a main-stream launch: stream order suffices)
+    DevBuf<float2> det_spec; DevBuf<int> pend; size_t spec_stride = 0; unsigned frame_no = 0; bool defer = false;
+    int buf_prev = 0, buf_cur = 1; hipEvent_t ev_spec[3]{}; bool spec_side[3] = {false, false, false}; bool have_cur = false;
+    const void* pf_frame = nullptr; const void* pf_dets = nullptr; int pf_nD = -1, pf_buf = -1; bool pf_valid = false;
+    const void* next_frame = nullptr; const void* next_dets = nullptr; int next_nD = 0;
     hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
     // mot_step_frame_host: copy stream + two device buffers (frame, detections); up[b]: upload of buffer b done, done[b]: the frame that read it finished
     hipStream_t copy = nullptr; DevBuf<uint8_t> hbuf[2]; DevBuf<bbox_t> dbuf[2]; hipEvent_t ev_up[2]{}, ev_done[2]{}; unsigned host_no = 0; bool host_ok = false;
+    int host_spec[2] = {-1, -1};  // spectra buffer the frame in host buffer b wrote (its side-stream feature launch reads the host buffer too)
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
     bool feat_joined = false;     // ... inside the predict launch itself (no side stream, no event to wait for)
 };
@@ -61,6 +69,7 @@ void devloop_destroy(DevLoop* d)
     if (d->ev_feat) (void)hipEventDestroy(d->ev_feat);
     if (d->ev_upd) (void)hipEventDestroy(d->ev_upd);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
+    for (hipEvent_t e : d->ev_spec) if (e) (void)hipEventDestroy(e);
     if (d->side) (void)hipStreamDestroy(d->side);
     if (d->host_ok) { for (int b = 0; b < 2; b++) { (void)hipEventDestroy(d->ev_up[b]); (void)hipEventDestroy(d->ev_done[b]); } (void)hipStreamDestroy(d->copy); }
     delete d;
@@ -161,7 +170,8 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             const char* dv = getenv("MOT_DEFER_BLEND");
             d->defer = !(dv && atoi(dv) == 0);
             d->spec_stride = (size_t)md * MOT_NCHAN * kp.nbins;
-            HIPCHK(d->det_spec.alloc(d->spec_stride * (d->defer ? 2 : 1)));
+            HIPCHK(d->det_spec.alloc(d->spec_stride * 3));
+            for (int b = 0; b < 3; b++) HIPCHK(hipEventCreateWithFlags(&d->ev_spec[b], hipEventDisableTiming));
             if (d->defer) {
                 HIPCHK(d->pend.alloc((size_t)cap)); HIPCHK(hipMemset(d->pend.p, 0xFF, sizeof(int) * cap));
                 S.defer = 1; S.pend_det = d->pend.p;
@@ -183,15 +193,23 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     if (S.kind == MOT_TRACKER_KCF && !frame_dev) return fail(MOT_ERR_ARG, "null frame");
     d->frame = frame_dev;
     d->frame_no++;
-    float2* spec_cur = d->det_spec.p + (d->defer ? (size_t)(d->frame_no & 1) * d->spec_stride : 0);            // this frame's detection spectra
-    const float2* spec_prev = d->det_spec.p + (d->defer ? (size_t)((d->frame_no - 1) & 1) * d->spec_stride : 0);   // ... the previous frame's
+    // this frame's spectra buffer: the one a look-ahead launch of the previous call filled for exactly this frame and detection list,
+    // else a free one (then the features are computed within the frame, as before)
+    d->have_cur = d->split && d->pf_valid && d->pf_frame == frame_dev && d->pf_dets == dets_dev && d->pf_nD == nD && dets_dev;
+    d->buf_cur = d->have_cur ? d->pf_buf : (d->buf_prev + 1) % 3;
+    d->pf_valid = false;
+    if (!d->have_cur) d->spec_side[d->buf_cur] = false;
+    float2* spec_cur = d->det_spec.p + (size_t)d->buf_cur * d->spec_stride;            // this frame's detection spectra
+    const float2* spec_prev = d->det_spec.p + (size_t)d->buf_prev * d->spec_stride;     // ... the previous frame's
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
     if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
     d->feat_early = false;
     static int early_max = -1;
     if (early_max < 0) { const char* ev = getenv("MOT_SPLIT_EARLY_MAX"); early_max = ev ? atoi(ev) : MOT_SPLIT_EARLY_MAX; }
     d->feat_joined = false;
-    const bool early = d->split && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= early_max;
+    const bool early = d->split && !d->have_cur && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= early_max;
+    // the blend prologue of this predict reads the previous frame's spectra: behind the side-stream launch that wrote them
+    if (d->split && d->defer && d->spec_side[d->buf_prev]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_prev], 0));
     static int joined_on = -1;
     if (joined_on < 0) { const char* ev = getenv("MOT_JOINED_LAUNCH"); joined_on = (ev && atoi(ev) == 0) ? 0 : 1; }
     if (S.kind == MOT_TRACKER_KCF) {
@@ -211,7 +229,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
                 HIPCHK(hipEventRecord(d->ev_in, c->stream));
                 HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
                 HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
-                HIPCHK(hipEventRecord(d->ev_feat, d->side));
+                HIPCHK(hipEventRecord(d->ev_spec[d->buf_cur], d->side)); d->spec_side[d->buf_cur] = true;
                 d->feat_early = true;
             }
             HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
@@ -235,33 +253,49 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const bbox_t* dets = (const bbox_t*)dets_dev;
     KcfPool kp{}; if (S.kind == MOT_TRACKER_KCF) kp = c->pools[d->pool]->dev;
     const bool split = d->split && S.kind == MOT_TRACKER_KCF && nD > 0;
-    float2* spec_cur = d->det_spec.p + (d->defer ? (size_t)(d->frame_no & 1) * d->spec_stride : 0);
+    float2* spec_cur = d->det_spec.p + (size_t)d->buf_cur * d->spec_stride;
+    const bool feat_here = split && !d->feat_early && !d->have_cur;     // this frame's detection features still have to be computed (side stream, beside the chain)
+    const bool ahead = d->split && S.kind == MOT_TRACKER_KCF && d->next_frame && d->next_dets && d->next_nD > 0 && d->next_nD <= S.max_dets;
     // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
     LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
-    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (split && !d->feat_early) ? d->ev_mid : nullptr, &life));
-    if (split && !d->feat_early) {
-        // features of every detection box, on the side stream, from the moment the Munkres kernel has been handed to the
-        // dispatcher (so its 17 workgroups are placed first); the frame and the boxes are inputs of this call
-        HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
+    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (feat_here || ahead) ? d->ev_mid : nullptr, &life));
+    if (feat_here || ahead) HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
+    if (feat_here) {
+        // features of every detection box, on the side stream, from the moment the association chain starts (its one-workgroup kernels
+        // leave the chip idle); the frame and the boxes are inputs of this call
         KcfLaunch lf{}; lf.frame = (const uint8_t*)d->frame; lf.boxes_in = dets; lf.spec_out = spec_cur; lf.slab_base = S.cap;
         HIPCHK(launch_kcf_update(kp, lf, nD, d->side));
-        HIPCHK(hipEventRecord(d->ev_feat, d->side));
+        HIPCHK(hipEventRecord(d->ev_spec[d->buf_cur], d->side)); d->spec_side[d->buf_cur] = true;
     }
+    if (ahead) {
+        // look-ahead: the NEXT frame's detection features (they depend on that frame and its boxes only, not on any tracker state), into
+        // the third buffer; the next call recognises the frame / list it was computed for
+        const int nb = 3 - d->buf_cur - d->buf_prev;                    // the buffer that is neither this frame's nor the previous frame's (the two always differ)
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->next_frame; lf.boxes_in = (const bbox_t*)d->next_dets; lf.spec_out = d->det_spec.p + (size_t)nb * d->spec_stride; lf.slab_base = S.cap;
+        HIPCHK(launch_kcf_update(kp, lf, d->next_nD, d->side));
+        HIPCHK(hipEventRecord(d->ev_spec[nb], d->side)); d->spec_side[nb] = true;
+        d->pf_frame = d->next_frame; d->pf_dets = d->next_dets; d->pf_nD = d->next_nD; d->pf_buf = nb; d->pf_valid = true;
+    }
+    d->next_frame = nullptr; d->next_dets = nullptr; d->next_nD = 0;
     if (ev) HIPCHK(hipEventRecord(ev[2], c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[3], c->stream));
     const int upd_max = S.spr + nD;
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
-        if (split) { if (!d->feat_joined) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_feat, 0)); l.det_spec = spec_cur; l.det_index = S.upd_det; }
+        if (split) { l.det_spec = spec_cur; l.det_index = S.upd_det; }
         if (d->defer) {
             // only tracks that keep their PREDICTED box (unmatched, not lost: td.cpp:550-581) are left in the update list -- few or none,
-            // count known on the device only: a small grid loops over them.  (The stream still orders the next predict behind the
-            // feature launch: its blend prologue reads this frame's spectra.)
+            // count known on the device only: a small grid loops over them.  They read no spectra, so this launch does not wait for the
+            // feature launch; the NEXT predict does (its blend prologue reads this frame's spectra), see dl_begin.
             l.grid_stride = 1;
             HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
-        } else HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
+        } else {
+            if (split && d->spec_side[d->buf_cur]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_cur], 0));   // the blend launch reads this frame's spectra
+            HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
+        }
         if (split) HIPCHK(hipEventRecord(d->ev_upd, c->stream));
+        if (split) d->buf_prev = d->buf_cur;
     } else HIPCHK(launch_kalman_update(c->kal, S.upd_slots, S.upd_count, upd_max, S.upd_boxes, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[4], c->stream));
     return MOT_OK;
@@ -270,10 +304,12 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
 } // namespace
 
 namespace mot_impl {
-// sticky device-side errors of the device-resident loop (the stream must be idle)
+// sticky device-side errors of the device-resident loop (the stream must be idle).  Also drains the side stream: a detection-feature
+// launch may still be reading the frame the caller is about to release.
 int devloop_check(mot_ctx* c)
 {
     if (!c->devloop) return MOT_OK;
+    if (c->devloop->side) HIPCHK(hipStreamSynchronize(c->devloop->side));
     int err[8];
     HIPCHK(hipMemcpy(err, c->devloop->S.err, sizeof err, hipMemcpyDeviceToHost));
     if (err[4]) return fail(MOT_ERR_DEVICE, "Munkres helper workgroups timed out (hand-off %d); the frame was dropped", err[4]);
@@ -366,10 +402,14 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
     static int h2d_mode = -1;                                          // MOT_H2D_MODE=1: uploads on the context's own stream (no overlap, no cross-stream events)
     if (h2d_mode < 0) { const char* ev = getenv("MOT_H2D_MODE"); h2d_mode = ev ? atoi(ev) : 0; }
     if (h2d_mode == 1) {
+        if (d->host_no >= 2 && d->host_spec[b] >= 0 && d->spec_side[d->host_spec[b]]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->host_spec[b]], 0));
         HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, c->stream));
         if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
     } else {
-        if (d->host_no >= 2) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_done[b], 0));   // the frame that read this buffer has finished
+        if (d->host_no >= 2) {
+            HIPCHK(hipStreamWaitEvent(d->copy, d->ev_done[b], 0));       // the frame that read this buffer has finished on the main stream ...
+            if (d->host_spec[b] >= 0 && d->spec_side[d->host_spec[b]]) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_spec[d->host_spec[b]], 0));   // ... and its feature launch on the side stream
+        }
         HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, d->copy));
         if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, d->copy));
         HIPCHK(hipEventRecord(d->ev_up[b], d->copy));
@@ -380,8 +420,22 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
     // with the deferred blend the NEXT frame's predict still reads nothing of this frame's buffers (spectra live in their own buffers),
     // so the buffer is free once this frame's stream work is done
     HIPCHK(hipEventRecord(d->ev_done[b], c->stream));
+    d->host_spec[b] = d->split ? d->buf_prev : -1;                       // (dl_finish has already rotated: buf_prev is this frame's buffer)
     d->host_no++;
     return MOT_OK;
+}
+
+int mot_step_frame_device_ahead(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, const void* next_frame_dev, const void* next_dets_dev, int next_nD)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    if (c->cfg.world != 1) return fail(MOT_ERR_STATE, "sharded context: use mot_step_begin_device / all-gather / mot_step_finish_device");
+    int rc = ensure_device(c); if (rc) return rc;
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    static int ahead_on = -1;
+    if (ahead_on < 0) { const char* ev = getenv("MOT_LOOKAHEAD"); ahead_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+    if (ahead_on) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
+    rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
+    return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
 }
 
 int mot_profile_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, float* stage_ms5)

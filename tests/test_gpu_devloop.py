@@ -370,3 +370,32 @@ def test_device_loop_fed_from_host_memory(mot, oracle):
             assert np.array_equal(tids, refs[f]["tids"]), f"frame {f} tids"
             assert np.array_equal(bnp(boxes), bnp(refs[f]["live"])), f"frame {f} live boxes"
     m.close(); c.close()
+
+
+@pytest.mark.parametrize("n,miss,fp", [(1024, 0, 0), (300, 6, 4), (48, 8, 5)])
+def test_device_loop_lookahead_vs_oracle(mot, oracle, n, miss, fp):
+    """mot_step_frame_device_ahead: the next frame's detection features are computed one frame early (three spectra buffers in
+    rotation, deferred blend reading the previous frame's).  Results must equal the oracle frame by frame -- also when the look-ahead is
+    wrong (a different frame / list arrives than was announced), missing (end of stream), or alternates with plain calls."""
+    from multiple_object_tracking_amd import synth
+    nframes = 9
+    scene = synth.Scene(n, 80, stream_id=7, miss_pct=miss, fp_pct=fp)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d[:1024] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    m = orc.OracleMot(oracle, 0, 0, 1024)
+    for f in range(nframes):
+        nxt = f + 1 if f + 1 < nframes else None
+        if f == 3:
+            c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))              # plain call in between (ignores what was prefetched for it? no: uses it)
+        elif f == 5 and nxt is not None:
+            c.step_frame_device_ahead(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]), fd[0].data_ptr(), dd[0].data_ptr(), len(dets[0]))   # announces the WRONG next frame
+        else:
+            c.step_frame_device_ahead(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]),
+                                      fd[nxt].data_ptr() if nxt is not None else 0, dd[nxt].data_ptr() if nxt is not None else 0, len(dets[nxt]) if nxt is not None else 0)
+        ref = m.step(frames[f], dets[f])
+        boxes, tids, ages = c.live_tracks()
+        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    m.close(); c.close()
