@@ -22,6 +22,24 @@ namespace {
 #define MOT_SPLIT_EARLY_MAX 512
 #define MOT_SPLIT_EXCL_MAX 256    // ... and one per CU (no sharing with predict workgroups) while they all fit that way
 
+// frame upload as a kernel: pinned host memory is mapped into the device's address space, so the copy stream can pull the frame over
+// PCIe with plain 16-byte loads.  (hipMemcpyAsync on a second stream stalled the HOST for ~6.5 ms every 5-15 calls on this stack --
+// tools/h2d_frame_probe.py -- which made the host-fed loop 3-10x slower than the resident one; a kernel has no such hiccup.)
+__global__ void __launch_bounds__(256) h2d_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16,
+                                                       uint2* __restrict__ dst2, const uint2* __restrict__ src2, size_t n8)
+{   // frame: 16-byte words; boxes: 8-byte words (24 bytes each: never a byte beyond the caller's array is read)
+    // a small grid (the kernels of the frame in flight keep their CUs) with four loads in flight per thread: ~0.5 MB outstanding, enough
+    // for the link's bandwidth-delay product
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = e;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) dst2[i] = src2[i];
+}
+
 __global__ void __launch_bounds__(1024) dl_scatter_kernel(DLState S, const bbox_t* gathered)
 {   // gathered segments -> live order (world > 1)
     const int n = *S.nlive, t = threadIdx.x;
@@ -399,8 +417,19 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         d->host_ok = true;
     }
     const int b = (int)(d->host_no & 1);
-    static int h2d_mode = -1;                                          // MOT_H2D_MODE=1: uploads on the context's own stream (no overlap, no cross-stream events)
-    if (h2d_mode < 0) { const char* ev = getenv("MOT_H2D_MODE"); h2d_mode = ev ? atoi(ev) : 0; }
+    // MOT_H2D_MODE: 2 (default) copy KERNEL on the copy stream (pinned, device-mapped host memory; anything else falls back to 0),
+    // 0 hipMemcpyAsync on the copy stream, 1 hipMemcpyAsync on the context's own stream (no overlap, no cross-stream events)
+    static int h2d_mode = -1;
+    if (h2d_mode < 0) { const char* ev = getenv("MOT_H2D_MODE"); h2d_mode = ev ? atoi(ev) : 2; }
+    const void* src_f = host_bgr; const void* src_d = host_dets;
+    bool by_kernel = false;
+    if (h2d_mode == 2 && ((uintptr_t)host_bgr % 16 == 0) && (!nD || (uintptr_t)host_dets % 8 == 0)) {
+        hipPointerAttribute_t af{}, ad{};
+        const bool okf = hipPointerGetAttributes(&af, host_bgr) == hipSuccess && af.devicePointer != nullptr;
+        const bool okd = !nD || (hipPointerGetAttributes(&ad, host_dets) == hipSuccess && ad.devicePointer != nullptr);
+        if (okf && okd) { by_kernel = true; src_f = af.devicePointer; if (nD) src_d = ad.devicePointer; }
+        else (void)hipGetLastError();                                  // pageable / unregistered memory: the runtime's staged copy below
+    }
     if (h2d_mode == 1) {
         if (d->host_no >= 2 && d->host_spec[b] >= 0 && d->spec_side[d->host_spec[b]]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->host_spec[b]], 0));
         HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, c->stream));
@@ -410,8 +439,15 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
             HIPCHK(hipStreamWaitEvent(d->copy, d->ev_done[b], 0));       // the frame that read this buffer has finished on the main stream ...
             if (d->host_spec[b] >= 0 && d->spec_side[d->host_spec[b]]) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_spec[d->host_spec[b]], 0));   // ... and its feature launch on the side stream
         }
-        HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, d->copy));
-        if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, d->copy));
+        if (by_kernel) {
+            const size_t n16 = fbytes / 16, n8 = (size_t)nD * sizeof(bbox_t) / 8;
+            hipLaunchKernelGGL(h2d_copy_kernel, dim3(32), dim3(256), 0, d->copy, reinterpret_cast<uint4*>(d->hbuf[b].p), reinterpret_cast<const uint4*>(src_f), n16,
+                               reinterpret_cast<uint2*>(d->dbuf[b].p), reinterpret_cast<const uint2*>(src_d), n8);
+            HIPCHK(hipGetLastError());
+        } else {
+            HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, d->copy));
+            if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, d->copy));
+        }
         HIPCHK(hipEventRecord(d->ev_up[b], d->copy));
         HIPCHK(hipStreamWaitEvent(c->stream, d->ev_up[b], 0));
     }

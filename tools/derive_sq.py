@@ -4,7 +4,7 @@
 usage: derive_sq.py <counter_collection.csv> > profiles/rNN_sq_counters.json"""
 import csv, json, statistics, sys
 
-KEYS = ("kcf_predict", "kcf_update", "munkres", "assoc_sub", "lap_rowscan", "lap_solve", "lap_verify", "mk_sparse", "mk_postcheck", "kalman")
+KEYS = ("kcf_features", "kcf_predict", "kcf_update", "munkres", "assoc_sub", "lap_rowscan", "lap_solve", "lap_verify", "mk_sparse", "mk_postcheck", "kalman")
 per = {}
 with open(sys.argv[1], newline="") as f:
     for row in csv.DictReader(f):
