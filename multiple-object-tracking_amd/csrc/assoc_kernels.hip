@@ -400,7 +400,7 @@ __device__ inline void lap_final_bookkeeping(const AssocArgs& a, int mode, bool 
     if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
     // re-arm for the next launch (this workgroup is the last reader)
     L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2;
-    L.hdr[LAP_H_DENSE] = 0; L.hdr[LAP_H_DONE] = 0; L.hdr[LAP_H_CERT] = 0; *L.cmaxkey = 0ull;
+    L.hdr[LAP_H_DENSE] = 0; L.hdr[LAP_H_DONE] = 0; L.hdr[LAP_H_CERT] = 0; L.hdr[LAP_H_VERDICT] = 0; *L.cmaxkey = 0ull;
 }
 
 // HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
@@ -924,7 +924,7 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
     return hipGetLastError();
 }
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life);   // lap_kernels.hip
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch);   // lap_kernels.hip
 hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s);                     // lap_dense.hip
 hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, const LifeArgs& life);   // mk_sparse.hip
 
@@ -963,8 +963,6 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         // nT_dev: the true nT is <= nT (the host-side upper bound); tiles outside exit early
         const int gR = ((nT_dev ? (nD > nT ? nD : nT) : maxR) + 63) / 64, gC = ((nT_dev ? (nD > nT ? nD : nT) : maxC) + 63) / 64;
         if (lap) {
-            e = launch_lap_front(a, gR, gC, s, ev_mid, life); if (e != hipSuccess) return e;
-            ev_mid = nullptr;
             // Dense solver (lap_dense.hip) for frames whose far matches defeat the sparse one (detector misses + false positives): its
             // three launches return at once when the sparse solver succeeded, but they are not even submitted unless one of the last
             // 512 launches needed them (the final kernel's hint in pinned host memory, read without synchronisation) or the number
@@ -980,8 +978,17 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
                 if (nD > 0) h[2] = nD;
                 want_dense = h[1] > 0;
             }
+            // Box costs without the dense solver in between: the sparse emulation rides in the solver's launch as its second workgroup
+            // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
+            static int two_block_on = -1, mk_batch_on = -1, fuse_on = -1;
+            if (two_block_on < 0) { const char* ev = getenv("MOT_LAP_TWO_BLOCK"); two_block_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+            if (mk_batch_on < 0) { const char* ev = getenv("MOT_MK_BATCH"); mk_batch_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+            if (fuse_on < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+            const bool two_block = two_block_on && fuse_on && !a.user && !want_dense;
+            e = launch_lap_front(a, gR, gC, s, ev_mid, life, two_block, mk_batch_on); if (e != hipSuccess) return e;
+            ev_mid = nullptr;
             if (want_dense) { e = launch_lap_dense(a, gR, gC, s); if (e != hipSuccess) return e; }
-            e = launch_mk_sparse(a, gR, gC, s, life); if (e != hipSuccess) return e;
+            if (!two_block) { e = launch_mk_sparse(a, gR, gC, s, life); if (e != hipSuccess) return e; }
             // working matrix + bitmaps for the dense emulation: chip-wide (lazy: every workgroup checks the verdict and leaves) for caller
             // matrices and for streams whose recent frames needed it; otherwise the final kernel prepares them itself if it has to
             hinted_now = ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0);

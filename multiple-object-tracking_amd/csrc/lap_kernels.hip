@@ -24,6 +24,7 @@
 #include "lap_certify.h"
 #include "lap_grid.h"
 #include "dl_lifecycle.h"
+#include "mk_sparse_body.h"
 
 using namespace assoc;
 
@@ -37,6 +38,9 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0) {                        // the housekeeping assoc_min_kernel does
         if (a.ws.ctl) { for (int i = 0; i < 2 * MK_HELPERS; i++) a.ws.ctl[CTL_PARTIAL + i * MK_PARTIAL_STRIDE] = MK_HSENT; for (int i = 0; i < 64; i++) a.ws.ctl[CTL_COV + i] = 0; }
         a.dims[0] = nR; a.dims[1] = nC; a.dims[2] = rowsTrk; a.dims[3] = nR <= nC;
+        // first kernel of the chain: the per-frame protocol words start from zero whatever the previous launch left (its final kernel
+        // re-arms them, but not on its early-out for an empty side)
+        a.ws.lap.hdr[LAP_H_VERDICT] = 0; a.ws.lap.hdr[LAP_H_DONE] = 0; a.ws.lap.hdr[LAP_H_CERT] = 0;
     }
     const int r = blockIdx.x * 4 + wave;
     if (r >= nR || nC <= 0) return;                                   // wave-uniform
@@ -187,16 +191,16 @@ __device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-
 // near-tight or infeasible; cross-class entries cost >= 1.0 and matter only for a row with u_i + eps >= 1, which scans every
 // column.  Same arithmetic per examined entry as lap_verify_kernel (the dense pass stays for caller matrices and behind the
 // dense solver).
-__global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int fused, LifeArgs life)
+// Returns (workgroup-uniform) 1 if the frame is certified here (and, in the device loop, committed), else 2.
+__device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life, unsigned char* lap_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
     LapShared& S = *reinterpret_cast<LapShared*>(lap_raw);
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const LapWs& L = a.ws.lap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t_begin = wall_clock64();
-    if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return; }
-    if (L.hdr[LAP_H_BAD]) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return; }
+    if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return 2; }
+    if (L.hdr[LAP_H_BAD]) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return 2; }
     for (int i = tid; i < nR * LAP_K; i += MK_THREADS) { S.cc[i] = L.ccost[i]; S.cj[i] = L.ccol[i]; }
     {   // largest cost of the matrix from the row maxima the row scan left in L.u
         const double rm = wave_min_f64_dpp(tid < nR ? -L.u[tid] : 0.0);
@@ -423,10 +427,10 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int 
         L.hdr[LAP_H_LAST + 7] = (int)(wall_clock64() - t_begin);
         L.hdr[49] = (int)(t_init - t_begin); L.hdr[50] = (int)t_sr; L.hdr[51] = (int)t_cm; L.hdr[52] = (int)(wall_clock64() - t_loop);   // (debug: phase ticks)
     }
-    if (!fused || a.user) return;
+    if (!fused || a.user) return 2;
     // ================= fused tail: dual check (spatial) -> certificate -> lifecycle =================
     __syncthreads();                                                   // margins are in LDS; every read of `cc` lies behind us
-    if (status) return;                                                // the solver gave up: the dense solver / the emulation decide (LAP_H_CERT stays 0)
+    if (status) return 2;                                              // the solver gave up: the dense solver / the emulation decide (LAP_H_CERT stays 0)
     const long long t_tail = wall_clock64();
     LapFused& F = *reinterpret_cast<LapFused*>(S.cc);
     const double eps = S.margins[0], tol = S.margins[1];
@@ -485,13 +489,37 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int 
         if (reason == 0) L.hdr[LAP_H_MODE] = 0;
         L.hdr[55] = (int)(wall_clock64() - t_tail);                      // (debug: dual check + certificate ticks)
     }
-    if (reason != 0 || !life.enabled) return;
+    if (reason != 0) return 2;
+    if (!life.enabled) return 1;
     // certified and in the device loop: commit the frame here (td.cpp:472-644); the rest of the chain returns at once
     if (tid < nR) a.ws.assignment[tid] = S.colOfRow[tid];
     __threadfence_block();
     __syncthreads();
     dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, F.life);
     if (tid == 0) { L.hdr[LAP_H_DONE] = 1; L.hdr[56] = (int)(wall_clock64() - t_tail); }
+    return 1;
+}
+
+__global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int fused, LifeArgs life)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
+    (void)lap_solve_run(a, fused, life, lap_raw);
+}
+
+// Two workgroups, one launch (box costs, device loop or host API): workgroup 0 is the solver with its fused tail, workgroup 1 the sparse
+// order-exact emulation, started SPECULATIVELY -- it needs nothing from the solver, only the candidate lists of the row scan -- so on a
+// tie frame the emulation is ~40 us into its run when the certificate fails, instead of waiting for a launch of its own behind it; on a
+// certified frame it is told to stop (it polls the verdict word once per step-5 cycle) and one launch of the chain is gone.  Exactly one
+// of the two commits the frame: the solver's workgroup iff it certifies, else the emulation iff its own check accepts the run; the
+// emulation publishes nothing before it has read the verdict.
+__global__ void __launch_bounds__(MK_THREADS) lap_solve2_kernel(AssocArgs a, LifeArgs life, int mk_batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
+    if (blockIdx.x == 1) { mk_sparse_run<true>(a, mk_batch, 1, life, lap_raw); return; }
+    const int verdict = lap_solve_run(a, 1, life, lap_raw);
+    __threadfence();                                                   // everything this workgroup wrote (duals, header, lifecycle) before the verdict
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&a.ws.lap.hdr[LAP_H_VERDICT], verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- stage 3 ----------------------------------------------------------------------------------------------------
@@ -564,12 +592,15 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a, int again)
 
 } // namespace
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life)
+// two_block: the caller will NOT launch mk_sparse_kernel behind this (no dense solver in between): the emulation rides in the solver's launch
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch)
 {
     static int attr_dev = -1;                                          // per-device function attribute
     int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
     if (attr_dev != dev) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapShared));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared)));
         if (e != hipSuccess) return e;
         attr_dev = dev;
     }
@@ -584,6 +615,10 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     static int fuse = -1;
     if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
     const int fused = (fuse && !a.user) ? 1 : 0;
+    if (fused && two_block) {
+        hipLaunchKernelGGL(lap_solve2_kernel, dim3(2), dim3(MK_THREADS), sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared), s, a, life, mk_batch);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a, fused, life);
     if (!fused) hipLaunchKernelGGL(lap_verify_kernel, dim3(gR, gC), dim3(256), 0, s, a, 0);
     return hipGetLastError();

@@ -20,508 +20,21 @@
 //     and hz = {c : tlive[c] != 0} as a bit mask: "the next uncovered column with an uncovered zero" is one masked
 //     find-first-bit, "its first uncovered zero row" one LDS round trip, and covering a row one LDS atomic per zero of
 //     that row; after an augmentation (all rows uncovered, :324-330) tlive = tzero.
-#include <stddef.h>
-#include "assoc_common.h"
-#include "lap_certify.h"
-#include "lap_grid.h"
-#include "dl_lifecycle.h"
+#include "mk_sparse_body.h"
 
 using namespace assoc;
 
 namespace {
 
-#define SPK LAP_K
-#define SP_TLS 32               /* slots per column in the transposed lists; a column wanted by more rows: not applicable */
-
-struct SpShared {
-    double Scol[MK_MAXN];                    // S_j   (member order keeps `tl` 8-byte aligned: it is filled and read as uint2)
-    u64 hkey;                                // step 5: order-preserving key of the minimum (LDS atomicMin, one per wavefront)
-    u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
-    unsigned tzero[MK_MAXN];                 // per column: which of its slots hold a zero
-    unsigned tlive[MK_MAXN];                 // ... a zero in an UNCOVERED row
-    unsigned short tl[SP_TLS * MK_MAXN];     // transposed lists, [column][slot]: (row << 4) | k, rows ascending
-    unsigned short cj[SPK * MK_MAXN];        // candidate columns, [k][row] (0xFFFF: none)
-    unsigned char pos[SPK * MK_MAXN];        // slot of (row, k) in its column's list
-    unsigned short zmask[MK_MAXN];           // zeros of a row as a mask over its candidates
-    short starColOfRow[MK_MAXN], starRowOfCol[MK_MAXN], primeColOfRow[MK_MAXN];
-    unsigned short clist[MK_MAXN];
-    int cnt[MK_MAXN];                        // set-up: fill cursors, then minSimple; event loop: row stamps of a batch (INT_MAX when idle)
-    unsigned char starK[MK_MAXN], primeK[MK_MAXN];   // candidate index of a row's starred / primed zero
-    unsigned ph32[MK_MAXW * 2];              // batch path: LDS copy of the columns uncovered in this phase
-    unsigned dirty32[MK_MAXW * 2];           // columns whose zero masks a step 5 changed (wave 0 refreshes their hz bits)
-    unsigned short blist[64];                // batch path: the candidate columns of one batch, ascending
-    int wave_tot[MK_THREADS / 64];
-    int flag[8];
-};
-static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
-static_assert(offsetof(SpShared, tl) % 8 == 0, "transposed lists are accessed as uint2");
-static_assert(SPK <= 16 && (SPK & (SPK - 1)) == 0 && (SP_TLS & (SP_TLS - 1)) == 0, "candidate index is packed into 4 bits; lane masks");
-static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certify scratch");
-// after the run the transposed lists are dead: their 64 KB hold the column grid of the fused after-the-fact check and the
-// lifecycle step's scratch
-struct SpPost { ColGrid grid; int life[DL_LIFE_SCRATCH_INTS]; double red[MK_THREADS / 64]; };
-static_assert(sizeof(SpPost) <= sizeof(unsigned short) * SP_TLS * MK_MAXN, "post-check overlay");
-
-__device__ __forceinline__ bool bit_of(const u64* m, int i) { return (m[i >> 6] >> (i & 63)) & 1ull; }
-__device__ __forceinline__ void lds_clear_bit64(u64* words, int i) { atomicAnd(reinterpret_cast<unsigned*>(words) + (i >> 5), ~(1u << (i & 31))); }
-
 // post_fused (box costs): the after-the-fact check runs in this workgroup as a disc query per row over a grid of the column boxes
-// (same bound per examined entry as mk_postcheck_kernel; an entry that is not examined satisfies it a fortiori, see below), and -- device
-// loop -- an accepted run is committed here (lifecycle step), so a tie frame needs no further kernel of the chain.
+// (same bound per examined entry as mk_postcheck_kernel; an entry that is not examined satisfies it a fortiori), and -- device loop -- an
+// accepted run is committed here (lifecycle step), so a tie frame needs no further kernel of the chain.  The body lives in
+// mk_sparse_body.h: the solver's launch runs it as its second workgroup (lap_kernels.hip); this kernel is the stand-alone form (caller
+// matrices, streams with the dense solver armed, MOT_LAP_FUSED=0).
 __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int mk_batch, int post_fused, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_raw[];
-    SpShared& S = *reinterpret_cast<SpShared*>(sp_raw);
-    int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
-    const LapWs& L = a.ws.lap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long t_begin = wall_clock64();
-    if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }
-    // ---- the fast path's verdict first: a certified unique optimum needs no emulation at all ----
-    const int bad = L.hdr[LAP_H_BAD];
-    if (L.hdr[LAP_H_DONE]) return;                                     // certified and committed by the solver's workgroup (fused tail, lap_kernels.hip)
-    // the solver's workgroup may already have evaluated the certificate (box costs); behind the dense solver it is evaluated again here
-    const int pre = L.hdr[LAP_H_DENSE] ? 0 : L.hdr[LAP_H_CERT];
-    const int reason = pre ? pre - 1 : lap_certify(L, nR, nC, reinterpret_cast<unsigned*>(sp_raw), S.flag);
-    __syncthreads();
-    const long long t_cert = wall_clock64();
-    if (reason == 0) { if (tid == 0) L.hdr[LAP_H_MODE] = 0; return; }
-    if (bad) { if (tid == 0) L.hdr[LAP_H_MODE] = 2; return; }          // negative / non-finite costs: dense emulation
-    // ---- set-up: candidate entries (values in registers: only the row's own thread ever touches them), d = c - row minimum
-    // (hungarian.cpp:83-89), zero masks, transposed lists ----
-    const int r = tid;
-    const int wordsC = (nC + 63) >> 6;
-    if (tid < 8) S.flag[tid] = 0;
-    S.cnt[tid] = 0; S.tzero[tid] = 0; S.Scol[tid] = 0.0;
-    S.starColOfRow[tid] = -1; S.starRowOfCol[tid] = -1; S.primeColOfRow[tid] = -1;
-    if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
-    if (tid < MK_MAXW * 2) S.dirty32[tid] = 0;
-    __syncthreads();
-    double dv[SPK]; unsigned short myc[SPK];
-    unsigned zm = 0, vk = 0;                                           // zero / present bits of the row's candidates
-#pragma unroll
-    for (int k = 0; k < SPK; k++) { dv[k] = DBL_MAX; myc[k] = 0xFFFF; }
-    if (r < nR) {
-        const double rmin = L.ccost[(size_t)r * SPK];
-#pragma unroll
-        for (int k = 0; k < SPK; k++) {
-            myc[k] = L.ccol[(size_t)r * SPK + k];
-            if (myc[k] != 0xFFFF) { vk |= 1u << k; dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < SPK; k++) S.cj[k * MK_MAXN + r] = myc[k];
-    S.zmask[r] = (unsigned short)zm;
-    __syncthreads();
-    {   // transposed lists: fill (any order), then sort each column's list by row.  The longest list bounds a per-column
-        // insertion sort (up to 32 entries of one thread: 20 us of dependent LDS round trips in a crowded scene); instead every
-        // ENTRY finds its rank by counting the smaller rows of its list -- all reads, then a barrier, then all writes.
-        const int mycnt = tid < nC ? S.cnt[tid] : 0;
-        if (mycnt > SP_TLS) S.flag[0] = 1;
-        __syncthreads();
-        if (S.flag[0]) { if (tid == 0) { L.hdr[LAP_H_MODE] = 2; L.hdr[LAP_H_LAST + 8] = 2; } return; }
-        S.cnt[tid] = 0;
-        {   // every slot starts as "no entry" (0xFFFF sorts behind every row): 64 KB, 8-byte stores (the array is 8-byte aligned)
-            uint2* t8 = reinterpret_cast<uint2*>(S.tl);
-            const uint2 ff = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-            for (int i = tid; i < SP_TLS * MK_MAXN * 2 / 8; i += MK_THREADS) t8[i] = ff;
-        }
-        __syncthreads();
-        if (r < nR) {
-#pragma unroll
-            for (int k = 0; k < SPK; k++) if (myc[k] != 0xFFFF) { const int p = atomicAdd(&S.cnt[myc[k]], 1); S.tl[myc[k] * SP_TLS + p] = (unsigned short)((r << 4) | k); }
-        }
-        __syncthreads();
-        // rank of an entry = entries of its list with a smaller packed value ((row << 4) | k: a row lists a column once, so the order is
-        // the row order); four slots per LDS read, empty slots (0xFFFF) never count
-        unsigned char rank[SPK];
-        if (r < nR) {
-#pragma unroll
-            for (int k = 0; k < SPK; k++) {
-                rank[k] = 0;
-                if (myc[k] != 0xFFFF) {
-                    const uint2* t2 = reinterpret_cast<const uint2*>(S.tl + myc[k] * SP_TLS);
-                    const unsigned me = (unsigned)((r << 4) | k);
-                    const int m4 = (S.cnt[myc[k]] + 3) >> 2;
-                    int rk = 0;
-                    for (int i = 0; i < m4; i++) {
-                        const uint2 q = t2[i];
-                        rk += ((q.x & 0xFFFFu) < me) + ((q.x >> 16) < me) + ((q.y & 0xFFFFu) < me) + ((q.y >> 16) < me);
-                    }
-                    rank[k] = (unsigned char)rk;
-                }
-            }
-        }
-        __syncthreads();
-        if (r < nR) {
-#pragma unroll
-            for (int k = 0; k < SPK; k++) if (myc[k] != 0xFFFF) {
-                S.tl[myc[k] * SP_TLS + rank[k]] = (unsigned short)((r << 4) | k); S.pos[k * MK_MAXN + r] = rank[k];
-                if ((zm >> k) & 1) atomicOr(&S.tzero[myc[k]], 1u << rank[k]);      // zero masks of the columns, from the entries' side
-            }
-        }
-        __syncthreads();
-        S.tlive[tid] = S.tzero[tid];                                   // all rows uncovered
-        __syncthreads();
-    }
-    const long long t_lists = wall_clock64();
-    // ---- step 1 (:93-101): rows ascending, each stars its first zero BY COLUMN INDEX whose column is still free.
-    // A row with ONE zero ("simple") can only ever want that column: among the simple rows of a column the lowest one gets it, unless
-    // a lower row with several zeros took it first.  Only the rows with several zeros ("complex": equal row minima, e.g. two tracks
-    // on one centroid) need the ordered pass, and they are few: wavefront 0 walks them in ascending order and asks, per zero column in
-    // ascending order, whether a lower simple row claims it (minSimple) or an earlier complex row took it (starRowOfCol). ----
-    int* minSimple = S.cnt;                                            // fill cursors are spent
-    minSimple[tid] = 0x7FFFFFFF;
-    __syncthreads();
-    const int nz = __popc(zm);
-    int fz = 0xFFFF;
-#pragma unroll
-    for (int k = 0; k < SPK; k++) if ((zm >> k) & 1) fz = min(fz, (int)myc[k]);
-    if (r < nR && nz == 1) atomicMin(&minSimple[fz], r);
-    {
-        const bool complex_row = r < nR && nz > 1;
-        const u64 bal = __ballot(complex_row);
-        if (lane == 0) S.wave_tot[wave] = __popcll(bal);
-        __syncthreads();
-        int off = 0, ncx = 0;
-        for (int w = 0; w < MK_THREADS / 64; w++) { const int t = S.wave_tot[w]; if (w < wave) off += t; ncx += t; }
-        if (complex_row) S.clist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
-        __syncthreads();
-        if (wave == 0) {                                               // ordered pass over the complex rows: lane = candidate slot
-            for (int q = 0; q < ncx; q++) {
-                const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
-                unsigned key = 0xFFFFu;
-                if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (minSimple[c] > rr && S.starRowOfCol[c] < 0) key = (unsigned)c; }
-                const unsigned mykey = key;
-                key = wave_min_u32_dpp(key);
-                if (lane == 0 && key != 0xFFFFu) { S.starColOfRow[rr] = (short)key; S.starRowOfCol[key] = (short)rr; }
-                if (mykey == key && key != 0xFFFFu) S.starK[rr] = (unsigned char)lane;
-            }
-        }
-        __syncthreads();
-        // simple rows: the lowest claimant of a column stars it unless a complex row holds it
-        if (r < nR && nz == 1 && minSimple[fz] == r && S.starRowOfCol[fz] < 0) { S.starColOfRow[r] = (short)fz; S.starRowOfCol[fz] = (short)r; S.starK[r] = (unsigned char)(__ffs((int)zm) - 1); }
-        __syncthreads();
-        S.cnt[tid] = 0x7FFFFFFF;                                           // from here on: the batch path's row stamps
-    }
-    {   // step 2a: covered columns = starred columns; hz = hzAll = columns that hold a zero
-        const bool has = tid < nC && S.starRowOfCol[tid] >= 0;
-        const u64 bal = __ballot(has);
-        const u64 hb = __ballot(S.tzero[tid] != 0);
-        if (lane == 0) { S.covC[wave] = bal; S.hz[wave] = hb; S.hzAll[wave] = hb; }
-    }
-    __syncthreads();
-    int ncov = 0;
-    for (int w = 0; w < wordsC; w++) ncov += __popcll(S.covC[w]);
-    bool done = ncov == nR;
-    int n_prime = 0, n_s5 = 0, n_aug = 0; long long t_s3 = 0, t_s5 = 0;
-    int n_bat = 0, n_seq = 0;                                           // (debug: iterations of the batch / the one-event path)   // (debug split of the event loop)
-    const long long t_setup = wall_clock64() - t_begin;
-    // Wavefront 0 keeps the 1024-bit masks as 32-bit words, lane l (and its mirror l + 32) holding word l & 31: covered columns /
-    // rows, columns uncovered in this phase, columns with a live zero (hzr) / with any zero (hzAllr).  Mirroring the upper half lets
-    // every lane store its word to the LDS copies without a branch.
-    unsigned* covR32 = reinterpret_cast<unsigned*>(S.covR); unsigned* covC32 = reinterpret_cast<unsigned*>(S.covC); unsigned* hz32 = reinterpret_cast<unsigned*>(S.hz);
-    const bool batch_on = mk_batch != 0;
-    const int l5 = lane & 31;
-    const unsigned vC = (l5 * 32 + 32 <= nC) ? ~0u : (l5 * 32 >= nC ? 0u : ((1u << (nC & 31)) - 1u));
-    unsigned cC = covC32[l5], cR = 0, ph = 0;
-    unsigned hzr = reinterpret_cast<unsigned*>(S.hz)[l5], hzAllr = hzr;
-    int nstar = ncov;                                                  // starred columns: + 1 per augmentation
-    bool hz_dirty = false;                                             // step 5 changed the masks: wave 0 rebuilds hzr / hzAllr
-    int status = 0;
-    while (!done) {
-        const long long t_a = wall_clock64();
-        // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
-        if (wave == 0) {
-            int action = 0; bool found = false;
-            unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
-            if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
-                // every lane owns word l5 of the masks (the mirror lane recomputes the same), so no cross-lane traffic is needed
-                for (unsigned dw = *reinterpret_cast<volatile unsigned*>(&S.dirty32[l5]); dw; dw &= dw - 1) {
-                    const int b = __ffs((int)dw) - 1, c = l5 * 32 + b;
-                    const unsigned bit = 1u << b;
-                    hzr = S.tlive[c] ? (hzr | bit) : (hzr & ~bit);
-                    hzAllr = S.tzero[c] ? (hzAllr | bit) : (hzAllr & ~bit);
-                }
-                S.dirty32[l5] = 0;
-                hz_dirty = false;
-            }
-            // step 4 (:283-334) for the primed, unstarred (row, col); afterwards every row is uncovered again and the sweep restarts
-            auto augment = [&](int row, int col) {
-                n_aug++;
-                int last = col;
-                if (lane == 0) {
-                    int cr = row, cc = col;
-                    for (int it = 0; it <= nR + nC; it++) {
-                        const int old_r = S.starRowOfCol[cc];
-                        S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr; S.starK[cr] = S.primeK[cr];
-                        if (old_r < 0) break;
-                        cc = S.primeColOfRow[old_r]; cr = old_r;
-                        if (cc < 0) break;
-                    }
-                    last = cc;
-                }
-                last = __builtin_amdgcn_readfirstlane(last);
-                // every covered row loses its prime and is uncovered again (:324-330): the live masks of the columns that hold its zeros
-                // go back to the zero masks (tlive == tzero & ~(slots of covered rows) everywhere, so no other column differs)
-                if (lane < 32) {
-                    for (unsigned t = cR; t; t &= t - 1) {
-                        const int r2 = lane * 32 + __ffs((int)t) - 1;
-                        S.primeColOfRow[r2] = -1;
-                        for (unsigned mm = S.zmask[r2]; mm; mm &= mm - 1) { const int c2 = S.cj[(__ffs((int)mm) - 1) * MK_MAXN + r2]; S.tlive[c2] = S.tzero[c2]; }
-                    }
-                }
-                S.primeColOfRow[row] = -1;
-                cR = 0; covR32[l5] = 0;
-                cC |= ph; if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);   // step 2a: every starred column is covered again
-                ph = 0;
-                hzr = hzAllr;
-                fm = ~0u; found = false;
-                return ++nstar == nR;                                  // step 2b
-            };
-            while (action == 0) {
-                if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
-                unsigned cand = hzr & ~cC & vC & fm;
-                unsigned cb = (unsigned)__ballot(cand != 0);           // (the upper half mirrors the lower one)
-                if (!cb && found) { found = false; fm = ~0u; cand = hzr & ~cC & vC; cb = (unsigned)__ballot(cand != 0); }   // the sweep found something: one more from column 0 (:246-248)
-                if (!cb) { action = 2; break; }
-                // three or more candidate columns in front of the sweep?  (non-empty words are counted on the scalar side; the
-                // per-lane prefix counts of the batch path come later, only when they are needed)
-                int total = 0;
-                if (batch_on) {
-                    const int nw = __popc(cb);
-                    if (nw >= 3) total = 3;
-                    else {
-                        const int w0 = __ffs((int)cb) - 1;
-                        total = __popc((unsigned)__builtin_amdgcn_readlane((int)cand, w0));
-                        if (nw == 2) total += __popc((unsigned)__builtin_amdgcn_readlane((int)cand, 31 - __clz((int)cb)));
-                    }
-                }
-                if (total >= 3) {
-                    n_bat++;
-                    // ---------- BATCH: up to 64 consecutive events of this sweep at once (lane = event).  Taken together are the events
-                    // of the first f candidate columns such that (1) their first uncovered zero rows are pairwise different, (2) no row but
-                    // possibly the last one is unstarred, (3) no column uncovered by one of them (its row's star column) that still has a
-                    // live zero lies in front of a later one -- then no event changes what a later one of the batch sees, and covers,
-                    // primes and live masks end exactly as after the f sequential iterations (CPU model: mks_solve_batched). ----------
-                    covC32[l5] = cC; S.ph32[l5] = ph; hz32[l5] = hzr;  // the LDS copies take the updates
-                    int before = 0; total = 0;                         // candidates in lower words / in all words (counts of the 32 words, bit-sliced through ballots)
-                    {
-                        const int pc = lane < 32 ? __popc(cand) : 0;
-                        const u64 lt = (1ull << lane) - 1ull;
-#pragma unroll
-                        for (int bb = 0; bb < 6; bb++) { const u64 mb = __ballot((pc >> bb) & 1); before += __popcll(mb & lt) << bb; total += __popcll(mb) << bb; }
-                    }
-                    if (lane < 32) { unsigned t = cand; int o = before; while (t && o < 64) { S.blist[o++] = (unsigned short)(lane * 32 + __ffs((int)t) - 1); t &= t - 1; } }
-                    const int ncand = min(total, 64);
-                    const bool act = lane < ncand;
-                    const int col = act ? (int)*reinterpret_cast<volatile unsigned short*>(&S.blist[lane]) : 0;
-                    const unsigned tlv = S.tlive[col];
-                    const unsigned e = S.tl[col * SP_TLS + (tlv ? __ffs((int)tlv) - 1 : 0)];
-                    if (__ballot(act && tlv == 0)) { action = 4; break; }   // hz out of step with the masks: cannot happen
-                    const int row = (int)(e >> 4) & (MK_MAXN - 1), ke = (int)(e & 15);
-                    const int sc = S.starColOfRow[row];
-                    const unsigned m = S.zmask[row];
-                    if (act) atomicMin(&S.cnt[row], lane);                 // the first event that wants a row owns it
-                    const unsigned tls = S.tlive[sc >= 0 ? sc : 0];
-                    const unsigned psb = 1u << S.pos[(int)(S.starK[row] & (SPK - 1)) * MK_MAXN + row];   // (meaningless, and unused, for an unstarred row)
-                    const int owner = *reinterpret_cast<volatile int*>(&S.cnt[row]);
-                    const unsigned limit = (act && sc > col && (tls & ~psb)) ? (unsigned)sc : 0x7FFFFFFFu;
-                    const unsigned smin = wave_min_u32_dpp(limit);
-                    const u64 stop = __ballot(act && ((unsigned)col > smin || owner != lane));
-                    const u64 augm = __ballot(act && sc < 0);
-                    int f = stop ? __ffsll((long long)stop) - 1 : ncand;
-                    const int ia = augm ? __ffsll((long long)augm) - 1 : 64;
-                    f = min(f, ia + 1);
-                    if (act) S.cnt[row] = 0x7FFFFFFF;
-                    if (lane < f) { S.primeColOfRow[row] = (short)col; S.primeK[row] = (unsigned char)ke; }   // :255
-                    if (lane < f && sc >= 0) {                         // cover the row (:270), uncover its star's column (:271)
-                        atomicOr(&covR32[row >> 5], 1u << (row & 31));
-                        atomicAnd(&covC32[sc >> 5], ~(1u << (sc & 31)));
-                        atomicOr(&S.ph32[sc >> 5], 1u << (sc & 31));
-                        for (unsigned mm = m; mm; mm &= mm - 1) {          // its zeros leave the live masks
-                            const int kk = __ffs((int)mm) - 1, c2 = S.cj[kk * MK_MAXN + row];
-                            const unsigned bitv = 1u << S.pos[kk * MK_MAXN + row];
-                            if (atomicAnd(&S.tlive[c2], ~bitv) == bitv) atomicAnd(&hz32[c2 >> 5], ~(1u << (c2 & 31)));
-                        }
-                    }
-                    n_prime += f - 1;
-                    cR = *reinterpret_cast<volatile unsigned*>(&covR32[l5]); cC = *reinterpret_cast<volatile unsigned*>(&covC32[l5]);
-                    ph = *reinterpret_cast<volatile unsigned*>(&S.ph32[l5]); hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
-                    if (ia < f) {
-                        if (augment(__builtin_amdgcn_readlane(row, ia), __builtin_amdgcn_readlane(col, ia))) { action = 3; break; }
-                        continue;
-                    }
-                    found = true;
-                    {   // the sweep continues behind the last column taken (:273)
-                        const int from = __builtin_amdgcn_readlane(col, f - 1) + 1, fw = from >> 5;
-                        fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
-                    }
-                    continue;
-                }
-                const int cw = __ffs((int)cb) - 1;
-                const int col = cw * 32 + __ffs(__builtin_amdgcn_readlane((int)cand, cw)) - 1;
-                // first uncovered row holding a zero in this column: ONE LDS round trip (every lane issues both loads, no branch between them)
-                const unsigned tlv = S.tlive[col];
-                const unsigned tle = S.tl[col * SP_TLS + l5];
-                const unsigned lv = (unsigned)__builtin_amdgcn_readfirstlane((int)tlv);
-                const unsigned ent = (unsigned)__builtin_amdgcn_readlane((int)tle, lv ? __ffs((int)lv) - 1 : 0);   // (before the check: both loads are issued together)
-                const int row = (int)(ent >> 4);
-                if (lv == 0) { action = 4; break; }                    // hz out of step with the masks: cannot happen
-                // the row's star, its zeros and where they sit in their columns' lists: one more round trip, all loads issued together
-                const int kk = lane & (SPK - 1);
-                const int sc_v = S.starColOfRow[row];
-                const unsigned m_v = S.zmask[row];
-                const int c2 = S.cj[kk * MK_MAXN + row];
-                const int ps = S.pos[kk * MK_MAXN + row];
-                const int sc = __builtin_amdgcn_readfirstlane(sc_v);
-                const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)m_v);
-                S.primeColOfRow[row] = (short)col;                     // :255 (every lane stores the same value)
-                S.primeK[row] = (unsigned char)(ent & 15);
-                n_seq++;
-                if (sc < 0) {
-                    if (augment(row, col)) { action = 3; break; }
-                    continue;
-                }
-                // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
-                cR |= (l5 == (row >> 5)) ? (1u << (row & 31)) : 0u;
-                covR32[l5] = cR;
-                if ((m & (m - 1)) == 0) {
-                    // the row's only zero is the one in this column (the usual case): its slot is the first live one of the mask just
-                    // read, so nothing has to come back from the LDS -- the column is empty iff that was its only live bit
-                    if (lane == 0) atomicAnd(&S.tlive[col], ~(lv & (0u - lv)));
-                    if ((lv & (lv - 1)) == 0) hzr &= ~((l5 == (col >> 5)) ? (1u << (col & 31)) : 0u);
-                } else {
-                    bool emptied = false;
-                    if (lane < SPK && ((m >> lane) & 1)) { const unsigned bitv = 1u << ps; emptied = atomicAnd(&S.tlive[c2], ~bitv) == bitv; }
-                    for (u64 eb = __ballot(emptied); eb; eb &= eb - 1) {   // columns that lost their last live zero (usually none or one)
-                        const int ce = __builtin_amdgcn_readlane(c2, __ffsll((long long)eb) - 1);
-                        hzr &= ~((l5 == (ce >> 5)) ? (1u << (ce & 31)) : 0u);
-                    }
-                }
-                {
-                    const unsigned sb = (l5 == (sc >> 5)) ? (1u << (sc & 31)) : 0u;
-                    cC &= ~sb; ph |= sb;
-                }
-                found = true;
-                {   // the sweep continues behind this column (:273)
-                    const int from = col + 1, fw = from >> 5;
-                    fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
-                }
-            }
-            covC32[l5] = cC;
-            if (lane == 0) { S.flag[1] = action; S.hkey = ~0ull; }
-        }
-        __syncthreads();
-        const int action = S.flag[1];
-        const long long t_b = wall_clock64();
-        t_s3 += t_b - t_a;
-        if (action == 3) { done = true; break; }
-        if (action == 4) { status = 2; break; }
-        // ================= step 5 (:337-368) on the candidate entries: thread = row =================
-        n_s5++;
-        // straight-line code (no per-candidate predication): an absent candidate has the value DBL_MAX, counts as covered and is
-        // carried through the update unchanged in effect (DBL_MAX + h == DBL_MAX); "x + 0.0" / "x - 0.0" are exact, so selecting
-        // the addend instead of the operation gives the reference's bits (:355-364)
-        const bool rc = bit_of(S.covR, r);
-        bool unc[SPK];
-        double h = DBL_MAX;
-#pragma unroll
-        for (int k = 0; k < SPK; k++) {
-            const int cc = myc[k] & (MK_MAXN - 1);                     // (0xFFFF -> a valid index; masked out by vk)
-            unc[k] = ((vk >> k) & 1) && !((covC32[cc >> 5] >> (cc & 31)) & 1u);
-            const double cand_v = (!rc && unc[k]) ? dv[k] : DBL_MAX;
-            h = cand_v < h ? cand_v : h;
-        }
-        {
-            const u64 hk = wave_min_u64_dpp(dkey(h));
-            if (lane == 0) atomicMin(&S.hkey, hk);
-        }
-        __syncthreads();
-        h = dunkey(S.hkey);
-        if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
-        unsigned nm = 0;
-        const double hr = rc ? h : 0.0;
-#pragma unroll
-        for (int k = 0; k < SPK; k++) {
-            const double x = (dv[k] + hr) - (unc[k] ? h : 0.0);        // :355-358, :361-364
-            dv[k] = x;
-            nm |= (fabs(x) < DBL_EPSILON) ? (1u << k) : 0u;
-        }
-        if (nm != zm) {                                                // zero bits that changed: the column-side masks follow
-#pragma unroll
-            for (int k = 0; k < SPK; k++) {
-                if (((nm ^ zm) >> k) & 1) {
-                    const unsigned bitv = 1u << S.pos[k * MK_MAXN + r];
-                    if ((nm >> k) & 1) { atomicOr(&S.tzero[myc[k]], bitv); if (!rc) atomicOr(&S.tlive[myc[k]], bitv); }
-                    else { atomicAnd(&S.tzero[myc[k]], ~bitv); if (!rc) atomicAnd(&S.tlive[myc[k]], ~bitv); }
-                    atomicOr(&S.dirty32[myc[k] >> 5], 1u << (myc[k] & 31));
-                }
-            }
-            zm = nm; S.zmask[r] = (unsigned short)nm;
-        }
-        if (tid < nC && !bit_of(S.covC, tid)) S.Scol[tid] += h;
-        hz_dirty = true;
-        __syncthreads();
-        t_s5 += wall_clock64() - t_b;
-    }
-    __syncthreads();
-    if (tid < nR) L.spAssign[tid] = S.starColOfRow[tid];
-    L.spS[tid] = S.Scol[tid];
-    if (tid == 0) {
-        L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
-        L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
-        L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
-        L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);
-        L.hdr[58] = n_bat; L.hdr[59] = n_seq;                             // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
-    }
-    if (!post_fused || a.user || status != 0) return;
-    // ================= fused after-the-fact check (see the header): every entry OUTSIDE the lists must satisfy
-    //     (c[i][j] - rowmin_i) - S_j > margin.
-    // Outside entries cost at least lc_i (the row's last candidate) and S_j <= Smax, so a row with (lc_i - rowmin_i) - Smax > margin
-    // is done without looking at any column (rounding is monotone: the bound holds for the float64 expressions themselves).  Otherwise
-    // only columns with cost <= rowmin_i + Smax + margin can fail: same-class boxes within that radius (grid query; the radius carries
-    // a whole pixel = 7.8e-4 cost units of slack), cross-class ones (cost >= 1) only if the radius reaches 1 -- then every column is examined.
-    const long long t_post = wall_clock64();
-    __syncthreads();                                                   // every read of the transposed lists lies behind us
-    SpPost& P = *reinterpret_cast<SpPost*>(S.tl);
-    const bool big = grid_build(P.grid, a, nR, nC, rowsTrk, S.wave_tot);
-    {
-        const double m = wave_min_f64_dpp(tid < nC ? -S.Scol[tid] : 0.0);
-        if (lane == 0) P.red[wave] = -m;
-    }
-    __syncthreads();
-    double Smax = P.red[0];
-    for (int w = 1; w < MK_THREADS / 64; w++) Smax = fmax(Smax, P.red[w]);
-    const double margin = 1e-9 * (1.0 + L.dhdr[3]);                    // as mk_postcheck_kernel
-    bool pviol = false;
-    if (r < nR && myc[SPK - 1] != 0xFFFF) {                            // (a row with fewer than LAP_K columns has every entry in its list)
-        const int lj = myc[SPK - 1];
-        const double rmin = L.ccost[(size_t)r * SPK], lc = L.ccost[(size_t)r * SPK + SPK - 1];
-        if (!((lc - rmin) - Smax > margin)) {
-            const bbox_t rb = rowsTrk ? a.trk[r] : a.det[r];
-            auto examine = [&](int j, double cst) {
-                const bool outside = cst > lc || (cst == lc && j > lj);
-                if (outside && !(cst - rmin - S.Scol[j] > margin)) pviol = true;
-            };
-            const double reach = rmin + Smax + margin;
-            if (big || !(reach < 0.99)) {
-                for (int j = 0; j < nC; j++) { const bbox_t cb = rowsTrk ? a.det[j] : a.trk[j]; examine(j, rowsTrk ? pair_cost(rb, cb) : pair_cost(cb, rb)); }
-            } else {
-                const int Ri = (int)(reach * (double)MOT_FRAME_W) + 2;
-                grid_query(P.grid, (rb.l + rb.r) >> 1, (rb.t + rb.b) >> 1, rb.type, Ri, [&](int j, int d2) { examine(j, cost_of_d2(d2, false)); });
-            }
-        }
-    }
-    const int spviol = __syncthreads_or(pviol) ? 1 : 0;
-    if (tid == 0) { L.hdr[LAP_H_SPVIOL] = spviol; L.hdr[57] = (int)(wall_clock64() - t_post); }
-    if (spviol || !life.enabled) return;
-    // accepted and in the device loop: commit the frame here (td.cpp:472-644); the final kernel only does its bookkeeping
-    if (tid < nR) a.ws.assignment[tid] = S.starColOfRow[tid];
-    __threadfence_block();
-    __syncthreads();
-    dl_lifecycle_body(life.S, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, P.life);
-    if (tid == 0) L.hdr[LAP_H_DONE] = 1;
+    mk_sparse_run<false>(a, mk_batch, post_fused, life, sp_raw);
 }
 
 // every entry outside the candidate lists against the final S_j (see the header); grid of 64 x 64 tiles

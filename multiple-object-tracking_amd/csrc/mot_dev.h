@@ -128,6 +128,8 @@ enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 
        LAP_H_DENSE = 6,       // lap_dense_kernel ran in this launch (the sparse solver gave up / its prices failed the dense check): the dual check runs again
        LAP_H_DONE = 7,        // the frame is decided AND committed: a kernel of this launch chain has already run the lifecycle step (device loop) --
                               // every later kernel of the chain returns at once; re-armed by the final kernel
+       LAP_H_VERDICT = 9,     // two-workgroup solver launch: 0 pending, 1 certified (the solver's workgroup decides and commits), 2 not certified (the
+                              // speculative sparse emulation of the second workgroup is wanted); agent-scope release / acquire; re-armed by the final kernel
        LAP_H_CERT = 8,        // 1 + the certificate's outcome when the solver's own workgroup already evaluated it (fused dual check, lap_kernels.hip); 0: not yet
        LAP_H_DSTAT = 42,      // [42..44] dense solver of the most recent launch: settled columns, free rows after the greedy start, device time (10 ns);
                               // [45] launches in which it ran, [46] ... and were then certified (cumulative)
