@@ -203,6 +203,13 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     return MOT_OK;
 }
 
+int split_early_max()
+{
+    static int early_max = -1;
+    if (early_max < 0) { const char* ev = getenv("MOT_SPLIT_EARLY_MAX"); early_max = ev ? atoi(ev) : MOT_SPLIT_EARLY_MAX; }
+    return early_max;
+}
+
 int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, const void* dets_dev = nullptr, int nD = 0)
 {
     RoctxRange range_("mot.frame.predict");
@@ -222,10 +229,12 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
     if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
     d->feat_early = false;
-    static int early_max = -1;
-    if (early_max < 0) { const char* ev = getenv("MOT_SPLIT_EARLY_MAX"); early_max = ev ? atoi(ev) : MOT_SPLIT_EARLY_MAX; }
+    const int early_max = split_early_max();
     d->feat_joined = false;
-    const bool early = d->split && !d->have_cur && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && S.spr + nD <= early_max;
+    // workgroups that will actually WORK in a joined / early launch: this rank's share of the tracks (every segment holds cap slots since the
+    // ownership tid % world drifts, but a rank owns about cap / world of them; the surplus workgroups of the grid return at once) + detections
+    const int own_est = (S.cap + S.world - 1) / S.world;
+    const bool early = d->split && !d->have_cur && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && own_est + nD <= early_max;
     // the blend prologue of this predict reads the previous frame's spectra: behind the side-stream launch that wrote them
     if (d->split && d->defer && d->spec_side[d->buf_prev]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_prev], 0));
     static int joined_on = -1;
@@ -246,7 +255,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
                 // detector output): in-order execution makes this event subsume the previous frame's update (ev_upd) as well
                 HIPCHK(hipEventRecord(d->ev_in, c->stream));
                 HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
-                HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, S.spr + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
+                HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, own_est + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
                 HIPCHK(hipEventRecord(d->ev_spec[d->buf_cur], d->side)); d->spec_side[d->buf_cur] = true;
                 d->feat_early = true;
             }
@@ -273,7 +282,9 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const bool split = d->split && S.kind == MOT_TRACKER_KCF && nD > 0;
     float2* spec_cur = d->det_spec.p + (size_t)d->buf_cur * d->spec_stride;
     const bool feat_here = split && !d->feat_early && !d->have_cur;     // this frame's detection features still have to be computed (side stream, beside the chain)
-    const bool ahead = d->split && S.kind == MOT_TRACKER_KCF && d->next_frame && d->next_dets && d->next_nD > 0 && d->next_nD <= S.max_dets;
+    // (small frames are better off with the joined predict + feature launch of their own frame than with a side-stream launch ahead)
+    const bool ahead = d->split && S.kind == MOT_TRACKER_KCF && d->next_frame && d->next_dets && d->next_nD > 0 && d->next_nD <= S.max_dets &&
+                       (S.cap + S.world - 1) / S.world + d->next_nD > split_early_max();
     // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
     LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
     HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (feat_here || ahead) ? d->ev_mid : nullptr, &life));
