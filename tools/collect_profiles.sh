@@ -13,6 +13,7 @@ python bench.py --tracks 256 --miss-pct 4 --fp-pct 3 --nms --steps 100 --warmup 
 python bench.py --tracks 1000 --miss-pct 4 --fp-pct 3 --nms --steps 20 --warmup 5 --steady 0 --profile-frames 10 --no-cpu-baseline --h2d 0 > $O/bench_n1000_detector_noise.json 2>/dev/null
 MOT_LOOKAHEAD=0 python bench.py --no-cpu-baseline --h2d 0 > $O/bench_n1024_no_lookahead.json 2>/dev/null
 MOT_DEFER_BLEND=0 MOT_LOOKAHEAD=0 python bench.py --no-cpu-baseline --h2d 0 > $O/bench_n1024_no_deferred_blend.json 2>/dev/null
+MOT_SPLIT_UPDATE=0 python bench.py --no-cpu-baseline --h2d 0 > $O/bench_n1024_fused_update.json 2>/dev/null
 python tools/kcf_probe.py --frames 8 > $O/kcf_probe_n1024.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_default -- python3 bench.py --no-cpu-baseline --h2d 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_driver -- python3 bench.py --steps 20 --warmup 5 --steady 0 --h2d 0 --profile-frames 0 --no-cpu-baseline > /dev/null 2>&1
