@@ -75,3 +75,30 @@ def test_committed_bench_line_keeps_the_contract():
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert abs(j["value"] - j["config"]["live_tracks_end"] * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) / j["value"] < 1e-6
+
+
+def test_round3_traffic_derivation_and_bench_line():
+    prof = os.path.join(ROOT, "profiles")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "derive_traffic.py"),
+                          os.path.join(prof, "r03_pmc_fetch_size.csv"), os.path.join(prof, "r03_pmc_write_size.csv"), "1024"],
+                         capture_output=True, text=True, check=True)
+    tj = json.loads(out.stdout)
+    assert tj == json.load(open(os.path.join(prof, "r03_traffic.json"))) and tj["deferred_blend"] is True
+    bench = _load(os.path.join(ROOT, "bench.py"), "bench_mod3")
+    ab = bench.alg_bytes(80)
+    alg_predict = 1024 * (ab["predict"] + ab["update"] - 80 * 80 * 3)   # predict launch incl. the deferred model update: 185,592 B per track
+    assert alg_predict == 1024 * 185592
+    assert 1.0 <= tj["kcf_predict_bytes_per_launch_n1024"] / alg_predict < 1.30
+    for name in ("r03_bench_n1024.json", "r03_bench_n1024_driver_style.json"):
+        j = json.loads(open(os.path.join(prof, name)).read().strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline", "cpu_baseline", "steady_state", "latency_bound", "h2d_inclusive", "parity_checked"):
+            assert key in j, (name, key)
+        r = j["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert r["alg_bytes_per_launch"] == alg_predict and r["traffic_source"] and r["traffic"] is not None
+        assert j["parity_checked"]["ok"] is True and j["parity_checked"]["equal_to"] == {"port": True, "reference": True}
+        assert j["h2d_inclusive"]["h2d"] == "included" and 0 < j["h2d_inclusive"]["value"] <= j["steady_state"]["value"] * 1.05
+        d = j["cpu_baseline"]["dropin"]
+        assert d["tracker_predict_us"] > 0 and d["reference_tracker_predict_us"] > 0
+        assert abs(j["value"] - j["config"]["live_tracks_end"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
