@@ -911,6 +911,11 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     // Deferred blend: tracker_update of the PREVIOUS frame (kcf.cpp:441-453: kf, alpha, model lerp) for this track, from the spectrum
     // its adopted detection box got in that frame's feature launch -- the same arithmetic, in the same order, as the blend launch it
     // replaces (kcf_update_body, blend-only path); pure HBM streaming that overlaps the feature phases of the neighbouring workgroups.
+    const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
+    const bool pre = kLds && p.nbins <= nt;                            // HBM-slab templates never prefetch (frees the registers for the DFTs)
+    const int bpre = min(tid, p.nbins - 1);
+    float2 xmr[MOT_HALF0]; float alr = 0.f;                            // 16 planes at a time (register budget for 2 workgroups / CU)
+    bool have_model = false;
     if (l.pend_det) {
         const int dj = l.pend_det[slot];
         if (dj >= 0) {
@@ -919,15 +924,41 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
             float2* xmw = p.xm + (size_t)slot * tot;
             const int first = p.first_update[slot];
             const float factor = first ? 1.0f : p.eta, keep = 1.0f - factor;       // kcf.cpp:443
-            for (int b = tid; b < p.nbins; b += nt) {                   // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
-                float kf = 0.f;
-                for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
-                const float kq = kf * p.norm;
-                const float a = p.yf_re[b] / (kq + p.lambda);
-                const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
-                p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
+            int i_lo = 0;                                               // first element the streaming blend below still has to do
+            if (pre) {
+                // one thread per bin: the first 16 planes are blended in registers and STAY there for this frame's correlation
+                // (no re-read of what was just written), kf runs over all 31 planes in channel order, alpha is blended in place
+                if (tid < p.nbins) {
+                    float2 sp[MOT_HALF0];
+#pragma unroll
+                    for (int ch = 0; ch < MOT_HALF0; ch++) { sp[ch] = dspec[ch * p.nbins + tid]; xmr[ch] = first ? make_float2(0.f, 0.f) : xmw[ch * p.nbins + tid]; }
+                    const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + tid];
+                    float kf = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < MOT_HALF0; ch++) {
+                        const float2 a = sp[ch]; kf = (a.x * a.x + a.y * a.y) + kf;
+                        float2 m = xmr[ch]; m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
+                        xmr[ch] = m; xmw[ch * p.nbins + tid] = m;
+                    }
+#pragma unroll
+                    for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + tid]; kf = (a.x * a.x + a.y * a.y) + kf; }
+                    const float kq = kf * p.norm;
+                    const float a = p.yf_re[tid] / (kq + p.lambda);
+                    alr = keep * old + factor * a;
+                    p.alpha[(size_t)slot * p.nbins + tid] = alr;
+                }
+                i_lo = MOT_HALF0 * p.nbins; have_model = true;
+            } else {
+                for (int b = tid; b < p.nbins; b += nt) {               // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
+                    float kf = 0.f;
+                    for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
+                    const float kq = kf * p.norm;
+                    const float a = p.yf_re[b] / (kq + p.lambda);
+                    const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
+                    p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
+                }
             }
-            for (int i0 = 0; i0 < tot; i0 += 8 * nt) {                  // kcf_update_xf (kcf.cpp:380-395): 16 loads in flight per thread
+            for (int i0 = i_lo; i0 < tot; i0 += 8 * nt) {               // kcf_update_xf (kcf.cpp:380-395): 16 loads in flight per thread
                 float2 a8[8], m8[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) { const int i = min(i0 + tid + j * nt, tot - 1); a8[j] = dspec[i]; m8[j] = first ? make_float2(0.f, 0.f) : xmw[i]; }
@@ -943,11 +974,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     }
     // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
     // they land while the features are computed
-    const float2* xm = p.xm + (size_t)slot * MOT_NCHAN * p.nbins;
-    const bool pre = kLds && p.nbins <= nt;                            // HBM-slab templates never prefetch (frees the registers for the DFTs)
-    const int bpre = min(tid, p.nbins - 1);
-    float2 xmr[MOT_HALF0]; float alr = 0.f;                            // 16 planes at a time (register budget for 2 workgroups / CU)
-    if (pre) {
+    if (pre && !have_model) {
 #pragma unroll
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
