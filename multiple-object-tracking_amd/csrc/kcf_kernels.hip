@@ -898,7 +898,7 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
     else if (spectrum) fft_forward<SLAB>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
 }
 
-template <bool kLds>
+template <bool kLds, bool kStagger = false>
 __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
@@ -916,70 +916,96 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     const int bpre = min(tid, p.nbins - 1);
     float2 xmr[MOT_HALF0]; float alr = 0.f;                            // 16 planes at a time (register budget for 2 workgroups / CU)
     bool have_model = false;
-    if (l.pend_det) {
-        const int dj = l.pend_det[slot];
-        if (dj >= 0) {
-            const int tot = MOT_NCHAN * p.nbins;
-            const float2* dspec = l.pend_spec + (size_t)dj * tot;
-            float2* xmw = p.xm + (size_t)slot * tot;
-            const int first = p.first_update[slot];
-            const float factor = first ? 1.0f : p.eta, keep = 1.0f - factor;       // kcf.cpp:443
-            int i_lo = 0;                                               // first element the streaming blend below still has to do
-            if (pre) {
-                // one thread per bin: the first 16 planes are blended in registers and STAY there for this frame's correlation
-                // (no re-read of what was just written), kf runs over all 31 planes in channel order, alpha is blended in place
-                if (tid < p.nbins) {
-                    float2 sp[MOT_HALF0];
+    const int dj = l.pend_det ? l.pend_det[slot] : -1;
+    // Workgroups i and i + 256 of a launch share a compute unit (dispatch order on the 8 x 32 CUs): the second of the pair does its
+    // blend AFTER the feature phases, so the model streaming of one overlaps the arithmetic of the other instead of all 512 resident
+    // workgroups hitting HBM in the launch's first microseconds
+    const bool late = kStagger && pre && dj >= 0 && ((blockIdx.x >> 8) & 1);
+    auto blend = [&]() {
+        const int tot = MOT_NCHAN * p.nbins;
+        const float2* dspec = l.pend_spec + (size_t)dj * tot;
+        float2* xmw = p.xm + (size_t)slot * tot;
+        const int first = p.first_update[slot];
+        const float factor = first ? 1.0f : p.eta, keep = 1.0f - factor;       // kcf.cpp:443
+        int i_lo = 0;                                               // first element the streaming blend below still has to do
+        if (pre) {
+            // one thread per bin: the first 16 planes are blended in registers and STAY there for this frame's correlation
+            // (no re-read of what was just written); the waves that own no bins stream planes 16..30 at the same time and hand
+            // |S|^2 of those planes over in LDS, so kf still adds up in channel order (kcf.cpp:269-304) and every HBM load of the
+            // blend is in flight at once -- one memory latency instead of three
+            const int wbins = (p.nbins + 63) & ~63, ns = nt - wbins;
+            const int half_lo = MOT_HALF0 * p.nbins, nhi = tot - half_lo;
+            const bool split = ns >= 128 && nhi <= MOT_HALF0 * ns;
+            float* sq = r.B;                                            // free here: before the crop, or between the norm and the channels
+            float kf = 0.f, old = 0.f;
+            // both roles run the same 16-element code on the same registers: element j of a bin thread is plane j of its bin, element
+            // j of a streaming thread is the j-th of its strided share of planes 16..30
+            const bool binthr = tid < p.nbins, strthr = split && tid >= wbins;
+            const int ebase = binthr ? tid : half_lo + (tid - wbins), estride = binthr ? p.nbins : ns;
+            const int elim = binthr ? half_lo : (strthr ? tot : 0);
+            float2 sp[MOT_HALF0];
 #pragma unroll
-                    for (int ch = 0; ch < MOT_HALF0; ch++) { sp[ch] = dspec[ch * p.nbins + tid]; xmr[ch] = first ? make_float2(0.f, 0.f) : xmw[ch * p.nbins + tid]; }
-                    const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + tid];
-                    float kf = 0.f;
+            for (int j = 0; j < MOT_HALF0; j++) {
+                const int i = min(ebase + j * estride, tot - 1);
+                sp[j] = dspec[i]; xmr[j] = first ? make_float2(0.f, 0.f) : xmw[i];
+            }
+            if (binthr) old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + tid];
 #pragma unroll
-                    for (int ch = 0; ch < MOT_HALF0; ch++) {
-                        const float2 a = sp[ch]; kf = (a.x * a.x + a.y * a.y) + kf;
-                        float2 m = xmr[ch]; m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y;
-                        xmr[ch] = m; xmw[ch * p.nbins + tid] = m;
-                    }
+            for (int j = 0; j < MOT_HALF0; j++) {
+                const int i = ebase + j * estride;
+                const float2 a = sp[j]; const float e2 = a.x * a.x + a.y * a.y;
+                float2 m = xmr[j]; m.x = keep * m.x + factor * a.x; m.y = keep * m.y + factor * a.y; xmr[j] = m;
+                if (i < elim) xmw[i] = m;
+                if (binthr) kf = e2 + kf; else if (i < elim) sq[i - half_lo] = e2;
+            }
+            if (split) __syncthreads();
+            if (tid < p.nbins) {
+                if (split) {
+#pragma unroll
+                    for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) kf = sq[(ch - MOT_HALF0) * p.nbins + tid] + kf;
+                } else {
 #pragma unroll
                     for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + tid]; kf = (a.x * a.x + a.y * a.y) + kf; }
-                    const float kq = kf * p.norm;
-                    const float a = p.yf_re[tid] / (kq + p.lambda);
-                    alr = keep * old + factor * a;
-                    p.alpha[(size_t)slot * p.nbins + tid] = alr;
                 }
-                i_lo = MOT_HALF0 * p.nbins; have_model = true;
-            } else {
-                for (int b = tid; b < p.nbins; b += nt) {               // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
-                    float kf = 0.f;
-                    for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
-                    const float kq = kf * p.norm;
-                    const float a = p.yf_re[b] / (kq + p.lambda);
-                    const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
-                    p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
-                }
+                const float kq = kf * p.norm;
+                const float a = p.yf_re[tid] / (kq + p.lambda);
+                alr = keep * old + factor * a;
+                p.alpha[(size_t)slot * p.nbins + tid] = alr;
             }
-            for (int i0 = i_lo; i0 < tot; i0 += 8 * nt) {               // kcf_update_xf (kcf.cpp:380-395): 16 loads in flight per thread
-                float2 a8[8], m8[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) { const int i = min(i0 + tid + j * nt, tot - 1); a8[j] = dspec[i]; m8[j] = first ? make_float2(0.f, 0.f) : xmw[i]; }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int i = i0 + tid + j * nt;
-                    if (i < tot) { float2 m = m8[j]; m.x = keep * m.x + factor * a8[j].x; m.y = keep * m.y + factor * a8[j].y; xmw[i] = m; }
-                }
+            i_lo = split ? tot : half_lo; have_model = true;
+        } else {
+            for (int b = tid; b < p.nbins; b += nt) {               // kcf_linear_correlation_kf + kcf_update_alpha (kcf.cpp:269-304, 364-378)
+                float kf = 0.f;
+                for (int ch = 0; ch < MOT_NCHAN; ch++) { const float2 a = dspec[ch * p.nbins + b]; kf = (a.x * a.x + a.y * a.y) + kf; }
+                const float kq = kf * p.norm;
+                const float a = p.yf_re[b] / (kq + p.lambda);
+                const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
+                p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
             }
-            __syncthreads();                                           // the blended model is visible to the whole workgroup (loads below)
-            if (tid == 0) { l.pend_det[slot] = -1; p.first_update[slot] = 0; }
         }
-    }
+        for (int i0 = i_lo; i0 < tot; i0 += 8 * nt) {               // kcf_update_xf (kcf.cpp:380-395): 16 loads in flight per thread
+            float2 a8[8], m8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int i = min(i0 + tid + j * nt, tot - 1); a8[j] = dspec[i]; m8[j] = first ? make_float2(0.f, 0.f) : xmw[i]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + tid + j * nt;
+                if (i < tot) { float2 m = m8[j]; m.x = keep * m.x + factor * a8[j].x; m.y = keep * m.y + factor * a8[j].y; xmw[i] = m; }
+            }
+        }
+        __syncthreads();                                           // the blended model is visible to the whole workgroup (loads below)
+        if (tid == 0) { l.pend_det[slot] = -1; p.first_update[slot] = 0; }
+    };
+    if (dj >= 0 && !late) blend();
     // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
     // they land while the features are computed
-    if (pre && !have_model) {
+    if (pre && !have_model && !late) {
 #pragma unroll
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
     features_prepare<!kLds>(p, l, item, pos, r, tid, nt, stage);
+    if (late) blend();
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -1058,7 +1084,7 @@ __global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB,
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    kcf_predict_body<kLds>(p, l, item, smem);
+    kcf_predict_body<kLds, kLds>(p, l, item, smem);
 }
 // size classes (device loop with per-track template sizes, kcf.cpp:148-152): the workgroup's pool descriptor comes from a device
 // table, indexed by the class of its track
