@@ -452,7 +452,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "alg_bytes_per_launch": per_launch, "avg_launch_ms": cands[dom][0],
-                               "note": "stage time between HIP events on the launch stream incl. the dispatch gap"}
+                               "note": "time between two HIP events recorded on the launch stream directly around the kernel launch (incl. the dispatch gap)"}
             other = [k for k in cands if k != dom][0]
             ob = cands[other][1] * n_live
             out["roofline_other"] = {"bound": "hbm", "kernel": other, "achieved": ob / (cands[other][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

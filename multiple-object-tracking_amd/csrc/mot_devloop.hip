@@ -227,7 +227,6 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     float2* spec_cur = d->det_spec.p + (size_t)d->buf_cur * d->spec_stride;            // this frame's detection spectra
     const float2* spec_prev = d->det_spec.p + (size_t)d->buf_prev * d->spec_stride;     // ... the previous frame's
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
-    if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
     d->feat_early = false;
     const int early_max = split_early_max();
     d->feat_joined = false;
@@ -237,6 +236,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     const bool early = d->split && !d->have_cur && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && own_est + nD <= early_max;
     // the blend prologue of this predict reads the previous frame's spectra: behind the side-stream launch that wrote them
     if (d->split && d->defer && d->spec_side[d->buf_prev]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_prev], 0));
+    if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));                  // profiling: the events bracket the predict launch itself, behind the stream's wait
     static int joined_on = -1;
     if (joined_on < 0) { const char* ev = getenv("MOT_JOINED_LAUNCH"); joined_on = (ev && atoi(ev) == 0) ? 0 : 1; }
     if (S.kind == MOT_TRACKER_KCF) {

@@ -26,7 +26,7 @@ def _dev(frames, dets, mot):
     return fd, dd, da
 
 
-@pytest.mark.parametrize("kind,n,size,nframes", [(0, 48, 80, 9), (1, 16, 80, 40), (0, 20, 64, 6)])
+@pytest.mark.parametrize("kind,n,size,nframes", [(0, 48, 80, 9), (1, 16, 80, 40), (0, 20, 64, 6), (0, 20, 96, 5)])
 def test_device_loop_vs_oracle(mot, oracle, kind, n, size, nframes):
     from multiple_object_tracking_amd import synth
     scene = synth.Scene(n, size, stream_id=21 + kind, miss_pct=8, fp_pct=4)
@@ -44,18 +44,18 @@ def test_device_loop_vs_oracle(mot, oracle, kind, n, size, nframes):
     m.close(); c.close()
 
 
-@pytest.mark.parametrize("n,nframes,miss,fp", [(600, 7, 4, 3), (1024, 7, 4, 3), (1024, 9, 0, 0)])
-def test_device_loop_large_vs_oracle(mot, oracle, n, nframes, miss, fp):
+@pytest.mark.parametrize("n,nframes,miss,fp,size", [(600, 7, 4, 3, 80), (1024, 7, 4, 3, 80), (1024, 9, 0, 0, 80), (400, 5, 3, 2, 64)])
+def test_device_loop_large_vs_oracle(mot, oracle, n, nframes, miss, fp, size):
     """the BENCHED configuration against the oracle: assignment fast path (certificate), sparse order-exact emulation, dense
     emulation as the last resort, lifecycle tail and split update.  With misses and false positives tracks die and spawn every
     frame (td.cpp:585-644) and a false positive's partner is a far-away free track: the candidate lists cannot decide those
     frames and the dense emulation runs; without them (the bench stream itself) the first two always suffice."""
     from multiple_object_tracking_amd import synth
-    scene = synth.Scene(n, 80, stream_id=5 if miss else 0, miss_pct=miss, fp_pct=fp)
+    scene = synth.Scene(n, size, stream_id=5 if miss else 0, miss_pct=miss, fp_pct=fp)
     items = list(scene.frames(nframes))
     frames = [f for f, _ in items]; dets = [d[:1024] for _, d in items]
     fd, dd, da = _dev(frames, dets, mot)
-    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    c = mot.MotContext(max_tracks=1024, max_dets=1024, dev_size=size)   # (64 px: the predict launch's paired workgroups and its blend split at a second template size)
     m = orc.OracleMot(oracle, 0, 0, 1024)
     used = set()
     for f in range(nframes):
