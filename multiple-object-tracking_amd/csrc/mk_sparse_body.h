@@ -104,7 +104,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     if (tid < MK_MAXW * 2) S.dirty32[tid] = 0;
     __syncthreads();
     double dv[SPK]; unsigned short myc[SPK];
-    unsigned zm = 0, vk = 0;                                           // zero / present bits of the row's candidates
+    unsigned zm = 0;                                                   // zero bits of the row's candidates
 #pragma unroll
     for (int k = 0; k < SPK; k++) { dv[k] = DBL_MAX; myc[k] = 0xFFFF; }
     if (r < nR) {
@@ -112,7 +112,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
             myc[k] = L.ccol[(size_t)r * SPK + k];
-            if (myc[k] != 0xFFFF) { vk |= 1u << k; dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
+            if (myc[k] != 0xFFFF) { dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
         }
     }
 #pragma unroll
@@ -439,15 +439,22 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         const bool rc = bit_of(S.covR, r);
         bool unc[SPK];
         double h = DBL_MAX;
+        {
+            // the eight cover words are loaded together (one LDS round trip, no per-candidate predication: an absent candidate names
+            // column 1023's word and its value DBL_MAX makes the answer irrelevant -- DBL_MAX +/- h == DBL_MAX); the minimum is a chain
+            // of v_min_f64 (no NaNs here; the sign of a zero minimum cannot matter: h > 0 whenever step 5 runs)
+            unsigned cw8[SPK];
 #pragma unroll
-        for (int k = 0; k < SPK; k++) {
-            const int cc = myc[k] & (MK_MAXN - 1);                     // (0xFFFF -> a valid index; masked out by vk)
-            unc[k] = ((vk >> k) & 1) && !((covC32[cc >> 5] >> (cc & 31)) & 1u);
-            const double cand_v = (!rc && unc[k]) ? dv[k] : DBL_MAX;
-            h = cand_v < h ? cand_v : h;
+            for (int k = 0; k < SPK; k++) cw8[k] = covC32[(myc[k] & (MK_MAXN - 1)) >> 5];
+#pragma unroll
+            for (int k = 0; k < SPK; k++) {
+                unc[k] = !((cw8[k] >> (myc[k] & 31)) & 1u);
+                const double cand_v = (!rc && unc[k]) ? dv[k] : DBL_MAX;
+                h = vmin_f64(cand_v, h);
+            }
         }
         {
-            const u64 hk = wave_min_u64_dpp(dkey(h));
+            const u64 hk = dkey(wave_min_f64_pos(h));
             if (lane == 0) atomicMin(&S.hkey, hk);
         }
         __syncthreads();
