@@ -52,6 +52,9 @@ __device__ __forceinline__ void lds_clear_bit64(u64* words, int i) { atomicAnd(r
 // the run polls L.hdr[LAP_H_VERDICT] (0 pending, 1 certified: the solver's workgroup decides and commits the frame, 2 not certified: this
 // run's result is wanted) once per step-5 cycle, gives up as soon as it reads 1, and publishes nothing before it has read 2.
 __device__ __forceinline__ int sp_verdict(const LapWs& L) { return __hip_atomic_load(&L.hdr[LAP_H_VERDICT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// the in-loop look: only the word's value matters there (nothing the partner wrote is read on its strength -- the run ends by
+// sp_wait_verdict's acquire load before it publishes anything), so no cache invalidate and no wait at the load
+__device__ __forceinline__ int sp_verdict_peek(const LapWs& L) { return __hip_atomic_load(&L.hdr[LAP_H_VERDICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // workgroup-uniform: waits until the solver's workgroup has published its verdict; false = certified there (this run is discarded)
 __device__ inline bool sp_wait_verdict(const LapWs& L, int* flag)
@@ -239,12 +242,13 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     int nstar = ncov;                                                  // starred columns: + 1 per augmentation
     bool hz_dirty = false;                                             // step 5 changed the masks: wave 0 rebuilds hzr / hzAllr
     int status = 0;
+    int vseen = 0;                                                     // (wavefront 0, speculative run) the verdict word as last seen
     while (!done) {
         const long long t_a = wall_clock64();
         // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
         if (wave == 0) {
             // (speculative run) this cycle's look at the verdict word: the load is issued here and consumed at the end of the event phase
-            const int vnow = SPEC ? sp_verdict(L) : 0;                  // (a second look every 8 events inside long phases was measured: -1.5 % overall)
+            const int vnow = (SPEC && vseen != 2) ? sp_verdict_peek(L) : vseen;   // once the result is wanted the word is final: no more looks   (a second look every 8 events inside long phases was measured: -1.5 % overall)
             int action = 0; bool found = false;
             unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
             if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
@@ -422,6 +426,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                 }
             }
             covC32[l5] = cC;
+            if (SPEC) vseen = vnow;
             if (lane == 0) { S.flag[1] = action; S.hkey = ~0ull; if (SPEC) S.flag[6] = vnow; }
         }
         __syncthreads();
