@@ -780,7 +780,7 @@ int mot_get_lap_stats(mot_ctx* c, int* out32)
     if (!c || !out32) return fail(MOT_ERR_ARG, "null argument");
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out32, c->assoc.lap.hdr + LAP_H_LAST, sizeof(int) * 32, hipMemcpyDeviceToHost));
-    if (getenv("MOT_LAP_DEBUG")) { int dbg[12]; HIPCHK(hipMemcpy(dbg, c->assoc.lap.hdr + 48, sizeof dbg, hipMemcpyDeviceToHost)); fprintf(stderr, "sparse event loop: %d batch iterations, %d one-event iterations\n", dbg[10], dbg[11]); fprintf(stderr, "lap debug ticks: sparse setup %d (certificate %d, lists %d) | solve init %d search %d commit %d final %d\n", dbg[0], dbg[5], dbg[6], dbg[1], dbg[2], dbg[3], dbg[4]); }
+    if (getenv("MOT_LAP_DEBUG")) { int dbg[12]; HIPCHK(hipMemcpy(dbg, c->assoc.lap.hdr + 48, sizeof dbg, hipMemcpyDeviceToHost)); fprintf(stderr, "sparse event loop: %d batch iterations, %d one-event iterations\n", dbg[10], dbg[11]); fprintf(stderr, "lap debug ticks: sparse setup %d (certificate %d, lists %d) post-check + lifecycle %d | solve init %d search %d commit %d final %d tail: check %d, to done %d\n", dbg[0], dbg[5], dbg[6], dbg[9], dbg[1], dbg[2], dbg[3], dbg[4], dbg[7], dbg[8]); }
     return MOT_OK;
 }
 
