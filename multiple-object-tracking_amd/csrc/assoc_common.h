@@ -27,6 +27,8 @@ typedef unsigned long long u64;
 //   BMOUT     [column][row word][2]: new zero bits of an uncovered column as two granules; a column's 32 granules are
 //             staged in LDS and written by one store instruction (256 contiguous bytes), not as 32 scalar writes
 //   COVBITS   [column word][i-th covered row][2]: zero bits of (covered row) x (64 covered columns), two granules
+//   COVSUM    [g]: how many of helper g's COVBITS rows hold a zero at all (normally none: such an entry just grew by h > 0); the
+//             controller reads the COVBITS granules only if some count is not 0
 // A granule is an aligned 8-byte word written by ONE store and carrying its own tag, so none of these hand-offs needs
 // a separate flag, an arrival counter or a store drain (guide: R2 granule, "needs no ordering at all"); the re-armed
 // words are drained by the controller one step before they are used again.
@@ -37,6 +39,7 @@ typedef unsigned long long u64;
 #define CTL_COV 64                     /* 64 granules */
 #define CTL_PARTIAL 128                /* [2][16] words, each on a 128-byte line of its own (16 writers) */
 #define MK_PARTIAL_STRIDE 16
+#define CTL_COVSUM 640                 /* [16] granules {zeros among (covered rows) x (helper g's covered columns) after the step, tag}, one 128-byte line each */
 #define CTL_COVBITS 1024               /* [16 column words][1024 rows][2]: a helper's granules are contiguous */
 #define CTL_BMOUT (1024 + 2 * 16384)   /* [1024 cols][16 row words][2] */
 #define MK_CTL_WORDS (1024 + 4 * 16384)

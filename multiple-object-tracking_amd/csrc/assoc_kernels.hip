@@ -153,7 +153,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             const u64 um = ~readlane64(cv, MK_MAXW + g) & validC;        // my uncovered columns
             if ((um >> lane) & 1) S.list[__popcll(um & ((1ull << lane) - 1))] = (unsigned short)(cbase + lane);
             if (lane == 0) {
-                S.flag[3] = state; S.flag[2] = __popcll(um);
+                S.flag[3] = state; S.flag[2] = __popcll(um); S.flag[6] = 0;
                 if (step == 1 && state == 0) { const u64 md = ctl_ld(ctl + CTL_MODE); S.flag[5] = ((unsigned)(md >> 32) == epoch + 1) ? (int)(md & 1) : 0; }
             }
         }
@@ -174,15 +174,8 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
 #pragma unroll
             for (int k = 0; k < 8; k++) if (k < nmine) v[k] = d[rclamp + (size_t)nR * (unsigned)__builtin_amdgcn_readfirstlane((int)S.list[k])];   // uniform guard
         }
-        // wave 1 (wave 0 is the poller): the first 4 covered rows of my covered columns, needed after h only
-        double x2[4]; int rr2[4] = {0, 0, 0, 0};
-        if (uwave == 1 && part2) {
-            wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);   // covered rows, ascending (== ncr entries)
-#pragma unroll
-            for (int q = 0; q < 4; q++) rr2[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(q, ncr - 1)]);
-#pragma unroll
-            for (int q = 0; q < 4; q++) x2[q] = d[(size_t)rr2[q] + coff];
-        }
+        // wave 1 (wave 0 is the poller): the covered rows, ascending, for the update of my covered columns (read behind the barrier below)
+        if (uwave == 1 && part2) wave_list_bits((lane < MK_MAXW) ? S.covR[lane] : 0, 0, S.clist, lane);   // (== ncr entries)
         if (nmine > 0) {
 #pragma unroll
             for (int k = 0; k < 8; k++) if (mine && k < nmine) { const u64 kk = dkey(v[k]); if (kk < best) best = kk; }
@@ -223,38 +216,32 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
         if (S.flag[3]) return;
         const double h = __longlong_as_double((long long)S.hbits);
         const u64 tagw = (u64)tag << 32;                                 // every granule carries the tag of its step 5
-        // ---- covered rows of my COVERED columns: += h (:355-358); wave 1, lane = column ----
-        if (uwave == 1 && part2) {
+        // ---- covered rows of my COVERED columns: += h (:355-358); lane = column, the rows are dealt eight at a time to the 16 waves
+        // (eight independent loads in flight per lane).  Such an entry was >= -rounding noise and h > 0, so it is NOT a zero afterwards
+        // -- except in a pathological rounding case, which is counted: the controller clears the bits of these entries itself when every
+        // helper reports a count of 0 (CTL_COVSUM) and reads the per-row granules (CTL_COVBITS, written as before) only otherwise ----
+        if (part2) {
             const bool act = cbase + lane < nC && ((S.covC[g] >> lane) & 1);
-            {
-                u64 bl[4];
+            int exc = 0;
+            for (int i0 = uwave * 8; i0 < ncr; i0 += 8 * (MK_THREADS / 64)) {
+                int rr[8]; double x[8];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const double x = x2[q] + h;
-                    if (act && q < ncr) d[(size_t)rr2[q] + coff] = x;
-                    bl[q] = __ballot(act && fabs(x) < DBL_EPSILON);
-                }
-                // 8 granules (4 rows x 2 halves), contiguous, one store instruction
-                const int q = (lane >> 1) & 3;
-                const u64 bq = q == 0 ? bl[0] : q == 1 ? bl[1] : q == 2 ? bl[2] : bl[3];
-                if (lane < 2 * min(ncr, 4)) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + q) * 2 + (lane & 1), ((lane & 1) ? bq >> 32 : bq & 0xFFFFFFFFull) | tagw, fast);
-            }
-            for (int i0 = 4; i0 < ncr; i0 += 4) {                       // more covered rows: 4 at a time
-                int rr[4]; double x[4];
+                for (int q = 0; q < 8; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
 #pragma unroll
-                for (int q = 0; q < 4; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
+                for (int q = 0; q < 8; q++) x[q] = d[(size_t)rr[q] + coff];
 #pragma unroll
-                for (int q = 0; q < 4; q++) x[q] = d[(size_t)rr[q] + coff];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 8; q++) {
                     if (i0 + q < ncr) {
                         x[q] += h;
                         if (act) d[(size_t)rr[q] + coff] = x[q];
                         const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
+                        exc += bal != 0;
                         if (lane < 2) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
                     }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's granules have landed before the summary (below, behind a barrier) can
+            if (exc && lane == 0) atomicAdd(&S.flag[6], exc);
         }
         // ---- phase B (:355-364) on my uncovered columns; the ballots are staged in LDS (the helpers do not use the zero
         // bitmap) and each column's 32 granules leave as ONE 256-byte store ----
@@ -269,6 +256,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             }
         }
         __syncthreads();
+        if (part2 && tid == 0) ctl_stx(ctl + CTL_COVSUM + g * MK_PARTIAL_STRIDE, tagw | (u64)(unsigned)S.flag[6], fast);   // every wave's covered-row granules are out
         if (uwave < min(nmine, 8) && lane < 2 * MK_MAXW) {
             const int c = S.list[uwave];
             const u64 bal = S.bm[uwave * MK_MAXW + (lane >> 1)];
@@ -557,6 +545,10 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     // cover masks live in wave 0's registers: lane w (<16) holds word w of covC / hz / phaseUnc, lane l holds
     // word (l & 15) of covR (replicated over the four 16-lane quarters); LDS mirrors serve the other waves
     u64 cC = (lane < MK_MAXW) ? S.covC[lane] : 0, cR16 = 0, phaseUnc = 0, hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
+    // hzl: columns that may hold a zero in an UNCOVERED row.  Within a phase rows only get covered and zero bits change in step 5 only,
+    // so a column the sweep has found empty stays empty until the next step 5 / augmentation: its bit is dropped and later events of
+    // the cycle do not test it again (a crowded noisy frame uncovers hundreds of star columns per phase, each a candidate otherwise)
+    u64 hzl = hz;
     const u64 vC = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
     bool covRany = false;
     int guard = 0;
@@ -591,13 +583,13 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                     if (col < 0) { action = 2; break; }
                     const u64 mw = (lane < wordsR) ? S.bm[col * MK_MAXW + lane] : 0;
                     row = wave_first_bit(mw, lane, wordsR);
-                    if (row < 0) { if (lane == (col >> 6)) hz &= ~(1ull << (col & 63)); continue; }   // stale hint
+                    if (row < 0) { if (lane == (col >> 6)) { hz &= ~(1ull << (col & 63)); hzl &= ~(1ull << (col & 63)); } continue; }   // stale hint
                 } else {
                     // general sweep: candidate columns (uncovered, >= from, may hold a zero) in ascending order, four per
                     // LDS read: quarter q of the wave tests column c_q against the uncovered rows
                     const int q = lane >> 4, wd = lane & 15;
                     const int fw = from >> 6;
-                    u64 cand = (lane < MK_MAXW) ? (~cC & vC & (hz | phaseUnc)) : 0;   // hz is a superset of "has a zero"
+                    u64 cand = (lane < MK_MAXW) ? (~cC & vC & hzl) : 0;   // hzl is a superset of "has a zero in an uncovered row"
                     if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
                     for (;;) {
                         int cs[4];
@@ -611,6 +603,9 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                         u64 m = 0;
                         if (myc >= 0 && wd < wordsR) m = S.bm[myc * MK_MAXW + wd] & ~cR16;
                         const u64 bal = __ballot(m != 0);
+#pragma unroll
+                        for (int j = 0; j < 4; j++)                   // a tested column without a live zero leaves the candidates of this cycle
+                            if (cs[j] >= 0 && ((bal >> (16 * j)) & 0xFFFFull) == 0 && lane == (cs[j] >> 6)) hzl &= ~(1ull << (cs[j] & 63));
                         if (bal) {
                             const int fl = __ffsll((long long)bal) - 1;   // lowest quarter = lowest column, lowest word = lowest row
                             const int qq = fl >> 4;
@@ -652,6 +647,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                     // phase kept a star, and the last column of the path just received its first one
                     cC |= phaseUnc; if (last >= 0 && lane == (last >> 6)) cC |= 1ull << (last & 63);
                     phaseUnc = 0;
+                    hzl = hz;                                         // every row is uncovered again; the uncovered columns are never-starred ones (hz is exact for them)
                     if (lane < MK_MAXW) { S.covR[lane] = 0; S.covC[lane] = cC; }
                     int total = 0;
                     for (int w = 0; w < wordsC; w++) total += __popcll(readlane64(cC, w));
@@ -662,7 +658,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 if ((lane & 15) == (row >> 6)) cR16 |= 1ull << (row & 63);                       // :270
                 covRany = true;
                 if (lane < MK_MAXW) {
-                    if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); }   // :271
+                    if (lane == (sc >> 6)) { cC &= ~(1ull << (sc & 63)); phaseUnc |= 1ull << (sc & 63); hzl |= 1ull << (sc & 63); }   // :271 (its zeros are unknown: a candidate)
                     S.covR[lane] = cR16; S.covC[lane] = cC;
                 }
                 found_in_sweep = true;
@@ -719,66 +715,97 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 const unsigned tag = epoch + myseq;
                 const bool ccol = ncr > 0 && tid < nC && ((S.covC[wave] >> lane) & 1);
                 const bool wcov = __ballot(ccol) != 0;                  // this wave's column word holds covered columns
-                // one round covers 64 uncovered columns (two granule slots per thread: a column's 32 granules are
-                // contiguous, so a wave instruction reads two whole columns = 4 lines) and 4 covered rows
-                const int rounds = max(max((ncu + 63) / 64, (ncr + 3) / 4), 1);
+                // BMOUT: one round covers 64 uncovered columns (two granule slots per thread: a column's 32 granules are contiguous, so a
+                // wave instruction reads two whole columns = 4 lines).  COVBITS (only when a helper reports a zero there): 4 covered rows a round
                 bool lostB = false;
-                for (int rd = 0; rd < rounds && !lostB; rd++) {
-                    int bk[2]; bool hb[2]; const u64* bp[2]; u64 bv[2] = {0, 0};
+                auto merge_rounds = [&](const int rounds, const bool with_bm, const bool with_cov) {
+                    for (int rd = 0; rd < rounds && !lostB; rd++) {
+                        int bk[2]; bool hb[2]; const u64* bp[2]; u64 bv[2] = {0, 0};
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int gi = (rd * 2 + j) * MK_THREADS + tid;
-                        bk[j] = gi >> 5;
-                        hb[j] = bk[j] < ncu && ((gi & 31) >> 1) < wordsR;
-                        bp[j] = ctl + CTL_BMOUT + (size_t)S.list[min(bk[j], ncu - 1)] * MK_MAXW * 2 + (gi & 31);
-                    }
-                    const int nrow = min(ncr - rd * 4, 4);              // covered rows of this round (may be <= 0)
-                    const bool hc = wcov && lane < 2 * nrow;
-                    const u64* cp = ctl + CTL_COVBITS + ((size_t)wave * MK_MAXN + rd * 4) * 2 + lane;
-                    u64 cvv = 0;
-                    bool mylost = false;
-                    for (int spins = 0;; ) {                            // every wave polls its own granules at its own pace
-                        bool ok = true;
-                        if (hb[0]) bv[0] = ctl_ld(bp[0]);
-                        if (hb[1]) bv[1] = ctl_ld(bp[1]);
-                        if (hc) cvv = ctl_ld(cp);
-                        if (hb[0]) ok &= (unsigned)(bv[0] >> 32) == tag;
-                        if (hb[1]) ok &= (unsigned)(bv[1] >> 32) == tag;
-                        if (hc) ok &= (unsigned)(cvv >> 32) == tag;
-                        if (!__ballot(!ok)) break;
-                        if (++spins > MK_SPIN_LIMIT) { mylost = true; break; }
-                    }
-                    lostB = __syncthreads_or(mylost);
-                    if (lostB) break;
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const u64 hi = __shfl_down(bv[j], 1);           // lane pairs: even lane = low half, odd lane = high half
-                        const u64 word = (bv[j] & 0xFFFFFFFFull) | (hi << 32);
-                        const bool mineW = hb[j] && !(lane & 1);
-                        if (mineW) {
+                        for (int j = 0; j < 2; j++) {
                             const int gi = (rd * 2 + j) * MK_THREADS + tid;
-                            S.bm[S.list[bk[j]] * MK_MAXW + ((gi & 31) >> 1)] = word;
+                            bk[j] = gi >> 5;
+                            hb[j] = with_bm && bk[j] < ncu && ((gi & 31) >> 1) < wordsR;
+                            bp[j] = ctl + CTL_BMOUT + (size_t)S.list[min(bk[j], ncu - 1)] * MK_MAXW * 2 + (gi & 31);
                         }
-                        // hz ("the column may hold a zero") of the two columns this wave instruction covers: exact again
-                        const u64 nzb = __ballot(mineW && word != 0);
-                        if ((lane & 31) == 0 && hb[j]) {
-                            const int c = S.list[bk[j]];
-                            unsigned int* wp = reinterpret_cast<unsigned int*>(&S.hz[c >> 6]) + ((c & 63) >> 5);
-                            const unsigned int bit = 1u << (c & 31);
-                            if ((lane ? nzb >> 32 : nzb & 0xFFFFFFFFull) != 0) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
+                        const int nrow = with_cov ? min(ncr - rd * 4, 4) : 0;   // covered rows of this round (may be <= 0)
+                        const bool hc = wcov && lane < 2 * nrow;
+                        const u64* cp = ctl + CTL_COVBITS + ((size_t)wave * MK_MAXN + rd * 4) * 2 + lane;
+                        u64 cvv = 0;
+                        bool mylost = false;
+                        for (int spins = 0;; ) {                            // every wave polls its own granules at its own pace
+                            bool ok = true;
+                            if (hb[0]) bv[0] = ctl_ld(bp[0]);
+                            if (hb[1]) bv[1] = ctl_ld(bp[1]);
+                            if (hc) cvv = ctl_ld(cp);
+                            if (hb[0]) ok &= (unsigned)(bv[0] >> 32) == tag;
+                            if (hb[1]) ok &= (unsigned)(bv[1] >> 32) == tag;
+                            if (hc) ok &= (unsigned)(cvv >> 32) == tag;
+                            if (!__ballot(!ok)) break;
+                            if (++spins > MK_SPIN_LIMIT) { mylost = true; break; }
                         }
-                    }
-                    if (wcov && nrow > 0) {
+                        lostB = __syncthreads_or(mylost);
+                        if (lostB) break;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const u64 lo = readlane64(cvv, 2 * q), hi2 = readlane64(cvv, 2 * q + 1);
-                            if (q < nrow && ccol) {
-                                const int rr = S.clist[rd * 4 + q];
-                                const bool z = (((lane < 32) ? lo : hi2) >> (lane & 31)) & 1;
-                                u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
-                                wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                        for (int j = 0; j < 2; j++) {
+                            const u64 hi = __shfl_down(bv[j], 1);           // lane pairs: even lane = low half, odd lane = high half
+                            const u64 word = (bv[j] & 0xFFFFFFFFull) | (hi << 32);
+                            const bool mineW = hb[j] && !(lane & 1);
+                            if (mineW) {
+                                const int gi = (rd * 2 + j) * MK_THREADS + tid;
+                                S.bm[S.list[bk[j]] * MK_MAXW + ((gi & 31) >> 1)] = word;
+                            }
+                            // hz ("the column may hold a zero") of the two columns this wave instruction covers: exact again
+                            const u64 nzb = __ballot(mineW && word != 0);
+                            if ((lane & 31) == 0 && hb[j]) {
+                                const int c = S.list[bk[j]];
+                                unsigned int* wp = reinterpret_cast<unsigned int*>(&S.hz[c >> 6]) + ((c & 63) >> 5);
+                                const unsigned int bit = 1u << (c & 31);
+                                if ((lane ? nzb >> 32 : nzb & 0xFFFFFFFFull) != 0) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
                             }
                         }
+                        if (wcov && nrow > 0) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const u64 lo = readlane64(cvv, 2 * q), hi2 = readlane64(cvv, 2 * q + 1);
+                                if (q < nrow && ccol) {
+                                    const int rr = S.clist[rd * 4 + q];
+                                    const bool z = (((lane < 32) ? lo : hi2) >> (lane & 31)) & 1;
+                                    u64& wd = S.bm[tid * MK_MAXW + (rr >> 6)];
+                                    wd = z ? (wd | (1ull << (rr & 63))) : (wd & ~(1ull << (rr & 63)));
+                                }
+                            }
+                        }
+                    }
+                };
+                merge_rounds(max((ncu + 63) / 64, 1), true, false);
+                // (covered rows) x (covered columns): every helper that owns covered columns reports how many of its rows still hold a zero
+                // there after + h.  Normally none does: those bits are cleared right here, no granule is read
+                if (!lostB && ncr > 0) {
+                    if (uwave == 0) {
+                        const bool need = lane < nhelp && lane < wordsC;
+                        const u64 cw = (lane < MK_MAXW) ? S.covC[lane] : 0;
+                        const u64 vw = (lane < wordsC) ? ((lane == wordsC - 1 && (nC & 63)) ? ((1ull << (nC & 63)) - 1) : ~0ull) : 0;
+                        const bool want = need && (cw & vw) != 0;
+                        u64 sv = 0; int spins = 0; bool lost = false;
+                        for (;;) {
+                            if (want) sv = ctl_ld(ctl + CTL_COVSUM + lane * MK_PARTIAL_STRIDE);
+                            if (!__ballot(want && (unsigned)(sv >> 32) != tag)) break;
+                            if (++spins > MK_SPIN_LIMIT) { lost = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const bool exc = __ballot(want && (unsigned)sv != 0) != 0;
+                        if (lane == 0) S.flag[4] = lost ? 2 : (exc ? 1 : 0);
+                    }
+                    __syncthreads();
+                    const int cs = S.flag[4];
+                    if (cs == 2) lostB = true;
+                    else if (cs == 1) merge_rounds((ncr + 3) / 4, false, true);
+                    else {
+                        // thread -> (column, row word) so that a wave touches consecutive LDS words
+                        const int wq = tid & (MK_MAXW - 1);
+                        const u64 crw = S.covR[wq];
+                        if (crw) for (int c = tid >> 4; c < nC; c += MK_THREADS / MK_MAXW) if ((S.covC[c >> 6] >> (c & 63)) & 1) S.bm[c * MK_MAXW + wq] &= ~crw;
                     }
                 }
                 if (lostB) { if (tid == 0) { stat[15] = 2; S.flag[7] = 1; } }
@@ -788,7 +815,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             __syncthreads();
             if (S.flag[7]) break;
             const long long tq3 = wall_clock64();
-            if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;      // updated column by column during the merge
+            if (wave == 0) { hz = (lane < MK_MAXW) ? S.hz[lane] : 0; hzl = hz | phaseUnc; }   // updated column by column during the merge; the new zeros sit in uncovered rows
             t_h3 += wall_clock64() - tq3;
         } else {
             const int ncu = S.flag[1];
@@ -869,7 +896,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 if (lane == 0) S.hz[wave] = (S.hz[wave] & S.covC[wave]) | bal;
             }
             __syncthreads();
-            if (wave == 0) hz = (lane < MK_MAXW) ? S.hz[lane] : 0;
+            if (wave == 0) { hz = (lane < MK_MAXW) ? S.hz[lane] : 0; hzl = hz | phaseUnc; }
         }
         t_s5 += wall_clock64() - t_b;
         if (++guard > 4 * MK_MAXN * MK_MAXN) break;                    // cannot happen for finite costs
