@@ -101,6 +101,7 @@ struct MkShared {
     unsigned short clist[MK_MAXN];  // init: contested lines, ascending
     unsigned short crosscnt[MK_MAXN];
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW];
+    u64 hzl[MK_MAXW];               // after a step 5: uncovered columns that hold a zero in an UNCOVERED row (exact)
     unsigned int taken32[2 * MK_MAXW], cont32[2 * MK_MAXW];
     double red[MK_THREADS / 64];
     u64 hbits;
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     int n_s4 = 0, n_s5 = 0, n_sw = 0, n_cov5 = 0, ncu0 = 0; long long t_s3 = 0, t_s5 = 0, t_h0 = 0, t_h1 = 0, t_h2 = 0, t_h3 = 0;     // wave-0 / thread-0 statistics
 
     for (int i = tid; i < MK_MAXN; i += MK_THREADS) { S.starColOfRow[i] = -1; S.starRowOfCol[i] = -1; S.primeColOfRow[i] = -1; }
-    if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
+    if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; S.hzl[tid] = 0; }
     if (tid == 0) S.flag[7] = 0;
     if (tid < 2 * MK_MAXW) { S.taken32[tid] = 0; S.cont32[tid] = 0; }
     if (certified) {                                                   // the unique optimum: nothing to emulate
@@ -757,11 +758,15 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                             }
                             // hz ("the column may hold a zero") of the two columns this wave instruction covers: exact again
                             const u64 nzb = __ballot(mineW && word != 0);
+                            // ... and whether one of its zeros sits in an uncovered row (the event loop's candidate mask)
+                            const u64 nzl = __ballot(mineW && (word & ~S.covR[((((rd * 2 + j) * MK_THREADS + tid) & 31) >> 1) & (MK_MAXW - 1)]) != 0);
                             if ((lane & 31) == 0 && hb[j]) {
                                 const int c = S.list[bk[j]];
                                 unsigned int* wp = reinterpret_cast<unsigned int*>(&S.hz[c >> 6]) + ((c & 63) >> 5);
+                                unsigned int* wl = reinterpret_cast<unsigned int*>(&S.hzl[c >> 6]) + ((c & 63) >> 5);
                                 const unsigned int bit = 1u << (c & 31);
                                 if ((lane ? nzb >> 32 : nzb & 0xFFFFFFFFull) != 0) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
+                                if ((lane ? nzl >> 32 : nzl & 0xFFFFFFFFull) != 0) atomicOr(wl, bit); else atomicAnd(wl, ~bit);
                             }
                         }
                         if (wcov && nrow > 0) {
@@ -815,7 +820,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             __syncthreads();
             if (S.flag[7]) break;
             const long long tq3 = wall_clock64();
-            if (wave == 0) { hz = (lane < MK_MAXW) ? S.hz[lane] : 0; hzl = hz | phaseUnc; }   // updated column by column during the merge; the new zeros sit in uncovered rows
+            if (wave == 0) { hz = (lane < MK_MAXW) ? S.hz[lane] : 0; hzl = (lane < MK_MAXW) ? S.hzl[lane] : 0; }   // updated column by column during the merge (every uncovered column is in it)
             t_h3 += wall_clock64() - tq3;
         } else {
             const int ncu = S.flag[1];
@@ -890,13 +895,13 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             t_h3 += wall_clock64() - tb0;
             {   // rebuild hz for the uncovered columns (their entries just changed)
                 const bool unc = tid < nC && !((S.covC[wave] >> lane) & 1);
-                bool has = false;
-                if (unc) for (int w = 0; w < wordsR; w++) has |= S.bm[tid * MK_MAXW + w] != 0;
-                const u64 bal = __ballot(has);
-                if (lane == 0) S.hz[wave] = (S.hz[wave] & S.covC[wave]) | bal;
+                bool has = false, hasl = false;
+                if (unc) for (int w = 0; w < wordsR; w++) { const u64 bw = S.bm[tid * MK_MAXW + w]; has |= bw != 0; hasl |= (bw & ~S.covR[w]) != 0; }
+                const u64 bal = __ballot(has), ball = __ballot(hasl);
+                if (lane == 0) { S.hz[wave] = (S.hz[wave] & S.covC[wave]) | bal; S.hzl[wave] = ball; }
             }
             __syncthreads();
-            if (wave == 0) { hz = (lane < MK_MAXW) ? S.hz[lane] : 0; hzl = hz | phaseUnc; }
+            if (wave == 0) { hz = (lane < MK_MAXW) ? S.hz[lane] : 0; hzl = (lane < MK_MAXW) ? S.hzl[lane] : 0; }
         }
         t_s5 += wall_clock64() - t_b;
         if (++guard > 4 * MK_MAXN * MK_MAXN) break;                    // cannot happen for finite costs
