@@ -217,33 +217,6 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
         if (S.flag[3]) return;
         const double h = __longlong_as_double((long long)S.hbits);
         const u64 tagw = (u64)tag << 32;                                 // every granule carries the tag of its step 5
-        // ---- covered rows of my COVERED columns: += h (:355-358); lane = column, the rows are dealt eight at a time to the 16 waves
-        // (eight independent loads in flight per lane).  Such an entry was >= -rounding noise and h > 0, so it is NOT a zero afterwards
-        // -- except in a pathological rounding case, which is counted: the controller clears the bits of these entries itself when every
-        // helper reports a count of 0 (CTL_COVSUM) and reads the per-row granules (CTL_COVBITS, written as before) only otherwise ----
-        if (part2) {
-            const bool act = cbase + lane < nC && ((S.covC[g] >> lane) & 1);
-            int exc = 0;
-            for (int i0 = uwave * 8; i0 < ncr; i0 += 8 * (MK_THREADS / 64)) {
-                int rr[8]; double x[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
-#pragma unroll
-                for (int q = 0; q < 8; q++) x[q] = d[(size_t)rr[q] + coff];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    if (i0 + q < ncr) {
-                        x[q] += h;
-                        if (act) d[(size_t)rr[q] + coff] = x[q];
-                        const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
-                        exc += bal != 0;
-                        if (lane < 2) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's granules have landed before the summary (below, behind a barrier) can
-            if (exc && lane == 0) atomicAdd(&S.flag[6], exc);
-        }
         // ---- phase B (:355-364) on my uncovered columns; the ballots are staged in LDS (the helpers do not use the zero
         // bitmap) and each column's 32 granules leave as ONE 256-byte store ----
 #pragma unroll
@@ -257,7 +230,6 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             }
         }
         __syncthreads();
-        if (part2 && tid == 0) ctl_stx(ctl + CTL_COVSUM + g * MK_PARTIAL_STRIDE, tagw | (u64)(unsigned)S.flag[6], fast);   // every wave's covered-row granules are out
         if (uwave < min(nmine, 8) && lane < 2 * MK_MAXW) {
             const int c = S.list[uwave];
             const u64 bal = S.bm[uwave * MK_MAXW + (lane >> 1)];
@@ -285,7 +257,36 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
                 ctl_stx(ctl + CTL_BMOUT + (size_t)c * MK_MAXW * 2 + lane, ((lane & 1) ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
             }
         }
+        // (behind phase B: the controller merges the uncovered columns' words while this runs)
+        // ---- covered rows of my COVERED columns: += h (:355-358); lane = column, the rows are dealt eight at a time to the 16 waves
+        // (eight independent loads in flight per lane).  Such an entry was >= -rounding noise and h > 0, so it is NOT a zero afterwards
+        // -- except in a pathological rounding case, which is counted: the controller clears the bits of these entries itself when every
+        // helper reports a count of 0 (CTL_COVSUM) and reads the per-row granules (CTL_COVBITS, written as before) only otherwise ----
+        if (part2) {
+            const bool act = cbase + lane < nC && ((S.covC[g] >> lane) & 1);
+            int exc = 0;
+            for (int i0 = uwave * 8; i0 < ncr; i0 += 8 * (MK_THREADS / 64)) {
+                int rr[8]; double x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = d[(size_t)rr[q] + coff];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if (i0 + q < ncr) {
+                        x[q] += h;
+                        if (act) d[(size_t)rr[q] + coff] = x[q];
+                        const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
+                        exc += bal != 0;
+                        if (lane < 2) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's granules have landed before the summary (below, behind a barrier) can
+            if (exc && lane == 0) atomicAdd(&S.flag[6], exc);
+        }
         __syncthreads();                                               // S.list / S.covR are rewritten by wave 0 for the next step
+        if (part2 && tid == 0) ctl_stx(ctl + CTL_COVSUM + g * MK_PARTIAL_STRIDE, tagw | (u64)(unsigned)S.flag[6], fast);   // every wave's covered-row granules are out
     }
 }
 
