@@ -118,7 +118,8 @@ struct MkShared {
 // All spins are executed by wave 0 as a whole on a wave-uniform (scalar) condition and are bounded: a spin loop
 // confined to one LANE is a divergent loop, and the structuriser may run the other lanes of that wave (and with them
 // the workgroup barrier behind the spin) ahead of it -- seen on gfx950: the barrier released before lane 0 had polled.
-__device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
+// force_cov (test hook, MOT_MUNKRES_HELPERS=2): every summary reports a zero, so the controller takes the per-row granule path
+__device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC, int force_cov)
 {
     u64* ctl = a.ws.ctl;
     double* __restrict__ d = a.ws.dist;
@@ -286,7 +287,7 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC)
             if (exc && lane == 0) atomicAdd(&S.flag[6], exc);
         }
         __syncthreads();                                               // S.list / S.covR are rewritten by wave 0 for the next step
-        if (part2 && tid == 0) ctl_stx(ctl + CTL_COVSUM + g * MK_PARTIAL_STRIDE, tagw | (u64)(unsigned)S.flag[6], fast);   // every wave's covered-row granules are out
+        if (part2 && tid == 0) ctl_stx(ctl + CTL_COVSUM + g * MK_PARTIAL_STRIDE, tagw | (u64)(unsigned)(S.flag[6] + force_cov), fast);   // every wave's covered-row granules are out
     }
 }
 
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     // an earlier kernel of the chain (the solver's fused tail / the sparse emulation) has already decided AND committed this frame
     // (lifecycle step included): bookkeeping only.  (The live count, and with it nR / nC, already belong to the next frame.)
     const bool committed = lap_mode && a.ws.lap.hdr[LAP_H_DONE] != 0;
-    if (HELP && blockIdx.x > 0) { if (blockIdx.x % MK_XCDS == 0 && nR > 0 && nC > 0 && !committed) mk_helper_loop(a, S, nR, nC); return; }
+    if (HELP && blockIdx.x > 0) { if (blockIdx.x % MK_XCDS == 0 && nR > 0 && nC > 0 && !committed) mk_helper_loop(a, S, nR, nC, (want_cost >> 3) & 1); return; }
     if (committed) {
         const int mode = a.ws.lap.hdr[LAP_H_MODE];
         __syncthreads();
@@ -1050,14 +1051,15 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // step 5 moves a lot of data: dense hard problems beyond ~512 lines.  MOT_MUNKRES_HELPERS=1 forces them on for
     // every problem above 256 lines, =0 off; default: above MK_HELP_MIN lines.
     static int helpers = -1;
-    if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; }
+    static int force_cov = 0;                                          // MOT_MUNKRES_HELPERS=2: forced on AND the controller reads the per-row COVBITS granules (test hook)
+    if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; force_cov = (ev && atoi(ev) == 2) ? 1 : 0; }
     // behind the fast path the dense emulation is the rare last resort: one workgroup, not the 1 + 128 workgroup helper grid
     // (whose launch alone costs more than the common case's whole final kernel)
     // ... unless the stream keeps needing it (detector misses + false positives force far matches no tier can certify): the final
     // kernel leaves a hint in pinned host memory, read here without synchronisation (stale by a frame or two: it only picks the grid)
     const bool hinted = hinted_now;                                    // (a noisy stream: the countdown above is armed)
     const bool big = !prep_in_kernel && ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
-    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, want_cost, life, lap ? 1 : 0);
+    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (force_cov << 3), life, lap ? 1 : 0);
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0) | (prep_in_kernel ? 4 : 0), life, lap ? 1 : 0);
     return hipGetLastError();
 }

@@ -493,10 +493,12 @@ def _run_variant(env_extra):
     return eval(out.stdout.split("LAP")[-1].strip())
 
 
-@pytest.mark.parametrize("helpers", ["0", "1"])
+@pytest.mark.parametrize("helpers", ["0", "1", "2"])
 def test_munkres_helper_workgroups_subprocess(helpers):
     """step-5 helper workgroups (munkres_kernel<true>, 1 + 16 workgroups, cross-CU control block) forced on for every
-    problem above 256 lines ("1") and forced off ("0"): identical assignments and cost either way."""
+    problem above 256 lines ("1") and forced off ("0"): identical assignments and cost either way.  "2": on, and every helper reports
+    a zero among its (covered row, covered column) entries, so the controller merges the per-row COVBITS granules instead of clearing
+    those bits itself -- the path a pathological rounding case would take."""
     _run_variant({"MOT_MUNKRES_HELPERS": helpers})
 
 
