@@ -1005,12 +1005,25 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             if (dense_mode < 0) { const char* ev = getenv("MOT_LAP_DENSE"); dense_mode = ev ? (atoi(ev) ? 1 : 0) : 2; }
             bool want_dense = dense_mode == 1;
             if (dense_mode == 2 && ws.dense_hint) {
-                volatile int* h = ws.dense_hint;                       // [0] device-written hint bits, [1] host-side countdown, [2] last nD
+                volatile int* h = ws.dense_hint;                       // [0] device-written hint bits, [1] host-side countdown, [2] last nD,
+                                                                       // [3] change-armed launches in a row that did not need it, [4] launches a count change is ignored for, [5] back-off level, [6] hold armed by a count change
                 // a detection count that changes from frame to frame is what detector noise looks like from the host: arm the dense
-                // solver at once, so that the first noisy frame of a stream does not have to go through the emulation
-                if ((h[0] & 2) || (h[2] > 0 && nD > 0 && h[2] != nD)) h[1] = 512; else if (h[1] > 0) h[1] = h[1] - 1;
+                // solver at once, so that the first noisy frame of a stream does not have to go through the emulation -- but only for a
+                // few launches, and with an exponential back-off when the device keeps reporting that nobody needed it (objects entering
+                // and leaving change the count on a clean stream too; round-2 advisor finding).  A launch that DID need it arms 512.
+                const bool changed = h[2] > 0 && nD > 0 && h[2] != nD;
+                if (h[0] & 2) { h[1] = 512; h[3] = 0; h[4] = 0; h[5] = 0; }   // a recent launch needed it: held for 512 launches, as before
+                else {
+                    if (h[1] > 0) h[1] = h[1] - 1;
+                    if (h[4] > 0) h[4] = h[4] - 1;
+                    else if (changed && h[6] < 8) h[6] = 8;              // [6]: the short hold a count change arms
+                    if (h[6] > 0) {
+                        h[6] = h[6] - 1;
+                        if (h[3] + 1 >= 32) { h[5] = h[5] < 6 ? h[5] + 1 : 6; h[4] = 64 << h[5]; h[3] = 0; h[6] = 0; } else h[3] = h[3] + 1;
+                    }
+                }
                 if (nD > 0) h[2] = nD;
-                want_dense = h[1] > 0;
+                want_dense = h[1] > 0 || h[6] > 0;
             }
             // Box costs without the dense solver in between: the sparse emulation rides in the solver's launch as its second workgroup
             // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
@@ -1025,7 +1038,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             if (!two_block) { e = launch_mk_sparse(a, gR, gC, s, life); if (e != hipSuccess) return e; }
             // working matrix + bitmaps for the dense emulation: chip-wide (lazy: every workgroup checks the verdict and leaves) for caller
             // matrices and for streams whose recent frames needed it; otherwise the final kernel prepares them itself if it has to
-            hinted_now = ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0);
+            hinted_now = ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[6] > 0);
             static int helpers_forced = -1;
             if (helpers_forced < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers_forced = (ev && atoi(ev)) ? 1 : 0; }
             prep_in_kernel = !a.user && !hinted_now && !helpers_forced;

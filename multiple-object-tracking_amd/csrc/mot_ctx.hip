@@ -393,7 +393,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(hipMemset(c->a_status.p, 0, 16 * sizeof(int))); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
-    HIPCHK(c->h_hint.alloc(16)); c->h_hint.p[0] = 0; c->h_hint.p[1] = 0; c->h_hint.p[2] = 0; c->assoc.dense_hint = c->h_hint.p;
+    HIPCHK(c->h_hint.alloc(16)); for (int i = 0; i < 16; i++) c->h_hint.p[i] = 0; c->assoc.dense_hint = c->h_hint.p;
     HIPCHK(c->a_ctl.alloc(MOT_ASSOC_CTL_WORDS)); HIPCHK(hipMemset(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n)); c->assoc.ctl = c->a_ctl.p;
     {   // assignment fast path workspace (lap_kernels.hip): one block, carved here
         size_t off = 0; auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
