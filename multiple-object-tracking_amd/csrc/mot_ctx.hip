@@ -24,27 +24,28 @@ namespace mot_impl {
 int ensure_device(mot_ctx* c) { HIPCHK(hipSetDevice(c->cfg.device)); return MOT_OK; }
 
 namespace {
-struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool tried = false; };
-RoctxApi& roctx_api()
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi& roctx_api()
 {
-    static RoctxApi api;
-    if (!api.tried) {
-        api.tried = true;
+    // initialised once, thread-safe (C++11 function-local static): contexts of several host threads may enqueue at the same time
+    static const RoctxApi api = [] {
+        RoctxApi a;
         const char* ev = getenv("MOT_ROCTX");
         if (ev && atoi(ev) != 0) {
             void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
             if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
             if (h) {
-                api.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
-                api.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
-                if (!api.push || !api.pop) { api.push = nullptr; api.pop = nullptr; }
+                a.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (!a.push || !a.pop) { a.push = nullptr; a.pop = nullptr; }
             }
         }
-    }
+        return a;
+    }();
     return api;
 }
 } // namespace
-RoctxRange::RoctxRange(const char* name) { RoctxApi& a = roctx_api(); on = a.push != nullptr; if (on) a.push(name); }
+RoctxRange::RoctxRange(const char* name) { const RoctxApi& a = roctx_api(); on = a.push != nullptr; if (on) a.push(name); }
 RoctxRange::~RoctxRange() { if (on) roctx_api().pop(); }
 } // namespace mot_impl
 

@@ -382,13 +382,11 @@ namespace {
 typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, void* /* ncclComm_t */, hipStream_t);
 nccl_all_gather_fn rccl_all_gather()
 {
-    static nccl_all_gather_fn fn = nullptr; static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static const nccl_all_gather_fn fn = [] {                           // bound once, thread-safe (function-local static)
         void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (h) fn = reinterpret_cast<nccl_all_gather_fn>(dlsym(h, "ncclAllGather"));
-    }
+        return h ? reinterpret_cast<nccl_all_gather_fn>(dlsym(h, "ncclAllGather")) : nullptr;
+    }();
     return fn;
 }
 } // namespace
