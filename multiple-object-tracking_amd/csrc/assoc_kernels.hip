@@ -101,6 +101,7 @@ struct MkShared {
     unsigned short clist[MK_MAXN];  // init: contested lines, ascending
     unsigned short crosscnt[MK_MAXN];
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW];
+    unsigned char hcols[64];        // helper workgroups: my covered columns (bit positions of my column word), ascending
     u64 hzl[MK_MAXW];               // after a step 5: uncovered columns that hold a zero in an UNCOVERED row (exact)
     unsigned int taken32[2 * MK_MAXW], cont32[2 * MK_MAXW];
     double red[MK_THREADS / 64];
@@ -259,32 +260,59 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC, 
             }
         }
         // (behind phase B: the controller merges the uncovered columns' words while this runs)
-        // ---- covered rows of my COVERED columns: += h (:355-358); lane = column, the rows are dealt eight at a time to the 16 waves
-        // (eight independent loads in flight per lane).  Such an entry was >= -rounding noise and h > 0, so it is NOT a zero afterwards
-        // -- except in a pathological rounding case, which is counted: the controller clears the bits of these entries itself when every
-        // helper reports a count of 0 (CTL_COVSUM) and reads the per-row granules (CTL_COVBITS, written as before) only otherwise ----
+        // ---- covered rows of my COVERED columns: += h (:355-358).  Such an entry was >= -rounding noise and h > 0, so it is NOT a zero
+        // afterwards -- except in a pathological rounding case, which is counted: the controller clears the bits of these entries itself when
+        // every helper reports a count of 0 (CTL_COVSUM) and reads the per-row granules (CTL_COVBITS) only otherwise.  Work item = (one of my
+        // covered columns, 64 consecutive entries of the covered-row list), lane = row: the matrix is column-major, so a wave instruction
+        // touches a few neighbouring lines instead of 64 scattered ones; eight items in flight per wave ----
         if (part2) {
-            const bool act = cbase + lane < nC && ((S.covC[g] >> lane) & 1);
-            int exc = 0;
-            for (int i0 = uwave * 8; i0 < ncr; i0 += 8 * (MK_THREADS / 64)) {
-                int rr[8]; double x[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
-#pragma unroll
-                for (int q = 0; q < 8; q++) x[q] = d[(size_t)rr[q] + coff];
+            const u64 mycov = S.covC[g] & validC;
+            const int ncc = __popcll(mycov);
+            if (uwave == 2 && ((mycov >> lane) & 1)) S.hcols[__popcll(mycov & ((1ull << lane) - 1ull))] = (unsigned char)lane;   // my covered columns, ascending
+            __syncthreads();
+            const int nchunk = (ncr + 63) >> 6, nitem = ncc * nchunk;
+            bool exc = false;
+            for (int t0 = uwave * 8; t0 < nitem; t0 += 8 * (MK_THREADS / 64)) {
+                double x[8]; size_t off[8]; bool ok[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    if (i0 + q < ncr) {
-                        x[q] += h;
-                        if (act) d[(size_t)rr[q] + coff] = x[q];
-                        const u64 bal = __ballot(act && fabs(x[q]) < DBL_EPSILON);
-                        exc += bal != 0;
-                        if (lane < 2) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
-                    }
+                    const int t = min(t0 + q, nitem - 1);
+                    const int ci = t / nchunk, ch = t - ci * nchunk;
+                    const int ri = ch * 64 + lane;
+                    ok[q] = t0 + q < nitem && ri < ncr;
+                    off[q] = (size_t)S.clist[min(ri, ncr - 1)] + (size_t)nR * (unsigned)(cbase + S.hcols[ci]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = d[off[q]];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    x[q] += h;
+                    if (ok[q]) { d[off[q]] = x[q]; exc |= fabs(x[q]) < DBL_EPSILON; }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's granules have landed before the summary (below, behind a barrier) can
-            if (exc && lane == 0) atomicAdd(&S.flag[6], exc);
+            if (__ballot(exc) && lane == 0) atomicAdd(&S.flag[6], 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the updated entries are out before anybody re-reads them below
+            __syncthreads();
+            if (S.flag[6] + force_cov > 0) {
+                // a zero among them (or the test hook): the zero bits of every covered row over my covered columns as tagged granules,
+                // read back from the updated entries (lane = column, as the controller's merge expects them)
+                const bool act = cbase + lane < nC && ((mycov >> lane) & 1);
+                for (int i0 = uwave * 8; i0 < ncr; i0 += 8 * (MK_THREADS / 64)) {
+                    int rr[8]; double y[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) rr[q] = __builtin_amdgcn_readfirstlane((int)S.clist[min(i0 + q, ncr - 1)]);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) y[q] = d[(size_t)rr[q] + coff];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (i0 + q < ncr) {
+                            const u64 bal = __ballot(act && fabs(y[q]) < DBL_EPSILON);
+                            if (lane < 2) ctl_stx(ctl + CTL_COVBITS + ((size_t)g * MK_MAXN + i0 + q) * 2 + lane, (lane ? bal >> 32 : bal & 0xFFFFFFFFull) | tagw, fast);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's granules have landed before the summary (below, behind a barrier) can
+            }
         }
         __syncthreads();                                               // S.list / S.covR are rewritten by wave 0 for the next step
         if (part2 && tid == 0) ctl_stx(ctl + CTL_COVSUM + g * MK_PARTIAL_STRIDE, tagw | (u64)(unsigned)(S.flag[6] + force_cov), fast);   // every wave's covered-row granules are out
