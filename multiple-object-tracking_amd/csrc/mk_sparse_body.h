@@ -235,6 +235,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     // every lane store its word to the LDS copies without a branch.
     unsigned* covR32 = reinterpret_cast<unsigned*>(S.covR); unsigned* covC32 = reinterpret_cast<unsigned*>(S.covC); unsigned* hz32 = reinterpret_cast<unsigned*>(S.hz);
     const bool batch_on = mk_batch != 0;
+    const int bthr = mk_batch > 1 ? mk_batch : 3;                       // candidate columns in front of the sweep that make a batch worth its fixed cost
     const int l5 = lane & 31;
     const unsigned vC = (l5 * 32 + 32 <= nC) ? ~0u : (l5 * 32 >= nC ? 0u : ((1u << (nC & 31)) - 1u));
     unsigned cC = covC32[l5], cR = 0, ph = 0;
@@ -306,14 +307,12 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                 int total = 0;
                 if (batch_on) {
                     const int nw = __popc(cb);
-                    if (nw >= 3) total = 3;
-                    else {
-                        const int w0 = __ffs((int)cb) - 1;
-                        total = __popc((unsigned)__builtin_amdgcn_readlane((int)cand, w0));
-                        if (nw == 2) total += __popc((unsigned)__builtin_amdgcn_readlane((int)cand, 31 - __clz((int)cb)));
+                    if (nw >= bthr) total = bthr;
+                    else {                                             // fewer non-empty words than the threshold: count their candidates
+                        for (unsigned t = cb; t; t &= t - 1) total += __popc((unsigned)__builtin_amdgcn_readlane((int)cand, __ffs((int)t) - 1));
                     }
                 }
-                if (total >= 3) {
+                if (total >= bthr) {
                     n_bat++;
                     // ---------- BATCH: up to 64 consecutive events of this sweep at once (lane = event).  Taken together are the events
                     // of the first f candidate columns such that (1) their first uncovered zero rows are pairwise different, (2) no row but
