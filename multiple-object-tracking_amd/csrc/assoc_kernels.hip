@@ -622,7 +622,19 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                     const int fw = from >> 6;
                     u64 cand = (lane < MK_MAXW) ? (~cC & vC & hzl) : 0;   // hzl is a superset of "has a zero in an uncovered row"
                     if (lane < fw) cand = 0; else if (lane == fw) cand &= ~0ull << (from & 63);
-                    for (;;) {
+                    {   // the first candidate alone (with the exact mask of the last step 5 it is almost always the hit): one LDS read, no
+                        // selection among four columns
+                        const int c0 = wave_first_bit(cand, lane, MK_MAXW);
+                        if (c0 >= 0) {
+                            const u64 m0 = (lane < wordsR) ? (S.bm[c0 * MK_MAXW + lane] & ~cR16) : 0;   // lanes 0..15: cR16 holds word `lane`
+                            const u64 bal0 = __ballot(m0 != 0);
+                            if (bal0) {
+                                const int fl = __ffsll((long long)bal0) - 1;
+                                col = c0; row = fl * 64 + __ffsll((long long)readlane64(m0, fl)) - 1;
+                            } else if (lane == (c0 >> 6)) { cand &= ~(1ull << (c0 & 63)); hzl &= ~(1ull << (c0 & 63)); }
+                        }
+                    }
+                    while (col < 0) {
                         int cs[4];
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
