@@ -243,6 +243,10 @@ int mot_live_response(mot_ctx* ctx, int live_index, float* out, int* f_rows, int
 /* debug: enable / read the per-phase time stamps (100 MHz ticks) of workgroup 0 of the device-loop KCF kernels:
  * [0] start [1] crop [2] gradient [3] histogram [4] norm [5] channels [6] DFT [7] end */
 int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long long* update8);
+/* Host-side scheduling state machine that decides whether a launch also submits the dense LAP solver's kernels (never a result):
+ * one step on a caller-owned int[16] (h[0] bit 1 = "a recent launch needed the dense solver", written by the device in the product);
+ * returns 1 if this launch would submit them.  Pure host code: callable without a GPU (tests/test_abi_symbols.py). */
+int mot_debug_dense_arming(int* h16, int nD);
 /* counters of the most recent Munkres launch: [0] step-4 augmentations [1] step-5 updates [2] step-3 sweeps
  * [3] step-5 passes with covered rows; [4..7] step-5 split in 10 ns ticks (helper workgroups: publish, wait for the
  * minimum, wait for the update, merge; one workgroup: pass 1, reduce, uncovered rows, covered rows); [8..12] device time

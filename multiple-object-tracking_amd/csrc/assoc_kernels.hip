@@ -998,6 +998,28 @@ hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int 
     return hipGetLastError();
 }
 
+// Dense-solver arming (host side, scheduling only -- never a result).  h: [0] device-written hint bits (bit 1: a recent launch needed the
+// dense solver), [1] hold armed by such a launch, [2] last detection count, [3] change-armed launches in a row that did not need it,
+// [4] launches a count change is ignored for, [5] back-off level, [6] hold armed by a count change.  Returns whether this launch submits
+// the dense solver's kernels.
+bool dense_arming_step(volatile int* h, int nD)
+{
+    const bool changed = h[2] > 0 && nD > 0 && h[2] != nD;
+    if (h[0] & 2) { h[1] = 512; h[3] = 0; h[4] = 0; h[5] = 0; }   // a recent launch needed it: held for 512 launches
+    else {
+        if (h[1] > 0) h[1] = h[1] - 1;
+        if (h[4] > 0) h[4] = h[4] - 1;
+        else if (changed && h[6] < 8) h[6] = 8;                  // a count change arms a short hold ...
+        if (h[6] > 0) {
+            h[6] = h[6] - 1;
+            if (h[3] + 1 >= 32) { h[5] = h[5] < 6 ? h[5] + 1 : 6; h[4] = 64 << h[5]; h[3] = 0; h[6] = 0; }   // ... with exponential back-off while nobody needs it
+            else h[3] = h[3] + 1;
+        }
+    }
+    if (nD > 0) h[2] = nD;
+    return h[1] > 0 || h[6] > 0;
+}
+
 hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch);   // lap_kernels.hip
 hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s);                     // lap_dense.hip
 hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, const LifeArgs& life);   // mk_sparse.hip
@@ -1051,19 +1073,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
                 // solver at once, so that the first noisy frame of a stream does not have to go through the emulation -- but only for a
                 // few launches, and with an exponential back-off when the device keeps reporting that nobody needed it (objects entering
                 // and leaving change the count on a clean stream too; round-2 advisor finding).  A launch that DID need it arms 512.
-                const bool changed = h[2] > 0 && nD > 0 && h[2] != nD;
-                if (h[0] & 2) { h[1] = 512; h[3] = 0; h[4] = 0; h[5] = 0; }   // a recent launch needed it: held for 512 launches, as before
-                else {
-                    if (h[1] > 0) h[1] = h[1] - 1;
-                    if (h[4] > 0) h[4] = h[4] - 1;
-                    else if (changed && h[6] < 8) h[6] = 8;              // [6]: the short hold a count change arms
-                    if (h[6] > 0) {
-                        h[6] = h[6] - 1;
-                        if (h[3] + 1 >= 32) { h[5] = h[5] < 6 ? h[5] + 1 : 6; h[4] = 64 << h[5]; h[3] = 0; h[6] = 0; } else h[3] = h[3] + 1;
-                    }
-                }
-                if (nD > 0) h[2] = nD;
-                want_dense = h[1] > 0 || h[6] > 0;
+                want_dense = dense_arming_step(h, nD);
             }
             // Box costs without the dense solver in between: the sparse emulation rides in the solver's launch as its second workgroup
             // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
@@ -1116,3 +1126,6 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0) | (prep_in_kernel ? 4 : 0), life, lap ? 1 : 0);
     return hipGetLastError();
 }
+
+// test hook (pure host code, no device needed): one step of the dense-solver arming state machine on a caller-owned int[16]
+extern "C" int mot_debug_dense_arming(int* h16, int nD) { return (h16 && dense_arming_step(h16, nD)) ? 1 : 0; }

@@ -68,3 +68,25 @@ def test_product_does_not_reference_oracle():
                 assert "mot_oracle" not in txt and "oracle/" not in txt.replace("tools/", ""), f"{f} references the oracle"
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libmot_amd.so")], text=True)
     assert "oracle" not in out
+
+
+def test_dense_solver_arming_state_machine(mot):
+    """host-side scheduling of the dense LAP solver's launches (assoc_kernels.hip: dense_arming_step), no GPU needed: a constant
+    detection count never arms it; a count change arms it for 8 launches; a clean stream whose count keeps changing backs off
+    exponentially; a launch that needed it (device hint bit 1) holds it for 512 launches whatever the back-off says"""
+    import numpy as np
+    lib = mot.load_library()
+    lib.mot_debug_dense_arming.argtypes = [C.c_void_p, C.c_int]
+    lib.mot_debug_dense_arming.restype = C.c_int
+    step = lambda h, nd: lib.mot_debug_dense_arming(h.ctypes.data_as(C.c_void_p), nd)
+    h = np.zeros(16, np.int32)
+    assert all(step(h, 1024) == 0 for _ in range(100))                       # the bench stream
+    assert step(h, 1000) == 1 and sum(step(h, 1000) for _ in range(20)) == 6  # 8 launches (one already taken, one spent by the arming call itself)
+    h[:] = 0
+    armed = [step(h, 900 + (f % 7)) for f in range(4000)]                    # a clean stream whose count changes every frame
+    assert sum(armed[:40]) >= 30 and sum(armed[2000:]) < 0.2 * 2000, (sum(armed[:40]), sum(armed[2000:]))
+    assert h[5] >= 3                                                          # backed off several times
+    h[0] = 2                                                                  # the device reports: the last launch needed the dense solver
+    assert step(h, 905) == 1 and h[1] == 512 and h[4] == 0 and h[5] == 0
+    h[0] = 0
+    assert sum(step(h, 905) for _ in range(600)) == 511                       # held for 512 launches, then released
