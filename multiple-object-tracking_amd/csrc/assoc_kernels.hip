@@ -273,14 +273,14 @@ __device__ void mk_helper_loop(const AssocArgs& a, MkShared& S, int nR, int nC, 
             const int nchunk = (ncr + 63) >> 6, nitem = ncc * nchunk;
             bool exc = false;
             for (int t0 = uwave * 8; t0 < nitem; t0 += 8 * (MK_THREADS / 64)) {
-                double x[8]; size_t off[8]; bool ok[8];
+                double x[8]; unsigned off[8]; bool ok[8];                // (element index < 2^20)
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int t = min(t0 + q, nitem - 1);
                     const int ci = t / nchunk, ch = t - ci * nchunk;
                     const int ri = ch * 64 + lane;
                     ok[q] = t0 + q < nitem && ri < ncr;
-                    off[q] = (size_t)S.clist[min(ri, ncr - 1)] + (size_t)nR * (unsigned)(cbase + S.hcols[ci]);
+                    off[q] = (unsigned)S.clist[min(ri, ncr - 1)] + (unsigned)nR * (unsigned)(cbase + S.hcols[ci]);
                 }
 #pragma unroll
                 for (int q = 0; q < 8; q++) x[q] = d[off[q]];
@@ -758,15 +758,16 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                 const unsigned tag = epoch + myseq;
                 const bool ccol = ncr > 0 && tid < nC && ((S.covC[wave] >> lane) & 1);
                 const bool wcov = __ballot(ccol) != 0;                  // this wave's column word holds covered columns
-                // BMOUT: one round covers 64 uncovered columns (two granule slots per thread: a column's 32 granules are contiguous, so a
+                // BMOUT: one round covers 128 uncovered columns (four granule slots per thread: a column's 32 granules are contiguous, so a
                 // wave instruction reads two whole columns = 4 lines).  COVBITS (only when a helper reports a zero there): 4 covered rows a round
                 bool lostB = false;
+                constexpr int MG = 4;                                  // granule slots per thread and round: 4 x 1024 / 32 = 128 uncovered columns a round
                 auto merge_rounds = [&](const int rounds, const bool with_bm, const bool with_cov) {
                     for (int rd = 0; rd < rounds && !lostB; rd++) {
-                        int bk[2]; bool hb[2]; const u64* bp[2]; u64 bv[2] = {0, 0};
+                        int bk[MG]; bool hb[MG]; const u64* bp[MG]; u64 bv[MG] = {0, 0, 0, 0};
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const int gi = (rd * 2 + j) * MK_THREADS + tid;
+                        for (int j = 0; j < MG; j++) {
+                            const int gi = (rd * MG + j) * MK_THREADS + tid;
                             bk[j] = gi >> 5;
                             hb[j] = with_bm && bk[j] < ncu && ((gi & 31) >> 1) < wordsR;
                             bp[j] = ctl + CTL_BMOUT + (size_t)S.list[min(bk[j], ncu - 1)] * MK_MAXW * 2 + (gi & 31);
@@ -778,11 +779,11 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                         bool mylost = false;
                         for (int spins = 0;; ) {                            // every wave polls its own granules at its own pace
                             bool ok = true;
-                            if (hb[0]) bv[0] = ctl_ld(bp[0]);
-                            if (hb[1]) bv[1] = ctl_ld(bp[1]);
+#pragma unroll
+                            for (int j = 0; j < MG; j++) if (hb[j]) bv[j] = ctl_ld(bp[j]);
                             if (hc) cvv = ctl_ld(cp);
-                            if (hb[0]) ok &= (unsigned)(bv[0] >> 32) == tag;
-                            if (hb[1]) ok &= (unsigned)(bv[1] >> 32) == tag;
+#pragma unroll
+                            for (int j = 0; j < MG; j++) if (hb[j]) ok &= (unsigned)(bv[j] >> 32) == tag;
                             if (hc) ok &= (unsigned)(cvv >> 32) == tag;
                             if (!__ballot(!ok)) break;
                             if (++spins > MK_SPIN_LIMIT) { mylost = true; break; }
@@ -790,18 +791,18 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                         lostB = __syncthreads_or(mylost);
                         if (lostB) break;
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
+                        for (int j = 0; j < MG; j++) {
                             const u64 hi = __shfl_down(bv[j], 1);           // lane pairs: even lane = low half, odd lane = high half
                             const u64 word = (bv[j] & 0xFFFFFFFFull) | (hi << 32);
                             const bool mineW = hb[j] && !(lane & 1);
                             if (mineW) {
-                                const int gi = (rd * 2 + j) * MK_THREADS + tid;
+                                const int gi = (rd * MG + j) * MK_THREADS + tid;
                                 S.bm[S.list[bk[j]] * MK_MAXW + ((gi & 31) >> 1)] = word;
                             }
                             // hz ("the column may hold a zero") of the two columns this wave instruction covers: exact again
                             const u64 nzb = __ballot(mineW && word != 0);
                             // ... and whether one of its zeros sits in an uncovered row (the event loop's candidate mask)
-                            const u64 nzl = __ballot(mineW && (word & ~S.covR[((((rd * 2 + j) * MK_THREADS + tid) & 31) >> 1) & (MK_MAXW - 1)]) != 0);
+                            const u64 nzl = __ballot(mineW && (word & ~S.covR[((((rd * MG + j) * MK_THREADS + tid) & 31) >> 1) & (MK_MAXW - 1)]) != 0);
                             if ((lane & 31) == 0 && hb[j]) {
                                 const int c = S.list[bk[j]];
                                 unsigned int* wp = reinterpret_cast<unsigned int*>(&S.hz[c >> 6]) + ((c & 63) >> 5);
@@ -825,7 +826,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
                         }
                     }
                 };
-                merge_rounds(max((ncu + 63) / 64, 1), true, false);
+                merge_rounds(max((ncu + 32 * MG - 1) / (32 * MG), 1), true, false);
                 // (covered rows) x (covered columns): every helper that owns covered columns reports how many of its rows still hold a zero
                 // there after + h.  Normally none does: those bits are cleared right here, no granule is read
                 if (!lostB && ncr > 0) {
