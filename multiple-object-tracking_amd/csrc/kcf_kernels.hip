@@ -632,6 +632,72 @@ __device__ __attribute__((noinline)) void dft2_mfma(const KcfPool& p, int f_off,
     }
 }
 
+// The same chain with every trip count a compile-time constant (XTL tiles of 16 lines, KSR k-steps of 4 rows): no exec-mask
+// branch around any MFMA, and the 8 * XTL * XTL constant column fragments of a lane are loaded ONCE (from the pool table in
+// global memory: no LDS copy, no barrier) and stay in registers over all passes and channels -- the generic version reads them from LDS
+// again for every (pass, channel), one LDS read per MFMA.  Same products in the same order: bit-identical output.
+template <int XTL, int KSR>
+__device__ __attribute__((noinline)) void dft2_mfma_fixed(const KcfPool& p, int f_off, float* __restrict__ out, int nch, int tid, int nt_)
+{
+    extern __shared__ __attribute__((aligned(16))) float dft2_smem[];
+    const float* __restrict__ F = dft2_smem + f_off;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6, q = lane >> 4, m = lane & 15;
+    const int hb = p.hb, wb = p.wb, ldf = 2 * p.fh, ntl = (ldf + 15) >> 4;
+    float cwr[XTL][XTL][4][2];
+#pragma unroll
+    for (int mt = 0; mt < XTL; mt++)
+#pragma unroll
+        for (int xt = 0; xt < XTL; xt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                cwr[mt][xt][r][0] = p.mf_cols2[(((mt * 3 + xt) * 4 + r) * 2 + 0) * 64 + lane];
+                cwr[mt][xt][r][1] = p.mf_cols2[(((mt * 3 + xt) * 4 + r) * 2 + 1) * 64 + lane];
+            }
+    for (int t = 0; t < ntl; t++) {
+        float bw[KSR];
+#pragma unroll
+        for (int s = 0; s < KSR; s++) bw[s] = p.mf_rows[t * 64 + lane + s * 3 * 64];
+        const int n = t * 16 + m;
+        for (int ch = wave; ch < nch; ch += nw) {
+            const float* Fc = F + ch * wb * ldf;
+            float v[XTL][4], v2[XTL][4];
+#pragma unroll
+            for (int xt = 0; xt < XTL; xt++) {
+                f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+                const int x = xt * 16 + m;
+                const float* in = Fc + min(x, wb - 1) * ldf;
+                float a[KSR];
+#pragma unroll
+                for (int s = 0; s < KSR; s++) { const int k = 4 * s + q; a[s] = in[min(k, hb - 1)]; a[s] = (x < wb && k < hb) ? a[s] : 0.f; }   // all LDS reads of the tile first
+#pragma unroll
+                for (int s = 0; s < KSR; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[xt][r] = acc[r];
+                    const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0xB1, 0xF, 0xF, false));   // lane ^ 1
+                    v2[xt][r] = (n & 1) ? -pv : pv;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < XTL; mt++) {
+                f32x4 o = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int xt = 0; xt < XTL; xt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(cwr[mt][xt][r][0], v[xt][r], o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(cwr[mt][xt][r][1], v2[xt][r], o, 0, 0, 0);
+                    }
+                if (n < ldf) {
+                    float* op = out + (size_t)ch * wb * ldf + n;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int xp = mt * 16 + q * 4 + r; if (xp < wb) op[xp * ldf] = o[r]; }
+                }
+            }
+        }
+    }
+}
+
 // ---- radix 4x5 prime-factor 20-point transforms, one thread per transform ----
 #define C1_5 0.30901699437494742f   /* cos(2pi/5) */
 #define C2_5 (-0.80901699437494742f) /* cos(4pi/5) */
@@ -894,7 +960,12 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
     phase_channels<HALF, SLAB>(p, r.A, r.N, fused ? stage : r.B, fo, l.feat_windowed, tid, nt);
     __syncthreads();
     DBG_STAMP(8 + HALF);
-    if (fused) { dft2_mfma(p, (int)(stage - smem_base()), (int)(stage - smem_base()) + MOT_HALF0 * p.wb * 2 * p.fh, r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt); __syncthreads(); }
+    if (fused) {
+        // 37 x 37 planes (148-px templates, BASELINE configs[4]): the straight-line instance; other HBM-slab sizes: the generic chain
+        if (((p.wb + 15) >> 4) == 3 && ((p.hb + 3) >> 2) == 10) dft2_mfma_fixed<3, 10>(p, (int)(stage - smem_base()), r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt);
+        else dft2_mfma(p, (int)(stage - smem_base()), (int)(stage - smem_base()) + MOT_HALF0 * p.wb * 2 * p.fh, r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt);
+        __syncthreads();
+    }
     else if (spectrum) fft_forward<SLAB>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
 }
 
