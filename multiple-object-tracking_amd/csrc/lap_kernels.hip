@@ -43,50 +43,68 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
         a.ws.lap.hdr[LAP_H_VERDICT] = 0; a.ws.lap.hdr[LAP_H_DONE] = 0; a.ws.lap.hdr[LAP_H_CERT] = 0;
     }
     const int r = blockIdx.x * 4 + wave;
-    if (r >= nR || nC <= 0) return;                                   // wave-uniform
     const LapWs& L = a.ws.lap;
+    // ---- box costs: the workgroup's four rows share one pass over the column boxes -- centroid and class of every column go to
+    // LDS once (coalesced 24-byte reads by all 256 threads; every wavefront used to read all nC boxes itself) ----
+    __shared__ unsigned s_cxy[MK_MAXN];                                // (cx & 0xFFFF) | cy << 16: |centroid| <= 1400 when the box is "small"
+    __shared__ int s_ty[MK_MAXN];
+    bool small = true;
+    if (!a.user) {
+        for (int j = threadIdx.x; j < nC; j += 256) {
+            const bbox_t cb = rowsTrk ? a.det[j] : a.trk[j];
+            small &= box_small(cb);
+            const int cx = (cb.l + cb.r) >> 1, cy = (cb.t + cb.b) >> 1;
+            s_cxy[j] = ((unsigned)cx & 0xFFFFu) | ((unsigned)cy << 16);
+            s_ty[j] = cb.type;
+        }
+        small = __syncthreads_and(small) != 0;
+    }
+    if (r >= nR || nC <= 0) return;                                   // wave-uniform (behind the workgroup's only barrier)
     bbox_t rb = {};
     if (!a.user) rb = rowsTrk ? a.trk[r] : a.det[r];
-    // ---- box costs: order by the integer key (class flag, squared centroid distance) and evaluate the float64 cost only for the
-    // entries that are kept.  Exact whenever the LAP_K smallest keys are same-class entries closer than 1280 px: their costs are
-    // < 1.0 <= every cross-class cost, and inside a class the cost grows strictly with the squared distance. ----
+    // Order by an integer key and evaluate the float64 cost only for the entries that are kept.  Key = squared centroid distance << 10 |
+    // column for same-class entries closer than 2048 px, "none" otherwise: ONE wave minimum per kept entry yields distance and column
+    // (equal distances: the lowest column), and a row that does not find LAP_K such entries among its columns takes the general form
+    // below.  Exact: same-class costs are < 1.0 <= every cross-class cost, and inside a class the cost grows strictly with the squared
+    // distance.
     if (!a.user) {
         unsigned ik[MK_MAXN / 64];
-        bool small = box_small(rb);
+        small &= box_small(rb);
+        const int rcx = (rb.l + rb.r) >> 1, rcy = (rb.t + rb.b) >> 1;
         unsigned mx0 = 0, mx1 = 0; bool any1 = false;
 #pragma unroll
         for (int t = 0; t < MK_MAXN / 64; t++) {
             const int j = t * 64 + lane;
             ik[t] = 0xFFFFFFFFu;
             if (j < nC) {
-                const bbox_t cb = rowsTrk ? a.det[j] : a.trk[j];
-                small &= box_small(cb);
-                int d2; bool pen; if (rowsTrk) pair_d2(rb, cb, d2, pen); else pair_d2(cb, rb, d2, pen);
-                ik[t] = (pen ? 0x80000000u : 0u) | (unsigned)d2;
-                if (pen) { any1 = true; if ((unsigned)d2 > mx1) mx1 = (unsigned)d2; } else if ((unsigned)d2 > mx0) mx0 = (unsigned)d2;
+                const unsigned u = s_cxy[j];
+                const int dx = rcx - (int)(short)(u & 0xFFFFu), dy = rcy - ((int)u >> 16);
+                const unsigned d2 = (unsigned)(dx * dx + dy * dy);
+                const bool pen = s_ty[j] != rb.type;
+                if (!pen && d2 < (1u << 22)) ik[t] = (d2 << 10) | (unsigned)j;
+                if (pen) { any1 = true; if (d2 > mx1) mx1 = d2; } else if (d2 > mx0) mx0 = d2;
             }
         }
-        if (!__ballot(!small)) {
-            unsigned selk = 0xFFFFFFFFu, selc = 0xFFFFu;              // lane k keeps the k-th smallest
+        if (small) {
+            unsigned sel = 0xFFFFFFFFu;                                // lane k keeps the k-th smallest
             for (int k = 0; k < LAP_K; k++) {
-                unsigned lk = 0xFFFFFFFFu; int lt = 0;
+                unsigned lk = 0xFFFFFFFFu;
 #pragma unroll
-                for (int t = 0; t < MK_MAXN / 64; t++) if (ik[t] < lk) { lk = ik[t]; lt = t; }
+                for (int t = 0; t < MK_MAXN / 64; t++) lk = ik[t] < lk ? ik[t] : lk;
                 const unsigned wm = wave_min_u32_dpp(lk);
-                const unsigned mycol = (lk == wm && lk != 0xFFFFFFFFu) ? (unsigned)(lt * 64 + lane) : 0xFFFFFFFFu;
-                const unsigned wc = wave_min_u32_dpp(mycol);          // equal cost: the lowest column
-                if (lane == k) { selk = wm; selc = wc == 0xFFFFFFFFu ? 0xFFFFu : wc; }
-                if (mycol == wc && wc != 0xFFFFFFFFu) {
+                if (lane == k) sel = wm;
+                if (wm != 0xFFFFFFFFu) {
 #pragma unroll
-                    for (int t = 0; t < MK_MAXN / 64; t++) if (t == lt) ik[t] = 0xFFFFFFFFu;
+                    for (int t = 0; t < MK_MAXN / 64; t++) ik[t] = ik[t] == wm ? 0xFFFFFFFFu : ik[t];   // keys are unique
                 }
             }
-            const bool near = lane >= LAP_K || selc == 0xFFFFu || selk < (unsigned)MOT_FRAME_W * MOT_FRAME_W;   // same class, closer than 1280 px
+            // lane k < LAP_K: a kept entry must exist unless the row has fewer than k + 1 columns, and lie closer than 1280 px
+            const bool near = lane >= LAP_K || (sel != 0xFFFFFFFFu ? (sel >> 10) < (unsigned)MOT_FRAME_W * MOT_FRAME_W : lane >= nC);
             if (!__ballot(!near)) {
                 if (lane < LAP_K) {
-                    const bool has = selc != 0xFFFFu;
-                    const double cst = has ? cost_of_d2((int)(selk & 0x7FFFFFFFu), (selk >> 31) != 0) : DBL_MAX;
-                    L.ccol[(size_t)r * LAP_K + lane] = (unsigned short)selc;
+                    const bool has = sel != 0xFFFFFFFFu;
+                    const double cst = has ? cost_of_d2((int)(sel >> 10), false) : DBL_MAX;
+                    L.ccol[(size_t)r * LAP_K + lane] = has ? (unsigned short)(sel & 1023u) : (unsigned short)0xFFFF;
                     L.ccost[(size_t)r * LAP_K + lane] = cst;
                     if (lane == 0) a.linemin[r] = dkey(cst);           // hungarian.cpp:69-81
                 }
