@@ -71,7 +71,7 @@ struct DevLoop {
     int buf_prev = 0, buf_cur = 1; hipEvent_t ev_spec[3]{}; bool spec_side[3] = {false, false, false}; bool have_cur = false;
     const void* pf_frame = nullptr; const void* pf_dets = nullptr; int pf_nD = -1, pf_buf = -1; bool pf_valid = false;
     const void* next_frame = nullptr; const void* next_dets = nullptr; int next_nD = 0;
-    hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_feat = nullptr, ev_upd = nullptr, ev_in = nullptr; bool split = false;
+    hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_in = nullptr; bool split = false;
     // mot_step_frame_host: copy stream + two device buffers (frame, detections); up[b]: upload of buffer b done, done[b]: the frame that read it finished
     hipStream_t copy = nullptr; DevBuf<uint8_t> hbuf[2]; DevBuf<bbox_t> dbuf[2]; hipEvent_t ev_up[2]{}, ev_done[2]{}; unsigned host_no = 0; bool host_ok = false;
     int host_spec[2] = {-1, -1};  // spectra buffer the frame in host buffer b wrote (its side-stream feature launch reads the host buffer too)
@@ -84,8 +84,6 @@ void devloop_destroy(DevLoop* d)
     if (!d) return;
     if (d->ev_ok) for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
-    if (d->ev_feat) (void)hipEventDestroy(d->ev_feat);
-    if (d->ev_upd) (void)hipEventDestroy(d->ev_upd);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     for (hipEvent_t e : d->ev_spec) if (e) (void)hipEventDestroy(e);
     if (d->side) (void)hipStreamDestroy(d->side);
@@ -179,10 +177,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             }
             if (!masked) HIPCHK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
             HIPCHK(hipEventCreateWithFlags(&d->ev_mid, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&d->ev_feat, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&d->ev_upd, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
-            HIPCHK(hipEventRecord(d->ev_upd, c->stream));
             // Deferred blend (default; MOT_DEFER_BLEND=0 restores the blend launch): the model update of frame f rides in frame f + 1's
             // predict kernel.  The spectra of frame f must then outlive the feature launch of frame f + 1: two buffers, by frame parity.
             const char* dv = getenv("MOT_DEFER_BLEND");
@@ -252,7 +247,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
         } else {
             if (early) {
                 // the side stream is ordered behind everything the caller has enqueued on the context stream so far (frame upload,
-                // detector output): in-order execution makes this event subsume the previous frame's update (ev_upd) as well
+                // detector output): in-order execution makes this event cover the previous frame's update as well
                 HIPCHK(hipEventRecord(d->ev_in, c->stream));
                 HIPCHK(hipStreamWaitEvent(d->side, d->ev_in, 0));
                 HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side, own_est + nD <= MOT_SPLIT_EXCL_MAX));   // own CUs beside the predict
@@ -323,7 +318,6 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
             if (split && d->spec_side[d->buf_cur]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_cur], 0));   // the blend launch reads this frame's spectra
             HIPCHK(launch_kcf_update(kp, l, upd_max, c->stream));
         }
-        if (split) HIPCHK(hipEventRecord(d->ev_upd, c->stream));
         if (split) d->buf_prev = d->buf_cur;
     } else HIPCHK(launch_kalman_update(c->kal, S.upd_slots, S.upd_count, upd_max, S.upd_boxes, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[4], c->stream));
