@@ -10,15 +10,18 @@ import mot_amd, orc
 from bench import gen_stream
 
 n, nf = int(sys.argv[1]), int(sys.argv[2])
+miss, fp = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, 0)
 lib = orc.load_oracle()
-frames, dets = gen_stream(n, 80, nf)
+counts = []
+frames, dets = gen_stream(n, 80, nf, miss_pct=miss, fp_pct=fp, nms=bool(miss or fp), counts=counts)
+if not counts: counts = [n] * nf
 fd = torch.from_numpy(frames).cuda(); dd = torch.from_numpy(dets.view(np.uint8).reshape(nf, -1)).cuda()
 c = mot_amd.MotContext(max_tracks=1024, max_dets=1024)
 m = orc.OracleMot(lib, 0, 0, 1024)
 used = [0, 0, 0]; t0 = time.time()
 for f in range(nf):
-    c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), n)
-    ref = m.step(frames[f], dets[f])
+    c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), counts[f])
+    ref = m.step(frames[f], dets[f][:counts[f]])
     boxes, tids, _ = c.live_tracks()
     if f > 0: used[int(c.lap_stats()[15])] += 1
     bnp = lambda b: np.stack([b[k] for k in ("l", "t", "b", "r", "type")], axis=1)
