@@ -14,6 +14,13 @@
 #include "dl_lifecycle.h"
 #include <dlfcn.h>
 
+// Events that order work between this context's streams on ONE device: no timing, and a DEVICE-scope release when recorded.  The
+// default (system-scope) release writes back and invalidates the caches at every record; the consumers here are kernels of the same
+// device.  (Timeline: the gap in front of the predict launch went from 10.5 to 5.9 us; the bench moved within its noise.  The two
+// sync packets of a frame -- this wait and the record in front of the row scan -- still cost ~13 us together: the fused-update
+// variant, which has neither, shows no gap at all between its kernels.)
+#define MOT_EVENT_FLAGS (hipEventDisableTiming | hipEventReleaseToDevice)
+
 using namespace mot_impl;
 
 namespace {
@@ -176,15 +183,15 @@ int devloop_get(mot_ctx* c, DevLoop** out)
                 if (!masked) { (void)hipGetLastError(); d->side = nullptr; }
             }
             if (!masked) HIPCHK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
-            HIPCHK(hipEventCreateWithFlags(&d->ev_mid, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_mid, MOT_EVENT_FLAGS));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_in, MOT_EVENT_FLAGS));
             // Deferred blend (default; MOT_DEFER_BLEND=0 restores the blend launch): the model update of frame f rides in frame f + 1's
             // predict kernel.  The spectra of frame f must then outlive the feature launch of frame f + 1: two buffers, by frame parity.
             const char* dv = getenv("MOT_DEFER_BLEND");
             d->defer = !(dv && atoi(dv) == 0);
             d->spec_stride = (size_t)md * MOT_NCHAN * kp.nbins;
             HIPCHK(d->det_spec.alloc(d->spec_stride * 3));
-            for (int b = 0; b < 3; b++) HIPCHK(hipEventCreateWithFlags(&d->ev_spec[b], hipEventDisableTiming));
+            for (int b = 0; b < 3; b++) HIPCHK(hipEventCreateWithFlags(&d->ev_spec[b], MOT_EVENT_FLAGS));
             if (d->defer) {
                 HIPCHK(d->pend.alloc((size_t)cap)); HIPCHK(hipMemset(d->pend.p, 0xFF, sizeof(int) * cap));
                 S.defer = 1; S.pend_det = d->pend.p;
@@ -415,7 +422,7 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         HIPCHK(hipStreamCreateWithFlags(&d->copy, hipStreamNonBlocking));
         for (int b = 0; b < 2; b++) {
             HIPCHK(d->hbuf[b].alloc(fbytes)); HIPCHK(d->dbuf[b].alloc((size_t)c->cfg.max_dets));
-            HIPCHK(hipEventCreateWithFlags(&d->ev_up[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&d->ev_done[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_up[b], MOT_EVENT_FLAGS)); HIPCHK(hipEventCreateWithFlags(&d->ev_done[b], MOT_EVENT_FLAGS));
         }
         d->host_ok = true;
     }
