@@ -339,6 +339,32 @@ def test_assign_tracking_costs_vs_oracle(mot, oracle, n):
     c.close()
 
 
+def test_assign_row_scan_fallbacks_vs_oracle(mot, oracle):
+    """lap_rowscan_kernel keeps the 8 nearest SAME-CLASS columns of a row through packed integer keys (squared distance << 10 | column,
+    LDS-staged centroids) and must fall back to its general float64 form whenever that is not the whole truth: a class with fewer than 8
+    members (the row's 8 smallest costs then include cross-class entries), boxes outside the +-1400 px range the packed centroids cover,
+    and centroid distances beyond 2048 px.  Every variant must reproduce the oracle's assignment and cost."""
+    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    rng = np.random.default_rng(77)
+    n = 160
+    def boxes(off_frame=False, rare=False, far=False):
+        cx = rng.integers(0, 1200, size=n); cy = rng.integers(0, 640, size=n)
+        ty = np.array([i % 3 for i in range(n)])
+        if rare: ty = np.where(np.arange(n) < 5, 1, 0)                   # class 1 has five members only
+        if off_frame: cx[:6] += 2000                                     # beyond box_small's range
+        if far: cx[:4] -= 1300; cx[4:8] += 900                           # pairs farther apart than 2048 px exist
+        trk = [(int(cx[i] + rng.integers(-3, 4)), int(cy[i] + rng.integers(-3, 4)), int(cy[i]) + 79, int(cx[i]) + 79, int(ty[i]), 0.9) for i in range(n)]
+        perm = rng.permutation(n)
+        det = [(int(cx[i] + rng.integers(-2, 3)), int(cy[i] + rng.integers(-2, 3)), int(cy[i]) + 79, int(cx[i]) + 79, int(ty[i]), 0.9) for i in perm]
+        return trk, det
+    for kw in ({}, {"rare": True}, {"off_frame": True}, {"far": True}, {"rare": True, "far": True}):
+        trk, det = boxes(**kw)
+        at, ad, cost = c.assign(trk, det)
+        ra, rc = orc.assignment_optimal(oracle, orc.cost_matrix(oracle, trk, det), n, n)
+        assert np.array_equal(ad, ra) and cost == rc, kw
+    c.close()
+
+
 # ---------------------------------------------------------------- frame loop
 def _scene(spec):
     from multiple_object_tracking_amd import synth
