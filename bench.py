@@ -452,7 +452,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "alg_bytes_per_launch": per_launch, "avg_launch_ms": cands[dom][0],
-                               "note": "time between two HIP events recorded on the launch stream directly around the kernel launch (incl. the dispatch gap)"}
+                               "note": "HIP events holding the kernel's own begin / end time stamps (hipExtLaunchKernelGGL start / stop events on the launch stream): the duration rocprofv3 reports for the launch, without the marker packets of an event pair around it"}
             other = [k for k in cands if k != dom][0]
             ob = cands[other][1] * n_live
             out["roofline_other"] = {"bound": "hbm", "kernel": other, "achieved": ob / (cands[other][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

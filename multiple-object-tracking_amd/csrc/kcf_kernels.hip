@@ -16,6 +16,7 @@
 // reference, including its rcpps/rsqrtps approximations (table emulation).
 // The DFTs are free to contract (FFTW's own rounding is not reproducible).
 #include "mot_dev.h"
+#include <hip/hip_ext.h>
 #include "bin_thresholds.inc"
 
 #define PI_F 3.14159265f /* libhog/gradientMex.cpp:12 */
@@ -1440,7 +1441,7 @@ static hipError_t set_lds_attr(K kern, size_t bytes)
     return e;
 }
 
-hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
+hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)
 {
     if (n <= 0) return hipSuccess;
     if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
@@ -1452,10 +1453,12 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     const size_t lds = kcf_lds_bytes(p);
     if (p.use_lds) {
         hipError_t e = set_lds_attr(kcf_predict_kernel<true>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+        if (t_start && t_stop) hipExtLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n);
+        else hipLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
     } else {
         hipError_t e = set_lds_attr(kcf_predict_kernel<false>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
+        if (t_start && t_stop) hipExtLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), (unsigned)lds, s, t_start, t_stop, 0, p, l, n);
+        else hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
     }
     return hipGetLastError();
 }

@@ -152,7 +152,9 @@ struct AssocWs {
 };
 
 // host-side launchers implemented in the .hip files
-hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
+// t_start / t_stop (profiling, both or none): the runtime records the KERNEL's own begin / end time stamps in these events
+// (hipExtLaunchKernelGGL) -- what rocprofv3 reports for the launch, without the two marker packets an event pair around it adds
+hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr);
 hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp, int n_pred, const KcfLaunch& lf, int n_feat, hipStream_t s);   // one launch: predict items, then feature-only items
 hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu = false);
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);

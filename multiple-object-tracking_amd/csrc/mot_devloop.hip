@@ -238,7 +238,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     const bool early = d->split && !d->have_cur && S.kind == MOT_TRACKER_KCF && dets_dev && nD > 0 && nD <= S.max_dets && own_est + nD <= early_max;
     // the blend prologue of this predict reads the previous frame's spectra: behind the side-stream launch that wrote them
     if (d->split && d->defer && d->spec_side[d->buf_prev]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_prev], 0));
-    if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));                  // profiling: the events bracket the predict launch itself, behind the stream's wait
+    bool ext_timed = false;                                            // profiling: the predict launch records its own begin / end (below)
     static int joined_on = -1;
     if (joined_on < 0) { const char* ev = getenv("MOT_JOINED_LAUNCH"); joined_on = (ev && atoi(ev) == 0) ? 0 : 1; }
     if (S.kind == MOT_TRACKER_KCF) {
@@ -249,6 +249,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
         if (early && joined_on) {
             // small frames leave most CUs idle during the predict: the detection features (they only need the frame and the boxes) ride in
             // the SAME launch as extra workgroups -- no side stream, no events (MOT_JOINED_LAUNCH=0: side-stream launch as in round 2)
+            if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
             HIPCHK(launch_kcf_predict_features(c->pools[d->pool]->dev, l, S.spr, lf, nD, c->stream));
             d->feat_early = true; d->feat_joined = true;
         } else {
@@ -261,10 +262,13 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
                 HIPCHK(hipEventRecord(d->ev_spec[d->buf_cur], d->side)); d->spec_side[d->buf_cur] = true;
                 d->feat_early = true;
             }
-            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream));
+            // profiling (single template size): the kernel's own begin / end stamps go to ev[0] / ev[1]
+            ext_timed = ev && S.ncls <= 1;
+            if (ev && !ext_timed) HIPCHK(hipEventRecord(ev[0], c->stream));
+            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream, ext_timed ? ev[0] : nullptr, ext_timed ? ev[1] : nullptr));
         }
-    } else HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream));
-    if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
+    } else { if (ev) HIPCHK(hipEventRecord(ev[0], c->stream)); HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream)); }
+    if (ev && !ext_timed) HIPCHK(hipEventRecord(ev[1], c->stream));
     d->begun = true;
     return MOT_OK;
 }
