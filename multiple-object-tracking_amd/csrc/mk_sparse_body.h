@@ -16,7 +16,6 @@ namespace assoc {
 struct SpShared {
     double Scol[MK_MAXN];                    // S_j   (member order keeps `tl` 8-byte aligned: it is filled and read as uint2)
     u64 hkey;                                // step 5: order-preserving key of the minimum (LDS atomicMin, one per wavefront)
-    u64 pad16;                               // (keeps `tl` 16-byte aligned: the rank pass reads it as uint4)
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
     unsigned tzero[MK_MAXN];                 // per column: which of its slots hold a zero
     unsigned tlive[MK_MAXN];                 // ... a zero in an UNCOVERED row
@@ -35,7 +34,7 @@ struct SpShared {
     int flag[8];
 };
 static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
-static_assert(offsetof(SpShared, tl) % 16 == 0, "transposed lists are accessed as uint2 / uint4");
+static_assert(offsetof(SpShared, tl) % 8 == 0, "transposed lists are accessed as uint2");
 static_assert(SPK <= 16 && (SPK & (SPK - 1)) == 0 && (SP_TLS & (SP_TLS - 1)) == 0, "candidate index is packed into 4 bits; lane masks");
 static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certify scratch");
 // after the run the transposed lists are dead: their 64 KB hold the column grid of the fused after-the-fact check and the
@@ -150,29 +149,19 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         // the row order); four slots per LDS read, empty slots (0xFFFF) never count
         unsigned char rank[SPK];
         if (r < nR) {
-            // the first 16 slots of every candidate's list are read unconditionally (two 16-byte reads; empty slots hold 0xFFFF and never
-            // count), four candidates' reads in flight at a time -- no data-dependent trip count, so no LDS round trip per loop iteration;
-            // lists beyond 16 entries (crowded spots) take one more pair of reads
-            auto cnt8 = [](const uint4 q, const unsigned me) {
-                return (int)((q.x & 0xFFFFu) < me) + (int)((q.x >> 16) < me) + (int)((q.y & 0xFFFFu) < me) + (int)((q.y >> 16) < me) +
-                       (int)((q.z & 0xFFFFu) < me) + (int)((q.z >> 16) < me) + (int)((q.w & 0xFFFFu) < me) + (int)((q.w >> 16) < me);
-            };
 #pragma unroll
-            for (int k0 = 0; k0 < SPK; k0 += 4) {
-                uint4 qa[4], qb[4]; int cn[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int col = myc[k0 + j] != 0xFFFF ? (int)myc[k0 + j] : 0;
-                    const uint4* t4 = reinterpret_cast<const uint4*>(S.tl + col * SP_TLS);
-                    qa[j] = t4[0]; qb[j] = t4[1]; cn[j] = S.cnt[col];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int k = k0 + j;
+            for (int k = 0; k < SPK; k++) {
+                rank[k] = 0;
+                if (myc[k] != 0xFFFF) {
+                    const uint2* t2 = reinterpret_cast<const uint2*>(S.tl + myc[k] * SP_TLS);
                     const unsigned me = (unsigned)((r << 4) | k);
-                    int rk = cnt8(qa[j], me) + cnt8(qb[j], me);
-                    if (myc[k] != 0xFFFF && cn[j] > 16) { const uint4* t4 = reinterpret_cast<const uint4*>(S.tl + myc[k] * SP_TLS); rk += cnt8(t4[2], me) + cnt8(t4[3], me); }
-                    rank[k] = myc[k] != 0xFFFF ? (unsigned char)rk : (unsigned char)0;
+                    const int m4 = (S.cnt[myc[k]] + 3) >> 2;
+                    int rk = 0;
+                    for (int i = 0; i < m4; i++) {
+                        const uint2 q = t2[i];
+                        rk += ((q.x & 0xFFFFu) < me) + ((q.x >> 16) < me) + ((q.y & 0xFFFFu) < me) + ((q.y >> 16) < me);
+                    }
+                    rank[k] = (unsigned char)rk;
                 }
             }
         }
