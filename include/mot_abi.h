@@ -265,6 +265,8 @@ int mot_get_assoc_stats(mot_ctx* ctx, int* out16);
  * [26..28] dense solver (frames whose far matches defeat the sparse one: detector misses + false positives) in the most recent launch:
  *   settled columns, free rows after the greedy start, time in 10 ns ticks; [29] launches in which it ran, [30] ... and were certified */
 int mot_get_lap_stats(mot_ctx* ctx, int* out32);
+/* debug: thread 0's time stamps along the sparse emulation's cycles of the most recent launch (MOT_MK_TIMING=1): out[0] = count, then tag << 56 | 10 ns ticks */
+int mot_debug_assoc_trace(mot_ctx* ctx, long long* out, int n);
 /* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
 int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);
 /* crop + gray + resize only (top/td.cpp:348-364) on the bound frame. */

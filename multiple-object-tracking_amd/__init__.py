@@ -343,6 +343,14 @@ class MotContext:
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
         return out
 
+    def assoc_trace(self, n: int = 8192) -> np.ndarray:
+        """(debug, MOT_MK_TIMING=1) thread 0's (tag, 10 ns ticks) along the sparse emulation's cycles of the most recent launch"""
+        out = np.zeros(n, np.int64)
+        self._chk(self.lib.mot_debug_assoc_trace(self._h, _vp(out), n))
+        k = int(out[0])
+        v = out[1:max(1, min(k, n))]
+        return np.stack([v >> 56, v & ((1 << 56) - 1)], axis=1)
+
     def lap_stats(self) -> np.ndarray:
         """assignment fast path: [0..7] most recent launch (outcome, rounds, free rows, searches, commits, near-tight
         edges, cyclic nodes, solver ticks), [15] what decided it (0 certificate, 1 sparse emulation, 2 dense emulation), [16..20] cumulative

@@ -1080,7 +1080,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
             static int two_block_on = -1, mk_batch_on = -1, fuse_on = -1;
             if (two_block_on < 0) { const char* ev = getenv("MOT_LAP_TWO_BLOCK"); two_block_on = (ev && atoi(ev) == 0) ? 0 : 1; }
-            if (mk_batch_on < 0) { const char* ev = getenv("MOT_MK_BATCH"); mk_batch_on = ev ? atoi(ev) : 1; }   // 0: one event per iteration; n > 1: batch threshold (default 3)
+            if (mk_batch_on < 0) { const char* ev = getenv("MOT_MK_BATCH"); mk_batch_on = (ev ? atoi(ev) : 1) & 0xFFFF; const char* lz = getenv("MOT_MK_LAZY"); if (lz && atoi(lz) == 0) mk_batch_on |= 0x40000000; const char* tm = getenv("MOT_MK_TIMING"); if (tm && atoi(tm)) mk_batch_on |= 0x20000000; }   // 0: one event per iteration; n > 1: batch threshold (default 3)
             if (fuse_on < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse_on = (ev && atoi(ev) == 0) ? 0 : 1; }
             const bool two_block = two_block_on && fuse_on && !a.user && !want_dense;
             e = launch_lap_front(a, gR, gC, s, ev_mid, life, two_block, mk_batch_on); if (e != hipSuccess) return e;

@@ -99,7 +99,7 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, c
         attr_dev = dev;
     }
     static int batch = -1;                                             // MOT_MK_BATCH=0: one event per iteration of the sparse emulation's event loop
-    if (batch < 0) { const char* ev = getenv("MOT_MK_BATCH"); batch = ev ? atoi(ev) : 1; }
+    if (batch < 0) { const char* ev = getenv("MOT_MK_BATCH"); batch = (ev ? atoi(ev) : 1) & 0xFFFF; const char* lz = getenv("MOT_MK_LAZY"); if (lz && atoi(lz) == 0) batch |= SP_LAZY_OFF; const char* tm = getenv("MOT_MK_TIMING"); if (tm && atoi(tm)) batch |= SP_TIMING; }   // MOT_MK_LAZY=0: the reference's full reset after every augmentation
     // box costs: the after-the-fact check (and the lifecycle step) run inside the emulation's workgroup; caller matrices keep the dense pass
     static int fuse = -1;
     if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }

@@ -12,16 +12,21 @@ namespace assoc {
 
 #define SPK LAP_K
 #define SP_TLS 32               /* slots per column in the transposed lists; a column wanted by more rows: not applicable */
+#define SP_UQ 64                /* union requests one step 5 can queue; more: the run falls back to the reference's full reset */
+#define SP_LAZY_OFF 0x40000000  /* flag in the mk_batch argument: MOT_MK_LAZY=0 */
+#define SP_TIMING   0x20000000  /* flag in the mk_batch argument: MOT_MK_TIMING=1 -- per-cycle clock reads for the probe tools (3 x s_memrealtime per step-5 cycle) */
+#define SP_CX_MAX 16            /* rows with several zeros at the start that the set-up ties together one by one; more: one component */
 
 struct SpShared {
+    int lab[MK_MAXN];                        // lazy reset: component label of a column in the zero graph (= smallest column of its component); first: scanned as int4
+    unsigned short cj[SPK * MK_MAXN];        // candidate columns, [row][k] (0xFFFF: none): a row's record is one 16-byte read
     double Scol[MK_MAXN];                    // S_j   (member order keeps `tl` 8-byte aligned: it is filled and read as uint2)
     u64 hkey;                                // step 5: order-preserving key of the minimum (LDS atomicMin, one per wavefront)
     u64 covR[MK_MAXW], covC[MK_MAXW], hz[MK_MAXW], hzAll[MK_MAXW];
     unsigned tzero[MK_MAXN];                 // per column: which of its slots hold a zero
     unsigned tlive[MK_MAXN];                 // ... a zero in an UNCOVERED row
     unsigned short tl[SP_TLS * MK_MAXN];     // transposed lists, [column][slot]: (row << 4) | k, rows ascending
-    unsigned short cj[SPK * MK_MAXN];        // candidate columns, [k][row] (0xFFFF: none)
-    unsigned char pos[SPK * MK_MAXN];        // slot of (row, k) in its column's list
+    unsigned char pos[SPK * MK_MAXN];        // slot of (row, k) in its column's list, [row][k]
     unsigned short zmask[MK_MAXN];           // zeros of a row as a mask over its candidates
     short starColOfRow[MK_MAXN], starRowOfCol[MK_MAXN], primeColOfRow[MK_MAXN];
     unsigned short clist[MK_MAXN];
@@ -30,11 +35,16 @@ struct SpShared {
     unsigned ph32[MK_MAXW * 2];              // batch path: LDS copy of the columns uncovered in this phase
     unsigned dirty32[MK_MAXW * 2];           // columns whose zero masks a step 5 changed (wave 0 refreshes their hz bits)
     unsigned short blist[64];                // batch path: the candidate columns of one batch, ascending
+    unsigned uq[2 + SP_UQ];                  // lazy reset: union requests of a step 5: [0] count, [1..] (label << 16 | label) -- count and first request are one 8-byte read
+    unsigned char dirtyLab[MK_MAXN];         // ... per label: the component must be re-grown from scratch at the next augmentation
     int wave_tot[MK_THREADS / 64];
     int flag[8];
+    unsigned tprof[4];                       // (MOT_MK_TIMING) wave 0's ticks by part: phase start, one-event iterations, batch iterations, augmentations
 };
 static_assert(sizeof(SpShared) <= MOT_LDS_LIMIT, "mk_sparse_kernel LDS");
 static_assert(offsetof(SpShared, tl) % 8 == 0, "transposed lists are accessed as uint2");
+static_assert(offsetof(SpShared, lab) % 16 == 0 && offsetof(SpShared, uq) % 8 == 0, "labels are scanned as int4; request count + first request as uint2");
+static_assert(offsetof(SpShared, cj) % 16 == 0 && offsetof(SpShared, pos) % 8 == 0 && SPK == 8, "a row's candidate columns / slots are read as one uint4 / uint2");
 static_assert(SPK <= 16 && (SPK & (SPK - 1)) == 0 && (SP_TLS & (SP_TLS - 1)) == 0, "candidate index is packed into 4 bits; lane masks");
 static_assert(sizeof(SpShared) >= LAP_EDGES * 4 + 2 * (MK_MAXN + 64), "lap_certify scratch");
 // after the run the transposed lists are dead: their 64 KB hold the column grid of the fused after-the-fact check and the
@@ -101,10 +111,13 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     const int r = tid;
     const int wordsC = (nC + 63) >> 6;
     if (tid < 8) S.flag[tid] = 0;
+    if (tid == 0) S.uq[0] = 0;
+    if (tid < 4) S.tprof[tid] = 0;
     S.cnt[tid] = 0; S.tzero[tid] = 0; S.Scol[tid] = 0.0;
     S.starColOfRow[tid] = -1; S.starRowOfCol[tid] = -1; S.primeColOfRow[tid] = -1;
     if (tid < MK_MAXW) { S.covR[tid] = 0; S.covC[tid] = 0; }
     if (tid < MK_MAXW * 2) S.dirty32[tid] = 0;
+    S.lab[tid] = tid; S.dirtyLab[tid] = 1;                             // lazy reset: every column its own component; phase 0 grows everything from scratch
     __syncthreads();
     double dv[SPK]; unsigned short myc[SPK];
     unsigned zm = 0;                                                   // zero bits of the row's candidates
@@ -119,7 +132,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         }
     }
 #pragma unroll
-    for (int k = 0; k < SPK; k++) S.cj[k * MK_MAXN + r] = myc[k];
+    for (int k = 0; k < SPK; k++) S.cj[r * SPK + k] = myc[k];
     S.zmask[r] = (unsigned short)zm;
     __syncthreads();
     {   // transposed lists: fill (any order), then sort each column's list by row.  The longest list bounds a per-column
@@ -169,7 +182,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         if (r < nR) {
 #pragma unroll
             for (int k = 0; k < SPK; k++) if (myc[k] != 0xFFFF) {
-                S.tl[myc[k] * SP_TLS + rank[k]] = (unsigned short)((r << 4) | k); S.pos[k * MK_MAXN + r] = rank[k];
+                S.tl[myc[k] * SP_TLS + rank[k]] = (unsigned short)((r << 4) | k); S.pos[r * SPK + k] = rank[k];
                 if ((zm >> k) & 1) atomicOr(&S.tzero[myc[k]], 1u << rank[k]);      // zero masks of the columns, from the entries' side
             }
         }
@@ -199,12 +212,13 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         int off = 0, ncx = 0;
         for (int w = 0; w < MK_THREADS / 64; w++) { const int t = S.wave_tot[w]; if (w < wave) off += t; ncx += t; }
         if (complex_row) S.clist[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
+        if (tid == 0) S.flag[5] = ncx;                                 // (lazy reset: how many rows start with several zeros)
         __syncthreads();
         if (wave == 0) {                                               // ordered pass over the complex rows: lane = candidate slot
             for (int q = 0; q < ncx; q++) {
                 const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
                 unsigned key = 0xFFFFu;
-                if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[lane * MK_MAXN + rr]; if (minSimple[c] > rr && S.starRowOfCol[c] < 0) key = (unsigned)c; }
+                if (lane < SPK && ((m >> lane) & 1)) { const int c = S.cj[rr * SPK + lane]; if (minSimple[c] > rr && S.starRowOfCol[c] < 0) key = (unsigned)c; }
                 const unsigned mykey = key;
                 key = wave_min_u32_dpp(key);
                 if (lane == 0 && key != 0xFFFFu) { S.starColOfRow[rr] = (short)key; S.starRowOfCol[key] = (short)rr; }
@@ -231,21 +245,62 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     int n_bat = 0, n_seq = 0;                                           // (debug: iterations of the batch / the one-event path)   // (debug split of the event loop)
     const long long t_setup = wall_clock64() - t_begin;
     // Wavefront 0 keeps the 1024-bit masks as 32-bit words, lane l (and its mirror l + 32) holding word l & 31: covered columns /
-    // rows, columns uncovered in this phase, columns with a live zero (hzr) / with any zero (hzAllr).  Mirroring the upper half lets
+    // rows, columns uncovered in this phase, columns with a live zero (hzr).  Mirroring the upper half lets
     // every lane store its word to the LDS copies without a branch.
     unsigned* covR32 = reinterpret_cast<unsigned*>(S.covR); unsigned* covC32 = reinterpret_cast<unsigned*>(S.covC); unsigned* hz32 = reinterpret_cast<unsigned*>(S.hz);
-    const bool batch_on = mk_batch != 0;
-    const int bthr = mk_batch > 1 ? mk_batch : 3;                       // candidate columns in front of the sweep that make a batch worth its fixed cost
+    const bool batch_on = (mk_batch & 0xFFFF) != 0;
+    const int bthr = (mk_batch & 0xFFFF) > 1 ? (mk_batch & 0xFFFF) : 3;                       // candidate columns in front of the sweep that make a batch worth its fixed cost
     const int l5 = lane & 31;
     const unsigned vC = (l5 * 32 + 32 <= nC) ? ~0u : (l5 * 32 >= nC ? 0u : ((1u << (nC & 31)) - 1u));
     unsigned cC = covC32[l5], cR = 0, ph = 0;
-    unsigned hzr = reinterpret_cast<unsigned*>(S.hz)[l5], hzAllr = hzr;
+    unsigned cRv = 0, phv = 0;                                         // lazy reset: the covered rows / uncovered star columns of CLEAN components (subsets of cR / ph)
+    unsigned hzr = reinterpret_cast<unsigned*>(S.hz)[l5];
     int nstar = ncov;                                                  // starred columns: + 1 per augmentation
-    bool hz_dirty = false;                                             // step 5 changed the masks: wave 0 rebuilds hzr / hzAllr
+    bool hz_dirty = false;                                             // step 5 changed the masks: wave 0 rebuilds hzr
     int status = 0;
     int vseen = 0;                                                     // (wavefront 0, speculative run) the verdict word as last seen
+    // ---- LAZY RESET (round 4; CPU model and the argument: oracle/mk_sparse_model.c, mks_run, lazy).  Between two step 5s the connected
+    // components of the zero graph evolve independently (the sweep visits columns in ascending order and repeats while anything
+    // happened: what a component does in pass p depends on its own state only).  The reference uncovers every row after an
+    // augmentation and re-grows its whole forest (:324-334): for a component that was grown from scratch in a phase that ran to its
+    // end and has seen no zero appear or vanish and no star change since, that re-growth reproduces covers and primes exactly, so
+    // it is skipped; everything else is DIRTY and reset.  Labels: lab[c] = smallest column of c's component, flat, merged by this
+    // wavefront when a step 5 creates a zero (components never split: exact, just not minimal). ----
+    bool lazy_ok = (mk_batch & SP_LAZY_OFF) == 0;
+    const bool timing = (mk_batch & SP_TIMING) != 0;
+    // (MOT_MK_TIMING) time stamps of thread 0 along the cycle, in the dense working matrix (unused by this tier): tag << 56 | ticks
+    long long* trace = reinterpret_cast<long long*>(a.ws.dist); int tr_n = 1;
+    auto tr = [&](int tag) { if (timing && tid == 0 && tr_n < 8190) trace[tr_n++] = ((long long)tag << 56) | (wall_clock64() & 0xFFFFFFFFFFFFFFll); };
+    bool scratch_phase = true;                                         // the running phase started from a reset (or is phase 0)
+    volatile unsigned char* dirtyLab = S.dirtyLab;
+    // merge the components of the columns ca, cb: every column labelled max(la, lb) gets min(la, lb)
+    auto lab_union = [&](int ca, int cb) {                             // wavefront 0, uniform arguments
+        const int la = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.lab[ca]));
+        const int lb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.lab[cb]));
+        if (la == lb) return;
+        const int lo = min(la, lb), hi = max(la, lb);
+        int4* l4 = reinterpret_cast<int4*>(S.lab);
+#pragma unroll
+        for (int j = 0; j < MK_MAXN / 256; j++) {
+            int4 v = l4[j * 64 + lane];
+            const bool any = v.x == hi || v.y == hi || v.z == hi || v.w == hi;
+            v.x = v.x == hi ? lo : v.x; v.y = v.y == hi ? lo : v.y; v.z = v.z == hi ? lo : v.z; v.w = v.w == hi ? lo : v.w;
+            if (any) l4[j * 64 + lane] = v;
+        }
+        if (lane == 0) dirtyLab[lo] = 1;                               // (only ever called for components that just changed)
+    };
+    if (wave == 0 && lazy_ok) {                                        // the zeros of the start: a row with several zeros ties their columns together
+        const int ncx0 = S.flag[5];
+        if (ncx0 > SP_CX_MAX) { for (int i = lane; i < MK_MAXN; i += 64) S.lab[i] = 0; }   // (dense / tie-heavy matrices: one component = the reference's full reset)
+        else for (int q = 0; q < ncx0; q++) {
+            const int rr = S.clist[q]; const unsigned m = S.zmask[rr];
+            const int kf = __ffs((int)m) - 1, cf = S.cj[rr * SPK + kf];
+            for (unsigned mm = m & (m - 1); mm; mm &= mm - 1) lab_union(cf, S.cj[rr * SPK + (__ffs((int)mm) - 1)]);
+        }
+    }
     while (!done) {
-        const long long t_a = wall_clock64();
+        const long long t_a = timing ? wall_clock64() : 0;
+        tr(1);
         // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
         if (wave == 0) {
             // (speculative run) this cycle's look at the verdict word: the load is issued here and consumed at the end of the event phase
@@ -253,50 +308,89 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
             int action = 0; bool found = false;
             unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
             if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
-                // every lane owns word l5 of the masks (the mirror lane recomputes the same), so no cross-lane traffic is needed
-                for (unsigned dw = *reinterpret_cast<volatile unsigned*>(&S.dirty32[l5]); dw; dw &= dw - 1) {
+                // every lane owns word l5 of the masks (the mirror lane recomputes the same), so no cross-lane traffic is needed.
+                // ONE round trip: the dirty word, the union requests' header (count + first request) and the label array
+                unsigned dw = *reinterpret_cast<volatile unsigned*>(&S.dirty32[l5]);
+                for (; dw; dw &= dw - 1) {
                     const int b = __ffs((int)dw) - 1, c = l5 * 32 + b;
                     const unsigned bit = 1u << b;
                     hzr = S.tlive[c] ? (hzr | bit) : (hzr & ~bit);
-                    hzAllr = S.tzero[c] ? (hzAllr | bit) : (hzAllr & ~bit);
                 }
                 S.dirty32[l5] = 0;
                 hz_dirty = false;
             }
+            if (timing && lane == 0) atomicAdd(&S.tprof[0], (unsigned)(wall_clock64() - t_a));
+            tr(2);
             // step 4 (:283-334) for the primed, unstarred (row, col); afterwards every row is uncovered again and the sweep restarts
-            auto augment = [&](int row, int col) {
+            auto augment = [&](int row, int col, int ke) {
                 n_aug++;
+                const long long t_g = timing ? wall_clock64() : 0;
                 int last = col;
-                if (lane == 0) {
-                    int cr = row, cc = col;
+                if (lane == 0) {                                       // two LDS round trips per step of the path: the column's star, then that row's prime
+                    int cr = row, cc = col, pk = ke;
                     for (int it = 0; it <= nR + nC; it++) {
                         const int old_r = S.starRowOfCol[cc];
-                        S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr; S.starK[cr] = S.primeK[cr];
+                        S.starColOfRow[cr] = (short)cc; S.starRowOfCol[cc] = (short)cr; S.starK[cr] = (unsigned char)pk;
                         if (old_r < 0) break;
-                        cc = S.primeColOfRow[old_r]; cr = old_r;
+                        cc = S.primeColOfRow[old_r]; pk = S.primeK[old_r]; cr = old_r;
                         if (cc < 0) break;
                     }
                     last = cc;
                 }
                 last = __builtin_amdgcn_readfirstlane(last);
-                // every covered row loses its prime and is uncovered again (:324-330): the live masks of the columns that hold its zeros
-                // go back to the zero masks (tlive == tzero & ~(slots of covered rows) everywhere, so no other column differs)
-                if (lane < 32) {
-                    for (unsigned t = cR; t; t &= t - 1) {
-                        const int r2 = lane * 32 + __ffs((int)t) - 1;
-                        S.primeColOfRow[r2] = -1;
-                        for (unsigned mm = S.zmask[r2]; mm; mm &= mm - 1) { const int c2 = S.cj[(__ffs((int)mm) - 1) * MK_MAXN + r2]; S.tlive[c2] = S.tzero[c2]; }
+                scratch_phase = true;
+                // LAZY RESET.  cRv / phv: covered rows / uncovered star columns of components that were CLEAN when the last from-scratch
+                // phase ended.  Whatever was covered since belongs to a dirty component (events only happen in components that were reset
+                // or got a new zero), so only cRv / phv have to be looked up: a member whose component a step 5 or a merge has made dirty
+                // in the meantime is reset with the rest.  A column ties every row with a zero in it into one component, so a row that
+                // stays covered has no zero in a column touched here.  (Both half-waves hold the same words and do the same, idempotent, work.)
+                if (!lazy_ok) { cRv = 0; phv = 0; }                    // the reference's full reset
+                else if (__ballot((cRv | phv) != 0)) {
+                    while (*reinterpret_cast<volatile int*>(&S.flag[4]) != n_s5) __builtin_amdgcn_s_sleep(1);   // wavefront 1 has merged this cycle's labels
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (*reinterpret_cast<volatile int*>(&S.flag[7])) { lazy_ok = false; cRv = 0; phv = 0; }
+                    for (unsigned t = cRv; t; t &= t - 1) {
+                        const int b = __ffs((int)t) - 1;
+                        const int pc = S.primeColOfRow[l5 * 32 + b];
+                        if (dirtyLab[S.lab[pc & (MK_MAXN - 1)]]) cRv &= ~(1u << b);
+                    }
+                    for (unsigned t = phv; t; t &= t - 1) {
+                        const int b = __ffs((int)t) - 1;
+                        if (dirtyLab[S.lab[l5 * 32 + b]]) phv &= ~(1u << b);
                     }
                 }
+                // the rows that come back lose their prime (:324-330) and their zeros are live again: tlive == tzero & ~(slots of covered
+                // rows), so each zero's slot bit is OR-ed back (fire and forget); the row's record is ONE round trip
+                hz32[l5] = hzr;                                        // the LDS copy takes the columns that get live zeros back
+                for (unsigned t = cR & ~cRv; t; t &= t - 1) {
+                    const int r2 = l5 * 32 + __ffs((int)t) - 1;
+                    const unsigned m2 = S.zmask[r2];
+                    const uint4 cjr = *reinterpret_cast<const uint4*>(&S.cj[r2 * SPK]);
+                    const uint2 psr = *reinterpret_cast<const uint2*>(&S.pos[r2 * SPK]);
+                    S.primeColOfRow[r2] = -1;
+                    for (unsigned mm = m2; mm; mm &= mm - 1) {
+                        const int k = __ffs((int)mm) - 1;
+                        const unsigned cw = (k & 4) ? ((k & 2) ? cjr.w : cjr.z) : ((k & 2) ? cjr.y : cjr.x);
+                        const int c2 = (int)((k & 1) ? (cw >> 16) : (cw & 0xFFFFu));
+                        const unsigned ps = (((k & 4) ? psr.y : psr.x) >> ((k & 3) * 8)) & 0xFFu;
+                        atomicOr(&S.tlive[c2], 1u << ps);
+                        atomicOr(&hz32[c2 >> 5], 1u << (c2 & 31));
+                    }
+                }
+                cR = cRv; covR32[l5] = cR;
+                cC |= ph & ~phv; ph = phv;                             // step 2a for the reset components: their starred columns are covered again
+                if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);
                 S.primeColOfRow[row] = -1;
-                cR = 0; covR32[l5] = 0;
-                cC |= ph; if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);   // step 2a: every starred column is covered again
-                ph = 0;
-                hzr = hzAllr;
+                hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
                 fm = ~0u; found = false;
+                if (timing && lane == 0) atomicAdd(&S.tprof[3], (unsigned)(wall_clock64() - t_g));
+                tr(4);
                 return ++nstar == nR;                                  // step 2b
             };
+            long long t_it = timing ? wall_clock64() : 0; int it_kind = 0;   // (timing: the previous iteration's kind, 1 one event / 2 batch)
+            auto lap_it = [&]() { tr(3 + 8 * it_kind); if (timing) { const long long t = wall_clock64(); if (it_kind && lane == 0) atomicAdd(&S.tprof[it_kind], (unsigned)(t - t_it)); t_it = t; } };
             while (action == 0) {
+                lap_it(); it_kind = 0;
                 if (++n_prime > 64 * MK_MAXN * MK_MAXN) { action = 4; break; }   // safety, never reached
                 unsigned cand = hzr & ~cC & vC & fm;
                 unsigned cb = (unsigned)__ballot(cand != 0);           // (the upper half mirrors the lower one)
@@ -313,7 +407,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                     }
                 }
                 if (total >= bthr) {
-                    n_bat++;
+                    n_bat++; it_kind = 2;
                     // ---------- BATCH: up to 64 consecutive events of this sweep at once (lane = event).  Taken together are the events
                     // of the first f candidate columns such that (1) their first uncovered zero rows are pairwise different, (2) no row but
                     // possibly the last one is unstarred, (3) no column uncovered by one of them (its row's star column) that still has a
@@ -339,7 +433,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                     const unsigned m = S.zmask[row];
                     if (act) atomicMin(&S.cnt[row], lane);                 // the first event that wants a row owns it
                     const unsigned tls = S.tlive[sc >= 0 ? sc : 0];
-                    const unsigned psb = 1u << S.pos[(int)(S.starK[row] & (SPK - 1)) * MK_MAXN + row];   // (meaningless, and unused, for an unstarred row)
+                    const unsigned psb = 1u << S.pos[row * SPK + (int)(S.starK[row] & (SPK - 1))];   // (meaningless, and unused, for an unstarred row)
                     const int owner = *reinterpret_cast<volatile int*>(&S.cnt[row]);
                     const unsigned limit = (act && sc > col && (tls & ~psb)) ? (unsigned)sc : 0x7FFFFFFFu;
                     const unsigned smin = wave_min_u32_dpp(limit);
@@ -355,8 +449,8 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                         atomicAnd(&covC32[sc >> 5], ~(1u << (sc & 31)));
                         atomicOr(&S.ph32[sc >> 5], 1u << (sc & 31));
                         for (unsigned mm = m; mm; mm &= mm - 1) {          // its zeros leave the live masks
-                            const int kk = __ffs((int)mm) - 1, c2 = S.cj[kk * MK_MAXN + row];
-                            const unsigned bitv = 1u << S.pos[kk * MK_MAXN + row];
+                            const int kk = __ffs((int)mm) - 1, c2 = S.cj[row * SPK + kk];
+                            const unsigned bitv = 1u << S.pos[row * SPK + kk];
                             if (atomicAnd(&S.tlive[c2], ~bitv) == bitv) atomicAnd(&hz32[c2 >> 5], ~(1u << (c2 & 31)));
                         }
                     }
@@ -364,7 +458,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                     cR = *reinterpret_cast<volatile unsigned*>(&covR32[l5]); cC = *reinterpret_cast<volatile unsigned*>(&covC32[l5]);
                     ph = *reinterpret_cast<volatile unsigned*>(&S.ph32[l5]); hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
                     if (ia < f) {
-                        if (augment(__builtin_amdgcn_readlane(row, ia), __builtin_amdgcn_readlane(col, ia))) { action = 3; break; }
+                        if (augment(__builtin_amdgcn_readlane(row, ia), __builtin_amdgcn_readlane(col, ia), __builtin_amdgcn_readlane(ke, ia))) { action = 3; break; }
                         continue;
                     }
                     found = true;
@@ -387,15 +481,15 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                 const int kk = lane & (SPK - 1);
                 const int sc_v = S.starColOfRow[row];
                 const unsigned m_v = S.zmask[row];
-                const int c2 = S.cj[kk * MK_MAXN + row];
-                const int ps = S.pos[kk * MK_MAXN + row];
+                const int c2 = S.cj[row * SPK + kk];
+                const int ps = S.pos[row * SPK + kk];
                 const int sc = __builtin_amdgcn_readfirstlane(sc_v);
                 const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)m_v);
                 S.primeColOfRow[row] = (short)col;                     // :255 (every lane stores the same value)
                 S.primeK[row] = (unsigned char)(ent & 15);
-                n_seq++;
+                n_seq++; it_kind = 1;
                 if (sc < 0) {
-                    if (augment(row, col)) { action = 3; break; }
+                    if (augment(row, col, (int)(ent & 15))) { action = 3; break; }
                     continue;
                 }
                 // cover the row (:270): its zeros leave the live masks; uncover its star's column (:271)
@@ -424,14 +518,35 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                     fm = l5 < fw ? 0u : (l5 == fw ? (~0u << (from & 31)) : ~0u);
                 }
             }
+            lap_it();
+            tr(5);
             covC32[l5] = cC;
             if (SPEC) vseen = vnow;
-            if (lane == 0) { S.flag[1] = action; S.hkey = ~0ull; if (SPEC) S.flag[6] = vnow; }
+            if (lane == 0) { S.flag[1] = action; S.flag[3] = (lazy_ok && scratch_phase) ? 1 : 0; S.hkey = ~0ull; if (SPEC) S.flag[6] = vnow; }
+            if (scratch_phase) { cRv = cR; phv = ph; }                 // a from-scratch phase ran to its end: every component is clean
+            scratch_phase = false;
+        }
+        else if (wave == 1 && n_s5 > 0 && (mk_batch & SP_LAZY_OFF) == 0) {
+            // LAZY RESET, label upkeep (beside wavefront 0's event phase, which needs the labels only when an augmentation finds members of
+            // clean components: it waits for flag[4] == this cycle then): the zeros the last step 5 created tie components together
+            if (*reinterpret_cast<volatile int*>(&S.flag[7]) == 0) {
+                const int nu = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.uq[0]));
+                if (nu > SP_UQ) { if (lane == 0) S.flag[7] = 1; }      // more than the queue holds: the reference's full reset from here on
+                else for (int i = 0; i < nu; i++) {                    // (a request carries the labels its thread saw; a label is a column of its component, so lab[] of it is current)
+                    const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.uq[1 + i]));
+                    lab_union((int)(q >> 16), (int)(q & 0xFFFFu));
+                }
+                if (nu && lane == 0) S.uq[0] = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) *reinterpret_cast<volatile int*>(&S.flag[4]) = n_s5;
         }
         __syncthreads();
         const int action = S.flag[1];
+        if (S.flag[3]) S.dirtyLab[tid] = 0;                            // a from-scratch phase ran to its end: every component is clean (marks of this step 5 come behind the next barrier)
         if (SPEC && S.flag[6] == 1) return;                            // certified by the solver's workgroup: this run is not wanted (uniform: read behind the barrier)
-        const long long t_b = wall_clock64();
+        const long long t_b = timing ? wall_clock64() : 0;
+        tr(6);
         t_s3 += t_b - t_a;
         if (action == 3) { done = true; break; }
         if (action == 4) { status = 2; break; }
@@ -459,9 +574,11 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         }
         {
             const u64 hk = dkey(wave_min_f64_pos(h));
+            tr(7);
             if (lane == 0) atomicMin(&S.hkey, hk);
         }
         __syncthreads();
+        tr(8);
         h = dunkey(S.hkey);
         if (!(h < DBL_MAX)) { status = 1; break; }                     // the minimum lies outside the candidate lists: not applicable
         unsigned nm = 0;
@@ -473,21 +590,36 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
             nm |= (fabs(x) < DBL_EPSILON) ? (1u << k) : 0u;
         }
         if (nm != zm) {                                                // zero bits that changed: the column-side masks follow
-#pragma unroll
-            for (int k = 0; k < SPK; k++) {
-                if (((nm ^ zm) >> k) & 1) {
-                    const unsigned bitv = 1u << S.pos[k * MK_MAXN + r];
-                    if ((nm >> k) & 1) { atomicOr(&S.tzero[myc[k]], bitv); if (!rc) atomicOr(&S.tlive[myc[k]], bitv); }
-                    else { atomicAnd(&S.tzero[myc[k]], ~bitv); if (!rc) atomicAnd(&S.tlive[myc[k]], ~bitv); }
-                    atomicOr(&S.dirty32[myc[k] >> 5], 1u << (myc[k] & 31));
+            // (rare: a thread or two per step.  Columns and slots are read from the LDS records, not from the registers: indexing myc[] by a
+            // run-time k would unroll this block eight-fold and park its addresses in registers across the whole loop -- they spilled)
+            const unsigned short* cjr = &S.cj[r * SPK]; const unsigned char* psr = &S.pos[r * SPK];
+#pragma unroll 1
+            for (unsigned ch = nm ^ zm; ch; ch &= ch - 1) {
+                const int k = __ffs((int)ch) - 1;
+                const int c = cjr[k];
+                const unsigned bitv = 1u << psr[k];
+                if ((nm >> k) & 1) { atomicOr(&S.tzero[c], bitv); if (!rc) atomicOr(&S.tlive[c], bitv); }
+                else { atomicAnd(&S.tzero[c], ~bitv); if (!rc) atomicAnd(&S.tlive[c], ~bitv); }
+                atomicOr(&S.dirty32[c >> 5], 1u << (c & 31));
+                S.dirtyLab[S.lab[c]] = 1;                              // lazy reset: the component continued from an older state
+            }
+            if ((nm & ~zm) && (nm & (nm - 1))) {                       // a zero appeared in a row that holds several now: its columns are one component
+                const unsigned lf = (unsigned)S.lab[cjr[__ffs((int)nm) - 1]];
+#pragma unroll 1
+                for (unsigned mm = nm & (nm - 1); mm; mm &= mm - 1) {
+                    const unsigned lk = (unsigned)S.lab[cjr[__ffs((int)mm) - 1]];
+                    if (lk == lf) continue;
+                    const unsigned qi = atomicAdd(&S.uq[0], 1u);
+                    if (qi < SP_UQ) S.uq[1 + qi] = (lf << 16) | lk;
                 }
             }
             zm = nm; S.zmask[r] = (unsigned short)nm;
         }
         if (tid < nC && !bit_of(S.covC, tid)) S.Scol[tid] += h;
         hz_dirty = true;
+        tr(9);
         __syncthreads();
-        t_s5 += wall_clock64() - t_b;
+        if (timing) t_s5 += wall_clock64() - t_b;
     }
     __syncthreads();
     if (SPEC && !sp_wait_verdict(L, &S.flag[6])) return;               // certified there: nothing of this run is published
@@ -498,7 +630,8 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
         L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
         L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);
-        L.hdr[58] = n_bat; L.hdr[59] = n_seq;                             // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
+        if (timing) trace[0] = tr_n;
+        L.hdr[58] = n_bat; L.hdr[59] = n_seq; L.hdr[60] = (int)S.tprof[0]; L.hdr[61] = (int)S.tprof[1]; L.hdr[62] = (int)S.tprof[2]; L.hdr[63] = (int)S.tprof[3];                             // (debug: event-loop split)   // (debug: set-up ticks: total, certificate, candidate + transposed lists)
     }
     if (!post_fused || a.user || status != 0) return;
     // ================= fused after-the-fact check (see the header): every entry OUTSIDE the lists must satisfy

@@ -781,7 +781,16 @@ int mot_get_lap_stats(mot_ctx* c, int* out32)
     if (!c || !out32) return fail(MOT_ERR_ARG, "null argument");
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out32, c->assoc.lap.hdr + LAP_H_LAST, sizeof(int) * 32, hipMemcpyDeviceToHost));
-    if (getenv("MOT_LAP_DEBUG")) { int dbg[12]; HIPCHK(hipMemcpy(dbg, c->assoc.lap.hdr + 48, sizeof dbg, hipMemcpyDeviceToHost)); fprintf(stderr, "sparse event loop: %d batch iterations, %d one-event iterations\n", dbg[10], dbg[11]); fprintf(stderr, "lap debug ticks: sparse setup %d (certificate %d, lists %d) post-check + lifecycle %d | solve init %d search %d commit %d final %d tail: check %d, to done %d\n", dbg[0], dbg[5], dbg[6], dbg[9], dbg[1], dbg[2], dbg[3], dbg[4], dbg[7], dbg[8]); }
+    if (getenv("MOT_LAP_DEBUG")) { int dbg[16]; HIPCHK(hipMemcpy(dbg, c->assoc.lap.hdr + 48, sizeof dbg, hipMemcpyDeviceToHost)); fprintf(stderr, "sparse event loop: %d batch iterations, %d one-event iterations; wave-0 ticks (MOT_MK_TIMING=1): phase start %d, one-event %d, batch %d, augment %d\n", dbg[10], dbg[11], dbg[12], dbg[13], dbg[14], dbg[15]); fprintf(stderr, "lap debug ticks: sparse setup %d (certificate %d, lists %d) post-check + lifecycle %d | solve init %d search %d commit %d final %d tail: check %d, to done %d\n", dbg[0], dbg[5], dbg[6], dbg[9], dbg[1], dbg[2], dbg[3], dbg[4], dbg[7], dbg[8]); }
+    return MOT_OK;
+}
+
+// (debug) the time stamps the sparse emulation left in the dense working matrix under MOT_MK_TIMING=1: out[0] = count, then tag << 56 | ticks
+int mot_debug_assoc_trace(mot_ctx* c, long long* out, int n)
+{
+    if (!c || !out || n <= 0) return fail(MOT_ERR_ARG, "bad argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->assoc.dist, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
     return MOT_OK;
 }
 

@@ -25,7 +25,14 @@ typedef struct { int status; /* 0 ok, 1 a-posteriori check failed, 2 not applica
 
 static int cmp_cand(double a, int ja, double b, int jb) { return a < b || (a == b && ja < jb); }
 
-static int mks_run(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info, int batch)
+/* union-find over the COLUMNS of the zero graph (lazy variant): a row ties all columns it holds a zero in together */
+static int uf_find(int* p, int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+static void uf_union(int* p, unsigned char* dirty, int a, int b) { a = uf_find(p, a); b = uf_find(p, b); if (a == b) return; if (b < a) { int t = a; a = b; b = t; } p[b] = a; dirty[a] |= dirty[b]; }
+static unsigned long long mix64(unsigned long long h, unsigned long long v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h; }
+
+/* lazy: at an augmentation only the connected components of the zero graph that are DIRTY are reset (see the comment at the reset);
+ * trace (optional, n_trace entries): a hash of (row covers, column covers, primes, stars) at every step-5 entry */
+static int mks_run(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info, int batch, int lazy, unsigned long long* trace, int n_trace)
 {
     memset(info, 0, sizeof *info);
     for (int i = 0; i < nR; i++) assignment[i] = -1;
@@ -130,14 +137,27 @@ static int mks_run(const double* c, int nR, int nC, int K, double margin, int* a
             }
         }
         free(bc); free(br); free(bs);
-    } else
-    for (;;) {
-        int n = 0; for (int j = 0; j < nC; j++) n += covC[j];
-        if (n == nR) break;                                            /* step 2b (:216-237) */
-        int jumped = 0;
-        for (;;) {
-            int zerosFound = 1;
-            while (zerosFound && !jumped) {                            /* step 3 (:240-280) */
+    } else {
+        /* LAZY RESET (lazy != 0; what the device runs since round 4).  Between two step 5s the connected components of the zero
+         * graph (columns tied together by every row that holds zeros in them) evolve independently of each other: the sweep visits
+         * columns in ascending order and passes repeat while anything happened, so what a component does in pass p depends on its
+         * own state only.  After an augmentation the reference uncovers every row and re-grows its whole alternating forest from
+         * scratch (:324-334, :192-213).  For a component that (1) was grown from scratch in a phase that ran until nothing was left
+         * to do, and (2) has had no zero appear or vanish and no star change since, that re-growth reproduces covers and primes
+         * exactly -- so it is skipped.  Everything else is DIRTY and is reset: the component of the augmenting path, components
+         * whose zero masks a step 5 changed (they continued from an older state; the reference re-grows them in sweep order over
+         * the NEW zeros, which may prime other columns), and components reset in a phase that was itself cut short by an
+         * augmentation.  Components only ever merge here (a vanished zero does not split them): resetting a clean component
+         * with a dirty one is exact, just not minimal. */
+        int* par = malloc(sizeof(int) * (size_t)nC); unsigned char* dirty = malloc((size_t)nC);
+        for (int j = 0; j < nC; j++) { par[j] = j; dirty[j] = 1; }         /* phase 0 grows everything from scratch */
+        for (int r = 0; r < nR; r++) { int first = -1; for (int k = 0; k < K; k++) if (ISZ(r, k)) { if (first < 0) first = cj[r * K + k]; else uf_union(par, dirty, first, cj[r * K + k]); } }
+        int nstar = 0; for (int j = 0; j < nC; j++) nstar += covC[j];
+        int scratch_phase = 1;                                             /* the running phase started from a reset (or is phase 0) */
+        int tn = 0;
+        while (nstar < nR) {                                               /* step 2b (:216-237) */
+            int jumped = 0, zerosFound = 1;
+            while (zerosFound && !jumped) {                                /* step 3 (:240-280) */
                 zerosFound = 0;
                 for (int col = 0; col < nC && !jumped; col++) {
                     if (covC[col]) continue;
@@ -145,31 +165,55 @@ static int mks_run(const double* c, int nR, int nC, int K, double margin, int* a
                         const int r = trow[t];
                         if (covR[r] || !ISZ(r, tk[t])) continue;
                         primeC[r] = col; info->primes++;
-                        if (starC[r] < 0) {                            /* step 4 (:283-334) */
+                        if (starC[r] < 0) {                                /* step 4 (:283-334) */
                             info->aug++;
                             int cr = r, cc = col;
                             for (;;) { const int old_r = starR[cc]; starC[cr] = cc; starR[cc] = cr; if (old_r < 0) break; cc = primeC[old_r]; cr = old_r; }
-                            for (int q = 0; q < nR; q++) { primeC[q] = -1; covR[q] = 0; }
-                            for (int q = 0; q < nC; q++) covC[q] = starR[q] >= 0;      /* step 2a (:192-213) */
-                            jumped = 1;
+                            if (!lazy) {
+                                for (int q = 0; q < nR; q++) { primeC[q] = -1; covR[q] = 0; }
+                                for (int q = 0; q < nC; q++) covC[q] = starR[q] >= 0;      /* step 2a (:192-213) */
+                            } else {
+                                dirty[uf_find(par, col)] = 1;              /* the path lies in one component (its edges are zeros) */
+                                primeC[r] = -1;
+                                for (int q = 0; q < nR; q++) if (covR[q] && dirty[uf_find(par, primeC[q])]) { primeC[q] = -1; covR[q] = 0; }
+                                for (int q = 0; q < nC; q++) if (dirty[uf_find(par, q)]) covC[q] = starR[q] >= 0;
+                            }
+                            nstar++; jumped = 1; scratch_phase = 1;
                         } else { covR[r] = 1; covC[starC[r]] = 0; zerosFound = 1; }
                         break;
                     }
                 }
             }
-            if (jumped) break;
-            double h = DBL_MAX;                                        /* step 5 (:337-368) */
+            if (jumped) continue;
+            if (trace && tn < n_trace) {                                   /* state at step-5 entry */
+                unsigned long long h = 1469598103934665603ull;
+                for (int q = 0; q < nR; q++) h = mix64(h, ((unsigned long long)covR[q] << 40) ^ ((unsigned long long)(unsigned)(primeC[q] + 1) << 20) ^ (unsigned)(starC[q] + 1));
+                for (int q = 0; q < nC; q++) h = mix64(h, covC[q]);
+                trace[tn] = h;
+            }
+            tn++;
+            if (lazy && scratch_phase) memset(dirty, 0, (size_t)nC);      /* a from-scratch phase ran to its end: everything is clean */
+            scratch_phase = 0;
+            double h = DBL_MAX;                                            /* step 5 (:337-368) */
             for (int r = 0; r < nR; r++) if (!covR[r]) for (int k = 0; k < K; k++) if (!covC[cj[r * K + k]] && d[r * K + k] < h) h = d[r * K + k];
-            if (h == DBL_MAX) { info->status = 1; goto out; }          /* no candidate entry among uncovered x uncovered: the minimum lies outside the lists */
-            for (int r = 0; r < nR; r++) for (int k = 0; k < K; k++) {
-                double x = d[r * K + k];
-                if (covR[r]) x += h;
-                if (!covC[cj[r * K + k]]) x -= h;
-                d[r * K + k] = x;
+            if (h == DBL_MAX) { info->status = 1; free(par); free(dirty); goto out; }   /* no candidate entry among uncovered x uncovered: the minimum lies outside the lists */
+            for (int r = 0; r < nR; r++) {
+                int changed = 0;
+                for (int k = 0; k < K; k++) {
+                    const int was = ISZ(r, k);
+                    double x = d[r * K + k];
+                    if (covR[r]) x += h;
+                    if (!covC[cj[r * K + k]]) x -= h;
+                    d[r * K + k] = x;
+                    if (was != ISZ(r, k)) { changed = 1; if (lazy) dirty[uf_find(par, cj[r * K + k])] = 1; }
+                }
+                if (lazy && changed) { int first = -1; for (int k = 0; k < K; k++) if (ISZ(r, k)) { if (first < 0) first = cj[r * K + k]; else uf_union(par, dirty, first, cj[r * K + k]); } }
             }
             for (int j = 0; j < nC; j++) if (!covC[j]) S[j] += h;
             info->s5++;
         }
+        info->iters = tn;
+        free(par); free(dirty);
     }
     /* a-posteriori check of every entry outside the candidate lists */
     for (int i = 0; i < nR && !info->status; i++) {
@@ -188,6 +232,8 @@ out:
     return info->status;
 }
 
-int mks_solve(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info) { return mks_run(c, nR, nC, K, margin, assignment, info, 0); }
+int mks_solve(const double* c, int nR, int nC, int K, double margin, int* assignment, mks_info* info) { return mks_run(c, nR, nC, K, margin, assignment, info, 0, 0, NULL, 0); }
+/* the same run with the lazy reset (mode 1) or the reference's full reset (mode 0), recording a hash of the machine's state at every step-5 entry */
+int mks_solve_traced(const double* c, int nR, int nC, int K, double margin, int lazy, int* assignment, mks_info* info, unsigned long long* trace, int n_trace) { return mks_run(c, nR, nC, K, margin, assignment, info, 0, lazy, trace, n_trace); }
 /* same run with the event loop taken `batch` (<= 64 on the device) events at a time where that is provably order-neutral */
-int mks_solve_batched(const double* c, int nR, int nC, int K, double margin, int batch, int* assignment, mks_info* info) { return mks_run(c, nR, nC, K, margin, assignment, info, batch < 1 ? 1 : batch); }
+int mks_solve_batched(const double* c, int nR, int nC, int K, double margin, int batch, int* assignment, mks_info* info) { return mks_run(c, nR, nC, K, margin, assignment, info, batch < 1 ? 1 : batch, 0, NULL, 0); }

@@ -49,8 +49,8 @@ print("REGRESSIONS_OK", used)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"MOT_MK_BATCH": "0"}, {"MOT_LAP_FAST": "0"}, {"MOT_LAP_MIN": "1", "MOT_LAP_DENSE": "1"}],
-                         ids=["default", "one_event_loop", "fast_path_off", "dense_solver_forced"])
+@pytest.mark.parametrize("env", [{}, {"MOT_MK_BATCH": "0"}, {"MOT_MK_LAZY": "0"}, {"MOT_LAP_FAST": "0"}, {"MOT_LAP_MIN": "1", "MOT_LAP_DENSE": "1"}],
+                         ids=["default", "one_event_loop", "full_reset", "fast_path_off", "dense_solver_forced"])
 def test_device_reproduces_regression_fixtures(env):
     out = subprocess.run([sys.executable, "-c", _CODE], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert "REGRESSIONS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

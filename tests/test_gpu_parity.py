@@ -528,13 +528,15 @@ def test_munkres_helper_workgroups_subprocess(helpers):
     _run_variant({"MOT_MUNKRES_HELPERS": helpers})
 
 
-@pytest.mark.parametrize("mode", ["all_sizes", "all_sizes_one_event_loop", "off"])
+@pytest.mark.parametrize("mode", ["all_sizes", "all_sizes_one_event_loop", "all_sizes_full_reset", "off"])
 def test_lap_fast_path_subprocess(mode):
     """assignment fast path (lap_kernels.hip: exact sparse solver + uniqueness certificate) forced on for EVERY problem size
     (MOT_LAP_MIN=1) and switched off (MOT_LAP_FAST=0): bit-identical assignments and cost either way, and with it on both
     outcomes must occur -- certified launches (emulation skipped) and tied optima (order-exact emulation ran)."""
     # all_sizes_one_event_loop: the sparse emulation's event loop without batching (MOT_MK_BATCH=0): one step-3 event per iteration
-    env = {"MOT_LAP_FAST": "0"} if mode == "off" else ({"MOT_LAP_MIN": "1"} if mode == "all_sizes" else {"MOT_LAP_MIN": "1", "MOT_MK_BATCH": "0"})
+    # all_sizes_full_reset: the sparse emulation with the reference's full reset after every augmentation (MOT_MK_LAZY=0) instead of the lazy one
+    env = {"off": {"MOT_LAP_FAST": "0"}, "all_sizes": {"MOT_LAP_MIN": "1"}, "all_sizes_one_event_loop": {"MOT_LAP_MIN": "1", "MOT_MK_BATCH": "0"},
+           "all_sizes_full_reset": {"MOT_LAP_MIN": "1", "MOT_MK_LAZY": "0"}}[mode]
     cum = _run_variant(env)
     if mode == "off":
         assert sum(cum) == 0, cum

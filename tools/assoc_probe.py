@@ -2,6 +2,7 @@
 """Per-frame association statistics of the device-resident loop on a synthetic stream (GPU box).
 usage: assoc_probe.py N FRAMES [MISS_PCT FP_PCT]"""
 import os, sys
+os.environ.setdefault("MOT_MK_TIMING", "1")   # per-cycle clock reads inside the emulation (off by default: they cost a few % of its time)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
