@@ -530,10 +530,12 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int 
 // certified frame it is told to stop (it polls the verdict word once per step-5 cycle) and one launch of the chain is gone.  Exactly one
 // of the two commits the frame: the solver's workgroup iff it certifies, else the emulation iff its own check accepts the run; the
 // emulation publishes nothing before it has read the verdict.
+// TIMING: the emulation's instrumented instantiation (MOT_MK_TIMING=1, probe tools only: its clock reads cost the event loop 6 % even when idle)
+template <bool TIMING>
 __global__ void __launch_bounds__(MK_THREADS) lap_solve2_kernel(AssocArgs a, LifeArgs life, int mk_batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
-    if (blockIdx.x == 1) { mk_sparse_run<true>(a, mk_batch, 1, life, lap_raw); return; }
+    if (blockIdx.x == 1) { mk_sparse_run<true, TIMING>(a, mk_batch, 1, life, lap_raw); return; }
     const int verdict = lap_solve_run(a, 1, life, lap_raw);
     __threadfence();                                                   // everything this workgroup wrote (duals, header, lifecycle) before the verdict
     __syncthreads();
@@ -618,7 +620,9 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     if (attr_dev != dev) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapShared));
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared)));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared)));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared)));
         if (e != hipSuccess) return e;
         attr_dev = dev;
     }
@@ -634,7 +638,9 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
     const int fused = (fuse && !a.user) ? 1 : 0;
     if (fused && two_block) {
-        hipLaunchKernelGGL(lap_solve2_kernel, dim3(2), dim3(MK_THREADS), sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared), s, a, life, mk_batch);
+        const size_t lds2 = sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared);
+        if (mk_batch & SP_TIMING) hipLaunchKernelGGL(lap_solve2_kernel<true>, dim3(2), dim3(MK_THREADS), lds2, s, a, life, mk_batch);
+        else hipLaunchKernelGGL(lap_solve2_kernel<false>, dim3(2), dim3(MK_THREADS), lds2, s, a, life, mk_batch);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a, fused, life);

@@ -31,10 +31,11 @@ namespace {
 // accepted run is committed here (lifecycle step), so a tie frame needs no further kernel of the chain.  The body lives in
 // mk_sparse_body.h: the solver's launch runs it as its second workgroup (lap_kernels.hip); this kernel is the stand-alone form (caller
 // matrices, streams with the dense solver armed, MOT_LAP_FUSED=0).
+template <bool TIMING>
 __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int mk_batch, int post_fused, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_raw[];
-    mk_sparse_run<false>(a, mk_batch, post_fused, life, sp_raw);
+    mk_sparse_run<false, TIMING>(a, mk_batch, post_fused, life, sp_raw);
 }
 
 // every entry outside the candidate lists against the final S_j (see the header); grid of 64 x 64 tiles
@@ -94,7 +95,9 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, c
     static int attr_dev = -1;
     int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
     if (attr_dev != dev) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mk_sparse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SpShared));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mk_sparse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SpShared));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mk_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SpShared));
         if (e != hipSuccess) return e;
         attr_dev = dev;
     }
@@ -104,7 +107,8 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, c
     static int fuse = -1;
     if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
     const int post_fused = (fuse && !a.user) ? 1 : 0;
-    hipLaunchKernelGGL(mk_sparse_kernel, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
+    if (batch & SP_TIMING) hipLaunchKernelGGL(mk_sparse_kernel<true>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
+    else hipLaunchKernelGGL(mk_sparse_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
     if (!post_fused) hipLaunchKernelGGL(mk_postcheck_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     return hipGetLastError();
 }

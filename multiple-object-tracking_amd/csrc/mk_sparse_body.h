@@ -10,11 +10,17 @@
 
 namespace assoc {
 
+// A `volatile` access through a generic pointer is NOT an LDS instruction: hipcc keeps it a FLAT load / store with sc0 sc1 (address-space
+// inference skips volatile accesses).  Where a value another wavefront (or another lane, through an LDS atomic) wrote has to be read again, a
+// compiler-level fence in front of a plain access does it: the access stays ds_read / ds_write, and the hardware executes one wavefront's LDS
+// instructions in order.
+#define LDS_REREAD() asm volatile("" ::: "memory")
+
 #define SPK LAP_K
 #define SP_TLS 32               /* slots per column in the transposed lists; a column wanted by more rows: not applicable */
 #define SP_UQ 64                /* union requests one step 5 can queue; more: the run falls back to the reference's full reset */
 #define SP_LAZY_OFF 0x40000000  /* flag in the mk_batch argument: MOT_MK_LAZY=0 */
-#define SP_TIMING   0x20000000  /* flag in the mk_batch argument: MOT_MK_TIMING=1 -- per-cycle clock reads for the probe tools (3 x s_memrealtime per step-5 cycle) */
+#define SP_TIMING   0x20000000  /* flag in the mk_batch argument: MOT_MK_TIMING=1 -- the host launches the instrumented instantiation (clock reads and a time-stamp trace for the probe tools) */
 #define SP_CX_MAX 16            /* rows with several zeros at the start that the set-up ties together one by one; more: one component */
 
 struct SpShared {
@@ -80,7 +86,7 @@ __device__ inline bool sp_wait_verdict(const LapWs& L, int* flag)
     }
 }
 
-template <bool SPEC>
+template <bool SPEC, bool TIMING>
 __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, const LifeArgs& life, unsigned char* sp_raw)
 {
     SpShared& S = *reinterpret_cast<SpShared*>(sp_raw);
@@ -267,16 +273,19 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     // it is skipped; everything else is DIRTY and reset.  Labels: lab[c] = smallest column of c's component, flat, merged by this
     // wavefront when a step 5 creates a zero (components never split: exact, just not minimal). ----
     bool lazy_ok = (mk_batch & SP_LAZY_OFF) == 0;
-    const bool timing = (mk_batch & SP_TIMING) != 0;
+    // TIMING is a template parameter: even switched off at run time the clock reads and their branches cost the event loop 6 % (measured);
+    // the instrumented instantiation is launched only under MOT_MK_TIMING=1 (probe tools)
+    constexpr bool timing = TIMING;
     // (MOT_MK_TIMING) time stamps of thread 0 along the cycle, in the dense working matrix (unused by this tier): tag << 56 | ticks
     long long* trace = reinterpret_cast<long long*>(a.ws.dist); int tr_n = 1;
     auto tr = [&](int tag) { if (timing && tid == 0 && tr_n < 8190) trace[tr_n++] = ((long long)tag << 56) | (wall_clock64() & 0xFFFFFFFFFFFFFFll); };
     bool scratch_phase = true;                                         // the running phase started from a reset (or is phase 0)
-    volatile unsigned char* dirtyLab = S.dirtyLab;
+    unsigned char* dirtyLab = S.dirtyLab;
     // merge the components of the columns ca, cb: every column labelled max(la, lb) gets min(la, lb)
     auto lab_union = [&](int ca, int cb) {                             // wavefront 0, uniform arguments
-        const int la = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.lab[ca]));
-        const int lb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.lab[cb]));
+        LDS_REREAD();
+        const int la = __builtin_amdgcn_readfirstlane(S.lab[ca]);
+        const int lb = __builtin_amdgcn_readfirstlane(S.lab[cb]);
         if (la == lb) return;
         const int lo = min(la, lb), hi = max(la, lb);
         int4* l4 = reinterpret_cast<int4*>(S.lab);
@@ -310,7 +319,8 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
             if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
                 // every lane owns word l5 of the masks (the mirror lane recomputes the same), so no cross-lane traffic is needed.
                 // ONE round trip: the dirty word, the union requests' header (count + first request) and the label array
-                unsigned dw = *reinterpret_cast<volatile unsigned*>(&S.dirty32[l5]);
+                LDS_REREAD();
+                unsigned dw = S.dirty32[l5];
                 for (; dw; dw &= dw - 1) {
                     const int b = __ffs((int)dw) - 1, c = l5 * 32 + b;
                     const unsigned bit = 1u << b;
@@ -346,9 +356,10 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                 // stays covered has no zero in a column touched here.  (Both half-waves hold the same words and do the same, idempotent, work.)
                 if (!lazy_ok) { cRv = 0; phv = 0; }                    // the reference's full reset
                 else if (__ballot((cRv | phv) != 0)) {
-                    while (*reinterpret_cast<volatile int*>(&S.flag[4]) != n_s5) __builtin_amdgcn_s_sleep(1);   // wavefront 1 has merged this cycle's labels
+                    for (;;) { LDS_REREAD(); if (S.flag[4] == n_s5) break; __builtin_amdgcn_s_sleep(1); }   // wavefront 1 has merged this cycle's labels
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    if (*reinterpret_cast<volatile int*>(&S.flag[7])) { lazy_ok = false; cRv = 0; phv = 0; }
+                    LDS_REREAD();
+                    if (S.flag[7]) { lazy_ok = false; cRv = 0; phv = 0; }
                     for (unsigned t = cRv; t; t &= t - 1) {
                         const int b = __ffs((int)t) - 1;
                         const int pc = S.primeColOfRow[l5 * 32 + b];
@@ -381,7 +392,8 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                 cC |= ph & ~phv; ph = phv;                             // step 2a for the reset components: their starred columns are covered again
                 if (last >= 0 && l5 == (last >> 5)) cC |= 1u << (last & 31);
                 S.primeColOfRow[row] = -1;
-                hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
+                LDS_REREAD();
+                hzr = hz32[l5];
                 fm = ~0u; found = false;
                 if (timing && lane == 0) atomicAdd(&S.tprof[3], (unsigned)(wall_clock64() - t_g));
                 tr(4);
@@ -424,7 +436,8 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                     if (lane < 32) { unsigned t = cand; int o = before; while (t && o < 64) { S.blist[o++] = (unsigned short)(lane * 32 + __ffs((int)t) - 1); t &= t - 1; } }
                     const int ncand = min(total, 64);
                     const bool act = lane < ncand;
-                    const int col = act ? (int)*reinterpret_cast<volatile unsigned short*>(&S.blist[lane]) : 0;
+                    LDS_REREAD();
+                    const int col = act ? (int)S.blist[lane] : 0;
                     const unsigned tlv = S.tlive[col];
                     const unsigned e = S.tl[col * SP_TLS + (tlv ? __ffs((int)tlv) - 1 : 0)];
                     if (__ballot(act && tlv == 0)) { action = 4; break; }   // hz out of step with the masks: cannot happen
@@ -434,7 +447,8 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                     if (act) atomicMin(&S.cnt[row], lane);                 // the first event that wants a row owns it
                     const unsigned tls = S.tlive[sc >= 0 ? sc : 0];
                     const unsigned psb = 1u << S.pos[row * SPK + (int)(S.starK[row] & (SPK - 1))];   // (meaningless, and unused, for an unstarred row)
-                    const int owner = *reinterpret_cast<volatile int*>(&S.cnt[row]);
+                    LDS_REREAD();
+                    const int owner = S.cnt[row];
                     const unsigned limit = (act && sc > col && (tls & ~psb)) ? (unsigned)sc : 0x7FFFFFFFu;
                     const unsigned smin = wave_min_u32_dpp(limit);
                     const u64 stop = __ballot(act && ((unsigned)col > smin || owner != lane));
@@ -455,8 +469,9 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
                         }
                     }
                     n_prime += f - 1;
-                    cR = *reinterpret_cast<volatile unsigned*>(&covR32[l5]); cC = *reinterpret_cast<volatile unsigned*>(&covC32[l5]);
-                    ph = *reinterpret_cast<volatile unsigned*>(&S.ph32[l5]); hzr = *reinterpret_cast<volatile unsigned*>(&hz32[l5]);
+                    LDS_REREAD();
+                    cR = covR32[l5]; cC = covC32[l5];
+                    ph = S.ph32[l5]; hzr = hz32[l5];
                     if (ia < f) {
                         if (augment(__builtin_amdgcn_readlane(row, ia), __builtin_amdgcn_readlane(col, ia), __builtin_amdgcn_readlane(ke, ia))) { action = 3; break; }
                         continue;
@@ -529,17 +544,19 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         else if (wave == 1 && n_s5 > 0 && (mk_batch & SP_LAZY_OFF) == 0) {
             // LAZY RESET, label upkeep (beside wavefront 0's event phase, which needs the labels only when an augmentation finds members of
             // clean components: it waits for flag[4] == this cycle then): the zeros the last step 5 created tie components together
-            if (*reinterpret_cast<volatile int*>(&S.flag[7]) == 0) {
-                const int nu = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.uq[0]));
+            LDS_REREAD();
+            if (S.flag[7] == 0) {
+                const int nu = __builtin_amdgcn_readfirstlane((int)S.uq[0]);
                 if (nu > SP_UQ) { if (lane == 0) S.flag[7] = 1; }      // more than the queue holds: the reference's full reset from here on
                 else for (int i = 0; i < nu; i++) {                    // (a request carries the labels its thread saw; a label is a column of its component, so lab[] of it is current)
-                    const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&S.uq[1 + i]));
+                    const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)S.uq[1 + i]);
                     lab_union((int)(q >> 16), (int)(q & 0xFFFFu));
                 }
                 if (nu && lane == 0) S.uq[0] = 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) *reinterpret_cast<volatile int*>(&S.flag[4]) = n_s5;
+            if (lane == 0) S.flag[4] = n_s5;
+            LDS_REREAD();
         }
         __syncthreads();
         const int action = S.flag[1];
