@@ -217,6 +217,24 @@ def main():
     ap.add_argument("--debug-assoc", action="store_true", help="print Munkres step counters / phase times per profiled frame to stderr")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as CHILD processes of a parent that has not touched
+    # the GPU (no torch import, no HIP call -- a process that has initialised the GPU must never exec or be replaced), relay rank 0's
+    # JSON line and hand the children's exit code on.  Under torch.distributed.run (WORLD_SIZE set) this branch is skipped.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MOT_BENCH_SELF_LAUNCHED="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for ln in proc.stdout.splitlines():
+            if ln.startswith("{"):
+                print(ln, flush=True)
+        raise SystemExit(proc.returncode)
+
     import torch
     import torch.distributed as dist
     import mot_amd
@@ -226,8 +244,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it as `python bench.py --gpus N` or under "
+                         "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # MOT_BENCH_BACKEND=gloo is a smoke-test mode for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the

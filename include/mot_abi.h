@@ -184,13 +184,19 @@ int mot_step_finish(mot_ctx* ctx, const void* gathered_boxes_dev, const bbox_t* 
  * Same per-frame semantics as mot_step_frame, but detections come from device
  * memory, nothing is copied back and no host synchronisation happens: the
  * frame's kernels are only enqueued.  Lifecycle (delete/spawn) is executed on
- * device as well.  mot_live_count() synchronises and returns the track count. */
+ * device as well.  mot_live_count() synchronises and returns the track count.
+ * Lifetime of the inputs: frame_dev and dets_dev are read by kernels on the context's stream AND by a detection-feature launch on a
+ * second stream of the context; every device-resident step call ends by ordering the context's stream behind that launch, so work the
+ * caller enqueues on mot_ctx_stream() AFTER the call (the next frame's upload into the same buffer, an overlay, ...) may overwrite
+ * both.  Touching them from any other stream needs mot_ctx_sync() (or an event recorded on the context's stream behind the call). */
 int mot_step_frame_device(mot_ctx* ctx, const void* frame_dev, const void* dets_dev /* bbox_t[nD] */, int nD);
 /* The same step with one frame of look-ahead: when the NEXT frame and its detection list are already in device memory (the reference's
  * detector thread runs ahead of the tracker thread through 64-slot rings, td.cpp:56-80,218-223), their detection features -- which
  * depend on that frame and its boxes only -- are computed beside THIS frame's association chain.  Results are identical to
  * mot_step_frame_device; the next call must pass the same pointers and count to benefit (anything else is computed as usual).
- * next_frame_dev / next_dets_dev may be null (end of stream).  Both frames' memory must stay valid until their step has executed. */
+ * next_frame_dev / next_dets_dev may be null (end of stream).  Both frames' memory must stay valid until their step has executed:
+ * the announced frame and list are read from the moment THIS call is enqueued until the call that processes them has ended (in stream
+ * order, as above); announcing one frame and then passing another is allowed and costs one extra stream wait. */
 int mot_step_frame_device_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
                                 const void* next_frame_dev, const void* next_dets_dev, int next_nD);
 int mot_step_begin_device(mot_ctx* ctx, const void* frame_dev, void** local_boxes_dev, int* slots_per_rank);
@@ -223,9 +229,13 @@ typedef struct {            /* bit-identical to top/cnntype.h:49-54 */
 int mot_yolo_postprocess(mot_ctx* ctx, const float* head0_dev, const float* head1_dev, const float* head2_dev, int tensor_h, int tensor_w,
                          int num_classes, int image_h, int image_w, const yolo3_options_t* opt, bbox_t* dets_dev_out, int cap, int* n_dev_out,
                          bbox_chain_t* host_chain_out);
+/* Candidates above obj_thresh beyond the workspace (4096) are dropped in arrival order, which the reference's unbounded vector never does
+ * (yolo3.cpp:176-201): the count is latched on the device.  Synchronises; MOT_ERR_CAPACITY if any call of this context dropped candidates
+ * (mot_yolo_postprocess reports it itself when host_chain_out is given).  dropped_candidates may be NULL. */
+int mot_yolo_status(mot_ctx* ctx, int* dropped_candidates);
 
 /* ---- overlay: the tracker thread's drawing step (td.cpp:647-733) ----------------
- * Three nested rectangle outlines per track (drawRect, top/drawlib.c:97-151) in colormap[hashcolor(tid) & 255] (td.cpp:295-304,
+ * Three nested rectangle outlines per track (drawRect, top/drawlib.c:97-151) in colormap[hashcolor(tid + 1) & 255] (td.cpp:295-304,
  * 620, 655-699), drawn into a 1280x720x3 frame in device memory, later tracks over earlier ones.  mot_overlay_draw takes host
  * arrays (any context); mot_overlay_live draws the live list of the device-resident loop without any copy.  Enqueued on the
  * context's stream; the frame must not be the input of a frame step that is still in flight. */

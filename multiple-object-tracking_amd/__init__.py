@@ -291,6 +291,12 @@ class MotContext:
             b = ch.bbox[i]; out[i] = (b.l, b.t, b.b, b.r, b.type, b.score)
         return out
 
+    def yolo_status(self) -> int:
+        """candidates dropped for lack of workspace since the context was created (synchronises); raises MotError (MOT_ERR_CAPACITY) if any"""
+        n = C.c_int(0)
+        self._chk(self.lib.mot_yolo_status(self._h, C.byref(n)))
+        return n.value
+
     # ---- overlay (td.cpp:647-733) ----
     def overlay_draw(self, frame_dev: int, boxes, tids):
         b = boxes_array(boxes); t = np.ascontiguousarray(tids, np.uint32)

@@ -17,6 +17,7 @@
 //     as self-tagged 8-byte granules (mk_helper_loop, assoc_common.h);
 //   * below 65 lines the Munkres workgroup computes costs, minima and bitmaps itself (mk_fused_cost).
 #include "assoc_common.h"
+#include "mot_env.h"
 #include "dl_lifecycle.h"
 #include <stdlib.h>
 
@@ -1044,11 +1045,8 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // Assignment fast path (lap_kernels.hip): exact sparse solver + uniqueness certificate in front of the emulation; rows <=
     // columns only (the only shape td.cpp:462-469 produces).  MOT_LAP_FAST=0 switches it off, MOT_LAP_MIN sets the smallest
     // problem (lines) it is used for -- below that the emulation of a whole frame costs less than the three extra launches.
-    static int lap_min = -1;
-    if (lap_min < 0) {
-        const char* e0 = getenv("MOT_LAP_FAST"); const char* e1 = getenv("MOT_LAP_MIN");
-        lap_min = (e0 && atoi(e0) == 0) ? (1 << 30) : (e1 ? (atoi(e1) > 1 ? atoi(e1) : 1) : MK_LAP_MIN_LINES);
-    }
+    const mot_impl::EnvSwitches& E = mot_impl::env();                   // the MOT_* switches, read once per process (mot_env.h)
+    const int lap_min = E.lap_min < 0 ? MK_LAP_MIN_LINES : E.lap_min;
     const bool lap = ws.lap.ccol && maxR > 0 && maxR <= maxC && lines >= lap_min;
     // scheduling hint left by the final kernel of earlier launches in pinned host memory, read without synchronisation (stale by a
     // frame or two: it only picks grids, never results): the stream keeps needing the dense emulation / the dense solver
@@ -1064,8 +1062,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             // three launches return at once when the sparse solver succeeded, but they are not even submitted unless one of the last
             // 512 launches needed them (the final kernel's hint in pinned host memory, read without synchronisation) or the number
             // of detections has just changed.  MOT_LAP_DENSE=0 never, =1 always.
-            static int dense_mode = -1;
-            if (dense_mode < 0) { const char* ev = getenv("MOT_LAP_DENSE"); dense_mode = ev ? (atoi(ev) ? 1 : 0) : 2; }
+            const int dense_mode = E.dense_mode;
             bool want_dense = dense_mode == 1;
             if (dense_mode == 2 && ws.dense_hint) {
                 volatile int* h = ws.dense_hint;                       // [0] device-written hint bits, [1] host-side countdown, [2] last nD,
@@ -1078,10 +1075,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             }
             // Box costs without the dense solver in between: the sparse emulation rides in the solver's launch as its second workgroup
             // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
-            static int two_block_on = -1, mk_batch_on = -1, fuse_on = -1;
-            if (two_block_on < 0) { const char* ev = getenv("MOT_LAP_TWO_BLOCK"); two_block_on = (ev && atoi(ev) == 0) ? 0 : 1; }
-            if (mk_batch_on < 0) { const char* ev = getenv("MOT_MK_BATCH"); mk_batch_on = (ev ? atoi(ev) : 1) & 0xFFFF; const char* lz = getenv("MOT_MK_LAZY"); if (lz && atoi(lz) == 0) mk_batch_on |= 0x40000000; const char* tm = getenv("MOT_MK_TIMING"); if (tm && atoi(tm)) mk_batch_on |= 0x20000000; }   // 0: one event per iteration; n > 1: batch threshold (default 3)
-            if (fuse_on < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+            const int two_block_on = E.two_block, mk_batch_on = E.mk_batch, fuse_on = E.lap_fused;   // MOT_LAP_TWO_BLOCK / MOT_MK_BATCH, MOT_MK_LAZY, MOT_MK_TIMING / MOT_LAP_FUSED
             const bool two_block = two_block_on && fuse_on && !a.user && !want_dense;
             e = launch_lap_front(a, gR, gC, s, ev_mid, life, two_block, mk_batch_on); if (e != hipSuccess) return e;
             ev_mid = nullptr;
@@ -1090,8 +1084,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             // working matrix + bitmaps for the dense emulation: chip-wide (lazy: every workgroup checks the verdict and leaves) for caller
             // matrices and for streams whose recent frames needed it; otherwise the final kernel prepares them itself if it has to
             hinted_now = ws.dense_hint && ((*reinterpret_cast<volatile int*>(ws.dense_hint) & 1) != 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[1] > 0 || reinterpret_cast<volatile int*>(ws.dense_hint)[6] > 0);
-            static int helpers_forced = -1;
-            if (helpers_forced < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers_forced = (ev && atoi(ev)) ? 1 : 0; }
+            const int helpers_forced = E.helpers == 1 ? 1 : 0;
             prep_in_kernel = !a.user && !hinted_now && !helpers_forced;
             if (!prep_in_kernel) hipLaunchKernelGGL(assoc_sub_kernel, dim3(gR, gC), dim3(256), 0, s, a, 1);
         }
@@ -1101,22 +1094,12 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
         }
     }
     if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }   // cost kernels submitted, the Munkres kernel comes next
-    static int attr_dev = -1;                                          // hipFuncSetAttribute is per device
-    int cur_dev = 0; e = hipGetDevice(&cur_dev); if (e != hipSuccess) return e;
-    const bool attr_set = attr_dev == cur_dev;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(munkres_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkShared));
-        if (e != hipSuccess) return e;
-        attr_dev = cur_dev;
-    }
+    e = mot_impl::func_lds_once(reinterpret_cast<const void*>(munkres_kernel<false>), (int)sizeof(MkShared)); if (e != hipSuccess) return e;
+    e = mot_impl::func_lds_once(reinterpret_cast<const void*>(munkres_kernel<true>), (int)sizeof(MkShared)); if (e != hipSuccess) return e;
     // Step-5 helper workgroups (16 more CUs stream the matrix; two cross-CU hand-offs per step 5) pay off only when
     // step 5 moves a lot of data: dense hard problems beyond ~512 lines.  MOT_MUNKRES_HELPERS=1 forces them on for
     // every problem above 256 lines, =0 off; default: above MK_HELP_MIN lines.
-    static int helpers = -1;
-    static int force_cov = 0;                                          // MOT_MUNKRES_HELPERS=2: forced on AND the controller reads the per-row COVBITS granules (test hook)
-    if (helpers < 0) { const char* ev = getenv("MOT_MUNKRES_HELPERS"); helpers = ev ? (atoi(ev) ? 1 : 0) : 2; force_cov = (ev && atoi(ev) == 2) ? 1 : 0; }
+    const int helpers = E.helpers, force_cov = E.force_cov;             // MOT_MUNKRES_HELPERS=2: forced on AND the controller reads the per-row COVBITS granules (test hook)
     // behind the fast path the dense emulation is the rare last resort: one workgroup, not the 1 + 128 workgroup helper grid
     // (whose launch alone costs more than the common case's whole final kernel)
     // ... unless the stream keeps needing it (detector misses + false positives force far matches no tier can certify): the final

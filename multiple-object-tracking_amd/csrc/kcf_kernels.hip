@@ -16,6 +16,7 @@
 // reference, including its rcpps/rsqrtps approximations (table emulation).
 // The DFTs are free to contract (FFTW's own rounding is not reproducible).
 #include "mot_dev.h"
+#include "mot_env.h"
 #include <hip/hip_ext.h>
 #include "bin_thresholds.inc"
 
@@ -1430,15 +1431,10 @@ size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats
 template <typename K>
 static hipError_t set_lds_attr(K kern, size_t bytes)
 {
-    // once per kernel symbol AND device: allow the full 160 KB of a gfx950 CU as dynamic LDS
-    static const void* done[64]; static int done_dev[64]; static int ndone = 0;
+    // once per kernel symbol AND device (mot_env.h: a mutex-guarded table, several tracker threads / devices per process): allow the full
+    // 160 KB of a gfx950 CU as dynamic LDS
     if (bytes <= 64 * 1024) return hipSuccess;
-    const void* key = reinterpret_cast<const void*>(kern);
-    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    for (int i = 0; i < ndone; i++) if (done[i] == key && done_dev[i] == dev) return hipSuccess;
-    e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, MOT_LDS_LIMIT);
-    if (e == hipSuccess && ndone < 64) { done[ndone] = key; done_dev[ndone++] = dev; }
-    return e;
+    return mot_impl::func_lds_once(reinterpret_cast<const void*>(kern), MOT_LDS_LIMIT);
 }
 
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)

@@ -17,6 +17,7 @@
 // Cost of a 1000 x 1000 frame with 4 % misses + 3 % false positives: 90-160 free rows after the greedy start, 3,700-4,700
 // settled columns in all (a far-matched row settles its whole cone: up to 380).
 #include "assoc_common.h"
+#include "mot_env.h"
 
 using namespace assoc;
 
@@ -182,13 +183,7 @@ hipError_t launch_lap_verify_again(const AssocArgs& a, int gR, int gC, hipStream
 // between the sparse solver's dual check and the certificate: cost matrix, dense solver, dual check of its result
 hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s)
 {
-    static int attr_dev = -1;
-    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    if (attr_dev != dev) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DenseShared));
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
+    hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_dense_kernel), (int)sizeof(DenseShared)); if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lap_cost_rm_kernel, dim3(gR, gC), dim3(256), 0, s, a);
     hipLaunchKernelGGL(lap_dense_kernel, dim3(1), dim3(MK_THREADS), sizeof(DenseShared), s, a);
     return launch_lap_verify_again(a, gR, gC, s);

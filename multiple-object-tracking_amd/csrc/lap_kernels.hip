@@ -25,6 +25,7 @@
 #include "lap_grid.h"
 #include "dl_lifecycle.h"
 #include "mk_sparse_body.h"
+#include "mot_env.h"
 
 using namespace assoc;
 
@@ -615,27 +616,18 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a, int again)
 // two_block: the caller will NOT launch mk_sparse_kernel behind this (no dense solver in between): the emulation rides in the solver's launch
 hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch)
 {
-    static int attr_dev = -1;                                          // per-device function attribute
-    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    if (attr_dev != dev) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapShared));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared)));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_solve2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared)));
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
+    hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_solve_kernel), (int)sizeof(LapShared)); if (e != hipSuccess) return e;
+    const int lds2i = (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared));
+    e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_solve2_kernel<false>), lds2i); if (e != hipSuccess) return e;
+    e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_solve2_kernel<true>), lds2i); if (e != hipSuccess) return e;
     // device loop: the detection features of the split update start on the side stream as soon as the predict is done, beside the
     // row scan (MOT_FEAT_BEFORE_ROWSCAN=0: behind it, as before: 2.86 instead of 2.94 M updates/s at 1024 tracks)
-    static int early = -1;
-    if (early < 0) { const char* ev = getenv("MOT_FEAT_BEFORE_ROWSCAN"); early = ev ? atoi(ev) : 1; }
+    const int early = mot_impl::env().feat_before_rowscan;
     if (ev_mid && early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
     if (ev_mid && !early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     // box costs: solver + dual check + certificate (+ lifecycle) in one workgroup; caller matrices keep the dense dual check
-    static int fuse = -1;
-    if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
+    const int fuse = mot_impl::env().lap_fused;
     const int fused = (fuse && !a.user) ? 1 : 0;
     if (fused && two_block) {
         const size_t lds2 = sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared);

@@ -21,6 +21,7 @@
 //     find-first-bit, "its first uncovered zero row" one LDS round trip, and covering a row one LDS atomic per zero of
 //     that row; after an augmentation (all rows uncovered, :324-330) tlive = tzero.
 #include "mk_sparse_body.h"
+#include "mot_env.h"
 
 using namespace assoc;
 
@@ -92,20 +93,11 @@ __global__ void __launch_bounds__(256) mk_postcheck_kernel(AssocArgs a)
 
 hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, const LifeArgs& life)
 {
-    static int attr_dev = -1;
-    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
-    if (attr_dev != dev) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mk_sparse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SpShared));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mk_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SpShared));
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
-    static int batch = -1;                                             // MOT_MK_BATCH=0: one event per iteration of the sparse emulation's event loop
-    if (batch < 0) { const char* ev = getenv("MOT_MK_BATCH"); batch = (ev ? atoi(ev) : 1) & 0xFFFF; const char* lz = getenv("MOT_MK_LAZY"); if (lz && atoi(lz) == 0) batch |= SP_LAZY_OFF; const char* tm = getenv("MOT_MK_TIMING"); if (tm && atoi(tm)) batch |= SP_TIMING; }   // MOT_MK_LAZY=0: the reference's full reset after every augmentation
+    hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(mk_sparse_kernel<false>), (int)sizeof(SpShared)); if (e != hipSuccess) return e;
+    e = mot_impl::func_lds_once(reinterpret_cast<const void*>(mk_sparse_kernel<true>), (int)sizeof(SpShared)); if (e != hipSuccess) return e;
+    const int batch = mot_impl::env().mk_batch;                        // MOT_MK_BATCH / MOT_MK_LAZY=0 (the reference's full reset after every augmentation) / MOT_MK_TIMING
     // box costs: the after-the-fact check (and the lifecycle step) run inside the emulation's workgroup; caller matrices keep the dense pass
-    static int fuse = -1;
-    if (fuse < 0) { const char* ev = getenv("MOT_LAP_FUSED"); fuse = (ev && atoi(ev) == 0) ? 0 : 1; }
+    const int fuse = mot_impl::env().lap_fused;
     const int post_fused = (fuse && !a.user) ? 1 : 0;
     if (batch & SP_TIMING) hipLaunchKernelGGL(mk_sparse_kernel<true>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
     else hipLaunchKernelGGL(mk_sparse_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);

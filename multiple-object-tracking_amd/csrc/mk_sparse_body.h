@@ -81,7 +81,10 @@ __device__ inline bool sp_wait_verdict(const LapWs& L, int* flag)
         const int v = *flag;
         __syncthreads();
         if (v) return v == 2;
-        if (spins > 4000000) return true;                               // the partner is gone (cannot happen): behave like a stand-alone run
+        // the partner never published a verdict ("cannot happen"): this run is NOT committed -- two writers must never be possible.  The
+        // verdict word for the final kernel keeps its armed value (2: the dense order-exact emulation decides the frame, or the solver's
+        // workgroup if it does certify after all); status word 3 records the time-out (mot_get_lap_stats()[8])
+        if (spins > 4000000) { if (threadIdx.x == 0) L.hdr[LAP_H_LAST + 8] = 3; return false; }
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -265,7 +268,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
     bool hz_dirty = false;                                             // step 5 changed the masks: wave 0 rebuilds hzr
     int status = 0;
     int vseen = 0;                                                     // (wavefront 0, speculative run) the verdict word as last seen
-    // ---- LAZY RESET (round 4; CPU model and the argument: oracle/mk_sparse_model.c, mks_run, lazy).  Between two step 5s the connected
+    // ---- LAZY RESET (round 4; CPU model and the argument: mk_sparse_model.c, mks_run, lazy).  Between two step 5s the connected
     // components of the zero graph evolve independently (the sweep visits columns in ascending order and repeats while anything
     // happened: what a component does in pass p depends on its own state only).  The reference uncovers every row after an
     // augmentation and re-grows its whole forest (:324-334): for a component that was grown from scratch in a phase that ran to its

@@ -423,9 +423,9 @@ int mot_ctx_destroy(mot_ctx* c)
     if (!c) return MOT_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->devloop) devloop_destroy(c->devloop);                        // (drains its side and copy streams before anything is freed)
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
-    if (c->devloop) devloop_destroy(c->devloop);
     if (c->yolo) yolo_destroy(c->yolo);
     delete c;
     return MOT_OK;

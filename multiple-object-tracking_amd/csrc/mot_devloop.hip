@@ -11,8 +11,10 @@
 // runs ONE ncclAllGather, and mot_step_finish_device continues; association and
 // lifecycle are replicated (deterministic) on every rank.
 #include "mot_ctx.h"
+#include "mot_env.h"
 #include "dl_lifecycle.h"
 #include <dlfcn.h>
+#include <string>
 
 // Events that order work between this context's streams on ONE device: no timing, and a DEVICE-scope release when recorded.  The
 // default (system-scope) release writes back and invalidates the caches at every record; the consumers here are kernels of the same
@@ -89,6 +91,9 @@ struct DevLoop {
 void devloop_destroy(DevLoop* d)
 {
     if (!d) return;
+    // a detection-feature launch (side stream) or an upload (copy stream) may still be running: nothing is freed under them
+    if (d->side) (void)hipStreamSynchronize(d->side);
+    if (d->copy) (void)hipStreamSynchronize(d->copy);
     if (d->ev_ok) for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
@@ -159,10 +164,10 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     if (S.kind == MOT_TRACKER_KCF) {
         c->pools[d->pool]->free_slots.clear();                           // the device owns the pool now
         for (int pi : d->cls_pool) c->pools[pi]->free_slots.clear();
-        const char* ev = getenv("MOT_SPLIT_UPDATE");                     // default on; 0 keeps the fused update kernel
+        const bool split_on = mot_impl::env().split_update != 0;          // MOT_SPLIT_UPDATE: default on; 0 keeps the fused update kernel
         // (size classes: the spectrum a detection is adopted with depends on the adopting track's template size, which is only
         // known after the assignment -- the fused update kernel is used)
-        if ((!ev || atoi(ev) != 0) && !multi) {
+        if (split_on && !multi) {
             const KcfPool& kp = c->pools[d->pool]->dev;
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // lo = numerically largest = lowest priority
@@ -170,10 +175,10 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             // one-workgroup kernels and the short dense passes of the association chain on the main stream never queue behind
             // detection-feature workgroups (2.44 -> 2.58 M updates/s at 1024 tracks).  0 (or a refusal by the runtime): a
             // low-priority stream over the whole chip, as in round 1.
-            const char* rs = getenv("MOT_SIDE_RESERVE");
+            const int rs = mot_impl::env().side_reserve;                    // MOT_SIDE_RESERVE (-1: by template size)
             // HBM-slab templates run one workgroup per CU for hundreds of microseconds: taking CUs away from them costs a
             // second round (256 tracks at 148 x 148: 322 k -> 240 k updates/s), so only LDS-resident templates reserve by default
-            const int reserve = rs ? atoi(rs) : (kp.use_lds ? 32 : 0);
+            const int reserve = rs >= 0 ? rs : (kp.use_lds ? 32 : 0);
             bool masked = false;
             if (reserve > 0 && reserve < 256) {
                 uint32_t mask[8];
@@ -187,8 +192,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             HIPCHK(hipEventCreateWithFlags(&d->ev_in, MOT_EVENT_FLAGS));
             // Deferred blend (default; MOT_DEFER_BLEND=0 restores the blend launch): the model update of frame f rides in frame f + 1's
             // predict kernel.  The spectra of frame f must then outlive the feature launch of frame f + 1: two buffers, by frame parity.
-            const char* dv = getenv("MOT_DEFER_BLEND");
-            d->defer = !(dv && atoi(dv) == 0);
+            d->defer = mot_impl::env().defer_blend != 0;
             d->spec_stride = (size_t)md * MOT_NCHAN * kp.nbins;
             HIPCHK(d->det_spec.alloc(d->spec_stride * 3));
             for (int b = 0; b < 3; b++) HIPCHK(hipEventCreateWithFlags(&d->ev_spec[b], MOT_EVENT_FLAGS));
@@ -207,9 +211,8 @@ int devloop_get(mot_ctx* c, DevLoop** out)
 
 int split_early_max()
 {
-    static int early_max = -1;
-    if (early_max < 0) { const char* ev = getenv("MOT_SPLIT_EARLY_MAX"); early_max = ev ? atoi(ev) : MOT_SPLIT_EARLY_MAX; }
-    return early_max;
+    const int v = mot_impl::env().split_early_max;
+    return v < 0 ? MOT_SPLIT_EARLY_MAX : v;
 }
 
 int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, const void* dets_dev = nullptr, int nD = 0)
@@ -224,6 +227,13 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     // else a free one (then the features are computed within the frame, as before)
     d->have_cur = d->split && d->pf_valid && d->pf_frame == frame_dev && d->pf_dets == dets_dev && d->pf_nD == nD && dets_dev;
     d->buf_cur = d->have_cur ? d->pf_buf : (d->buf_prev + 1) % 3;
+    if (d->split && d->pf_valid && !d->have_cur) {
+        // the caller announced another frame / list than the one it passes now.  The look-ahead launch of the previous call may still be
+        // WRITING its spectra buffer (and the shared HBM slabs) and READING the frame it was announced with: this frame takes the buffer
+        // that is neither that one nor the previous frame's, and the context stream waits for the abandoned launch (rare; costs one wait)
+        d->buf_cur = 3 - d->buf_prev - d->pf_buf;
+        if (d->spec_side[d->pf_buf]) { HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->pf_buf], 0)); d->spec_side[d->pf_buf] = false; }
+    }
     d->pf_valid = false;
     if (!d->have_cur) d->spec_side[d->buf_cur] = false;
     float2* spec_cur = d->det_spec.p + (size_t)d->buf_cur * d->spec_stride;            // this frame's detection spectra
@@ -239,8 +249,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     // the blend prologue of this predict reads the previous frame's spectra: behind the side-stream launch that wrote them
     if (d->split && d->defer && d->spec_side[d->buf_prev]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_prev], 0));
     bool ext_timed = false;                                            // profiling: the predict launch records its own begin / end (below)
-    static int joined_on = -1;
-    if (joined_on < 0) { const char* ev = getenv("MOT_JOINED_LAUNCH"); joined_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+    const int joined_on = mot_impl::env().joined_launch;
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; }
@@ -273,7 +282,11 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     return MOT_OK;
 }
 
-int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev, int nD, hipEvent_t* ev)
+// release_inputs: the context stream waits, at the end of the frame, for the side-stream feature launch that read THIS frame's image and
+// detection list -- so a caller may overwrite both in stream order behind the call (round-3 advisor finding: with the deferred blend only
+// the next frame's predict waited for that launch).  The next predict needed that wait anyway (its blend prologue reads the spectra), so
+// the wait moves, it is not added.  mot_step_frame_host guards its own two buffers and passes false.
+int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev, int nD, hipEvent_t* ev, bool release_inputs = true)
 {
     RoctxRange range_("mot.frame.assoc_update");
     DLState& S = d->S;
@@ -332,6 +345,10 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
         if (split) d->buf_prev = d->buf_cur;
     } else HIPCHK(launch_kalman_update(c->kal, S.upd_slots, S.upd_count, upd_max, S.upd_boxes, c->stream));
     if (ev) HIPCHK(hipEventRecord(ev[4], c->stream));
+    if (release_inputs && d->split && d->spec_side[d->buf_prev]) {       // (rotated above: buf_prev is this frame's spectra buffer)
+        HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->buf_prev], 0));
+        d->spec_side[d->buf_prev] = false;                             // the context stream is ordered behind that launch from here on
+    }
     return MOT_OK;
 }
 
@@ -385,14 +402,19 @@ int mot_step_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_de
 // ---- native RCCL leg ----------------------------------------------------------------------------------------------
 namespace {
 typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, void* /* ncclComm_t */, hipStream_t);
-nccl_all_gather_fn rccl_all_gather()
+struct RcclBinding { nccl_all_gather_fn fn = nullptr; std::string why; };
+const RcclBinding* rccl_binding()
 {
-    static const nccl_all_gather_fn fn = [] {                           // bound once, thread-safe (function-local static)
+    static const RcclBinding b = [] {                                   // bound once, thread-safe (function-local static); the loader's message is kept with it
+        RcclBinding r;
         void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        return h ? reinterpret_cast<nccl_all_gather_fn>(dlsym(h, "ncclAllGather")) : nullptr;
+        if (!h) { const char* m = dlerror(); r.why = m ? m : "dlopen failed"; return r; }
+        r.fn = reinterpret_cast<nccl_all_gather_fn>(dlsym(h, "ncclAllGather"));
+        if (!r.fn) { const char* m = dlerror(); r.why = m ? m : "symbol ncclAllGather missing"; }
+        return r;
     }();
-    return fn;
+    return &b;
 }
 } // namespace
 
@@ -400,8 +422,9 @@ int mot_step_frame_sharded(mot_ctx* c, const void* frame_dev, const void* dets_d
 {
     if (!c || !nccl_comm) return fail(MOT_ERR_ARG, "null argument");
     int rc = ensure_device(c); if (rc) return rc;
-    nccl_all_gather_fn all_gather = rccl_all_gather();
-    if (!all_gather) return fail(MOT_ERR_DEVICE, "librccl.so.1 / ncclAllGather not available: %s", dlerror() ? dlerror() : "symbol missing");
+    const RcclBinding& rb = *rccl_binding();
+    nccl_all_gather_fn all_gather = rb.fn;
+    if (!all_gather) return fail(MOT_ERR_DEVICE, "librccl.so.1 / ncclAllGather not available: %s", rb.why.c_str());
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
     rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
     // the frame's single collective: every rank's segment of predicted boxes, in place (send = recv + rank * count), on the SAME stream
@@ -433,8 +456,7 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
     const int b = (int)(d->host_no & 1);
     // MOT_H2D_MODE: 2 (default) copy KERNEL on the copy stream (pinned, device-mapped host memory; anything else falls back to 0),
     // 0 hipMemcpyAsync on the copy stream, 1 hipMemcpyAsync on the context's own stream (no overlap, no cross-stream events)
-    static int h2d_mode = -1;
-    if (h2d_mode < 0) { const char* ev = getenv("MOT_H2D_MODE"); h2d_mode = ev ? atoi(ev) : 2; }
+    const int h2d_mode = mot_impl::env().h2d_mode;
     const void* src_f = host_bgr; const void* src_d = host_dets;
     bool by_kernel = false;
     if (h2d_mode == 2 && ((uintptr_t)host_bgr % 16 == 0) && (!nD || (uintptr_t)host_dets % 8 == 0)) {
@@ -466,7 +488,7 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         HIPCHK(hipStreamWaitEvent(c->stream, d->ev_up[b], 0));
     }
     rc = dl_begin(c, d, d->hbuf[b].p, nullptr, d->dbuf[b].p, nD); if (rc) return rc;
-    rc = dl_finish(c, d, nullptr, d->dbuf[b].p, nD, nullptr); if (rc) return rc;
+    rc = dl_finish(c, d, nullptr, d->dbuf[b].p, nD, nullptr, false); if (rc) return rc;
     // with the deferred blend the NEXT frame's predict still reads nothing of this frame's buffers (spectra live in their own buffers),
     // so the buffer is free once this frame's stream work is done
     HIPCHK(hipEventRecord(d->ev_done[b], c->stream));
@@ -481,8 +503,7 @@ int mot_step_frame_device_ahead(mot_ctx* c, const void* frame_dev, const void* d
     if (c->cfg.world != 1) return fail(MOT_ERR_STATE, "sharded context: use mot_step_begin_device / all-gather / mot_step_finish_device");
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
-    static int ahead_on = -1;
-    if (ahead_on < 0) { const char* ev = getenv("MOT_LOOKAHEAD"); ahead_on = (ev && atoi(ev) == 0) ? 0 : 1; }
+    const int ahead_on = mot_impl::env().lookahead;
     if (ahead_on) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
     rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
     return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);

@@ -1,0 +1,70 @@
+// mot_env.h -- host-side process configuration shared by the launchers: the MOT_* environment switches, read ONCE (C++11 function-local
+// static: initialisation is thread-safe, the object is immutable afterwards), and the per-DEVICE table of kernel attributes already set
+// (hipFuncSetAttribute is per device; one tracker thread per GPU in one process is the advertised deployment).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace mot_impl {
+
+struct EnvSwitches {
+    int lap_min;             // MOT_LAP_FAST=0: fast path off (1 << 30); MOT_LAP_MIN: smallest problem (lines) it is used for; -1: the built-in default
+    int dense_mode;          // MOT_LAP_DENSE: 0 never, 1 always, 2 (default) when the stream's recent frames needed it
+    int two_block;           // MOT_LAP_TWO_BLOCK=0: the sparse emulation as a launch of its own behind the solver
+    int mk_batch;            // MOT_MK_BATCH (low 16 bits; 0: one event per iteration, n > 1: batch threshold) | MOT_MK_LAZY=0 -> 0x40000000 | MOT_MK_TIMING=1 -> 0x20000000
+    int lap_fused;           // MOT_LAP_FUSED=0: dual check / after-the-fact check as chip-wide passes
+    int helpers;             // MOT_MUNKRES_HELPERS: 0 off, 1 forced on, 2 default (by size); force_cov: =2 test hook
+    int force_cov;
+    int feat_before_rowscan; // MOT_FEAT_BEFORE_ROWSCAN (default 1)
+    int split_early_max;     // MOT_SPLIT_EARLY_MAX (-1: built-in default)
+    int joined_launch;       // MOT_JOINED_LAUNCH=0: side-stream feature launch for small frames too
+    int h2d_mode;            // MOT_H2D_MODE: 2 (default) copy kernel, 0 hipMemcpyAsync on the copy stream, 1 on the context's stream
+    int lookahead;           // MOT_LOOKAHEAD=0: mot_step_frame_device_ahead ignores its hint
+    int split_update;        // MOT_SPLIT_UPDATE=0: fused update kernel
+    int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
+    int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
+};
+
+inline const EnvSwitches& env()
+{
+    static const EnvSwitches e = [] {
+        auto geti = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+        auto off = [](const char* name) { const char* v = getenv(name); return v && atoi(v) == 0; };
+        EnvSwitches s{};
+        s.lap_min = off("MOT_LAP_FAST") ? (1 << 30) : (getenv("MOT_LAP_MIN") ? (geti("MOT_LAP_MIN", 1) > 1 ? geti("MOT_LAP_MIN", 1) : 1) : -1);
+        s.dense_mode = getenv("MOT_LAP_DENSE") ? (geti("MOT_LAP_DENSE", 0) ? 1 : 0) : 2;
+        s.two_block = off("MOT_LAP_TWO_BLOCK") ? 0 : 1;
+        s.mk_batch = (geti("MOT_MK_BATCH", 1) & 0xFFFF) | (off("MOT_MK_LAZY") ? 0x40000000 : 0) | (geti("MOT_MK_TIMING", 0) ? 0x20000000 : 0);
+        s.lap_fused = off("MOT_LAP_FUSED") ? 0 : 1;
+        s.helpers = getenv("MOT_MUNKRES_HELPERS") ? (geti("MOT_MUNKRES_HELPERS", 0) ? 1 : 0) : 2;
+        s.force_cov = geti("MOT_MUNKRES_HELPERS", 0) == 2 ? 1 : 0;
+        s.feat_before_rowscan = geti("MOT_FEAT_BEFORE_ROWSCAN", 1);
+        s.split_early_max = geti("MOT_SPLIT_EARLY_MAX", -1);
+        s.joined_launch = off("MOT_JOINED_LAUNCH") ? 0 : 1;
+        s.h2d_mode = geti("MOT_H2D_MODE", 2);
+        s.lookahead = off("MOT_LOOKAHEAD") ? 0 : 1;
+        s.split_update = off("MOT_SPLIT_UPDATE") ? 0 : 1;
+        s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
+        s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
+        return s;
+    }();
+    return e;
+}
+
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes) once per (device, kernel); safe from several threads / devices
+inline hipError_t func_lds_once(const void* fn, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void*>> done;
+    int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& d : done) if (d.first == dev && d.second == fn) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.emplace_back(dev, fn);
+    return e;
+}
+
+} // namespace mot_impl

@@ -1,5 +1,5 @@
 // overlay_kernels.hip -- the tracker thread's drawing step on device: three nested rectangle outlines per live
-// track (top/td.cpp:647-733) drawn by drawRect (top/drawlib.c:97-151) in colormap[hashcolor(tid) & 255] (td.cpp:295-304, 620,
+// track (top/td.cpp:647-733) drawn by drawRect (top/drawlib.c:97-151) in colormap[hashcolor(tid + 1) & 255] (td.cpp:295-304, 620,
 // 655-699), straight into the BGR frame in HBM.
 //
 // The reference draws track after track, so where outlines overlap the LAST track wins.  All three outlines of a track have
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) overlay_kernel(uint8_t* __restrict__ fram
     if (j >= (n_dev ? *n_dev : n)) return;
     const bbox_t b = boxes[j];
     const unsigned prio = (epoch << 11) | (unsigned)(j + 1);
-    const unsigned color = colormap(hashcolor(tids[j]));
+    const unsigned color = colormap(hashcolor(tids[j] + 1u));            // td.cpp:619-620: tid = tracker_id++; color = hashcolor(tracker_id) -- the id AFTER the increment
     const uint8_t R = (color >> 16) & 0xff, G = (color >> 8) & 0xff, B = color & 0xff;
 #pragma unroll
     for (int k = 0; k < 3; k++) {                                      // td.cpp:701-731

@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(1024) yolo_nms_kernel(YoloArgs a)
             }
         }
         *a.nout = nout;
+        if (*a.ncand > YOLO_CAND) a.ncand[1] += *a.ncand - YOLO_CAND;      // sticky: candidates dropped for lack of room (which ones is arrival order: the output of this call is not the reference's)
         *a.ncand = 0;                                                      // re-armed for the next call
     }
 }
@@ -180,14 +181,31 @@ extern "C" int mot_yolo_postprocess(mot_ctx* c, const float* head0_dev, const fl
     hipLaunchKernelGGL(yolo_nms_kernel, dim3(1), dim3(1024), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     if (host_chain_out) {                                                  // the reference's hand-over format (cnntype.h:43-47): at most 128 boxes
-        int n = 0;
+        int n = 0, dropped = 0;
         HIPCHK(hipMemcpyAsync(&n, n_dev_out, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&dropped, W.ints.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (dropped) return fail(MOT_ERR_CAPACITY, "detector post-processing: %d candidates above the objectness threshold did not fit (%d at most); raise obj_thresh", dropped, YOLO_CAND);
         if (n > MOT_CHAIN_MAX_BOXES) n = MOT_CHAIN_MAX_BOXES;
         host_chain_out->nbox = n;
         if (n) HIPCHK(hipMemcpy(host_chain_out->bbox, dets_dev_out, sizeof(bbox_t) * n, hipMemcpyDeviceToHost));
     }
     return MOT_OK;
+}
+
+// Candidates beyond the workspace (4096 above obj_thresh) are dropped in arrival order -- unlike the reference's unbounded vector
+// (yolo3.cpp:176-201), so such a call's output is NOT the reference's.  The count is latched on the device; this query synchronises and
+// returns MOT_ERR_CAPACITY if any call since the context was created dropped candidates (mot_yolo_postprocess with host_chain_out
+// reports it by itself).  The reference's other corner, an EMPTY candidate list (correct_yolo_boxes then pushes one uninitialised box,
+// yolo3.cpp:203-254), is not restated: no candidates here means no detections.
+extern "C" int mot_yolo_status(mot_ctx* c, int* dropped_candidates)
+{
+    using namespace mot_impl;
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    int dropped = 0;
+    if (c->yolo) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(&dropped, c->yolo->ints.p + 1, sizeof(int), hipMemcpyDeviceToHost)); }
+    if (dropped_candidates) *dropped_candidates = dropped;
+    return dropped ? fail(MOT_ERR_CAPACITY, "detector post-processing dropped %d candidates (%d fit)", dropped, YOLO_CAND) : MOT_OK;
 }
 
 namespace mot_impl { void yolo_destroy(YoloWs* w) { delete w; } }

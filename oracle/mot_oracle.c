@@ -932,7 +932,7 @@ void orc_overlay(uint8_t* frame, const orc_bbox_t* boxes, const unsigned* tids, 
 {
     const uint32_t* cm = orc_colormap();
     for (int j = 0; j < n; j++) {                                      /* td.cpp:647-733 */
-        const uint32_t color = cm[orc_hashcolor(tids[j]) & 255];       /* td.cpp:620,699 */
+        const uint32_t color = cm[orc_hashcolor(tids[j] + 1u) & 255];  /* td.cpp:619-620: tid = tracker_id++; color = hashcolor(tracker_id) & 255, i.e. of tid + 1; :699 */
         const orc_bbox_t b = boxes[j];
         orc_draw_rect(frame, b.l, b.t, b.r, b.b, color);
         orc_draw_rect(frame, b.l + 1, b.t + 1, b.r - 1, b.b - 1, color);

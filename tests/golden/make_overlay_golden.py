@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors of the overlay step (top/td.cpp:647-733): the REFERENCE's own drawRect (top/drawlib.c:97-151, compiled by
 oracle/Makefile into oracle/_ref/libref_drawlib.so) driven through the tracker thread's drawing loop -- three nested outlines per
-track in colormap[hashcolor(tid) & 255].  The colour table is read as DATA from the reference's td.cpp:655-697 (256 integers), the
+track in colormap[hashcolor(tid + 1) & 255] (td.cpp:619-620).  The colour table is read as DATA from the reference's td.cpp:655-697 (256 integers), the
 hash (td.cpp:295-304) is restated here.  Build container only.  Output: tests/golden/overlay_cases.npz -- per case the boxes, the
 track ids and the frame bytes the reference changed (flat byte offsets + values over a zero frame), plus the 256-entry table."""
 import ctypes as C
@@ -70,7 +70,7 @@ def main():
         frame = np.zeros(720 * 1280 * 3 + 4096, np.uint8)              # (slack behind the frame: the reference writes unchecked)
         sent = np.zeros_like(frame)
         for (l, t, b, r), tid in zip(boxes, tids):
-            color = int(cm[hashcolor(tid) & 255])
+            color = int(cm[hashcolor((tid + 1) & 0xFFFFFFFF) & 255])    # td.cpp:619-620: tid = tracker_id++, color = hashcolor(tracker_id): the id after the increment
             for d in range(3):                                         # td.cpp:701-731
                 draw.drawRect(orc.P(frame), l + d, t + d, r - d, b - d, color)
                 draw.drawRect(orc.P(sent), l + d, t + d, r - d, b - d, 0xFFFFFF)

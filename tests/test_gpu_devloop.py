@@ -399,3 +399,33 @@ def test_device_loop_lookahead_vs_oracle(mot, oracle, n, miss, fp):
         assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
         assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
     m.close(); c.close()
+
+
+def test_device_loop_one_buffer_reused_in_stream_order(mot, oracle):
+    """ONE device frame buffer and ONE detection buffer, overwritten for every frame by copies enqueued on the context's own stream right
+    behind the previous step call, nothing synchronised in between (mot_abi.h: "work the caller enqueues on mot_ctx_stream() after the
+    call may overwrite both").  At 1024 tracks the detection features of a frame run on a second stream beside its association chain:
+    the step call must order the context's stream behind that launch, or the next upload overwrites a frame that is still being read
+    (round-3 advisor finding).  Checked against the oracle at the end and half way."""
+    from multiple_object_tracking_amd import synth
+    n, nframes = 1024, 8
+    scene = synth.Scene(n, 80, stream_id=11)
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d[:1024] for _, d in items]
+    src_f = torch.from_numpy(np.stack(frames)).cuda()                  # staging copies (device to device on the context's stream)
+    _, src_d, _ = _dev(frames, dets, mot)
+    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    ext = torch.cuda.ExternalStream(c.stream())
+    buf_f = torch.empty_like(src_f[0]); buf_d = torch.empty_like(src_d[0])
+    m = orc.OracleMot(oracle, 0, 0, 1024)
+    torch.cuda.synchronize()
+    for f in range(nframes):
+        with torch.cuda.stream(ext):
+            buf_f.copy_(src_f[f], non_blocking=True); buf_d.copy_(src_d[f], non_blocking=True)
+        c.step_frame_device(buf_f.data_ptr(), buf_d.data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        if f in (nframes // 2, nframes - 1):
+            boxes, tids, _ = c.live_tracks()
+            assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+            assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    m.close(); c.close()

@@ -91,6 +91,27 @@ def test_bench_sharded_branch_two_ranks_one_gpu():
     assert j["smoke_backend"].startswith("gloo") and j["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1) starts its two ranks itself, as child
+    processes of a parent that never touches the GPU, relays rank 0's one JSON line and the exit code.  Two ranks on ONE GPU: the gloo-staged
+    smoke backend, as above."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MOT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--tracks", "96", "--steady", "0",
+                          "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0
+    # a failing rank must surface as a non-zero exit code of the parent
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--tracks", "96", "--size", "7"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0
+
+
 class _NcclId(__import__("ctypes").Structure):
     _fields_ = [("internal", __import__("ctypes").c_char * 128)]
 

@@ -33,6 +33,22 @@ def test_oracle_overlay_matches_reference_vectors(oracle):
         assert np.array_equal(frame, _expected(g, k)), f"case {k}"
 
 
+def test_overlay_colour_follows_the_spawn_sequence(oracle):
+    """td.cpp:619-620: `tid = tracker_id++; color = hashcolor(tracker_id) & 255` -- the colour is hashed from the id AFTER the
+    increment, so the track with tid 0 is painted in colormap[hashcolor(1) & 255] (round-3 advisor finding: tid was hashed)."""
+    from golden.make_overlay_golden import hashcolor
+    g = np.load(FIX)
+    cm = g["colormap"]
+    for tid in (0, 1, 7, 255, 2 ** 32 - 1):
+        frame = np.zeros(NB, np.uint8)
+        boxes = orc.boxes_array([(100, 50, 90, 160, 0, 0.9)])
+        _oracle_overlay(oracle, frame, boxes, np.array([tid], np.uint32))
+        px = frame.reshape(720, 1280, 3)[50, 130]                       # a pixel of the top edge; drawRect stores R, G, B at byte offsets 0, 1, 2
+        want = int(cm[hashcolor((tid + 1) & 0xFFFFFFFF) & 255])
+        assert (int(px[0]) << 16 | int(px[1]) << 8 | int(px[2])) == want, tid
+    assert cm[hashcolor(1) & 255] != cm[hashcolor(0) & 255]              # (so the test can tell the two apart)
+
+
 @pytest.mark.gpu
 def test_device_overlay_matches_reference_vectors_and_oracle(mot, oracle):
     import torch

@@ -71,3 +71,27 @@ def test_device_yolo_postprocess_vs_oracle(mot, oracle, th, tw, nc, npos, seed):
     chain = c.yolo_postprocess([h.data_ptr() for h in hd], th, tw, nc, 720, 1280, 0.5, 0.45, ANCHORS, dets.data_ptr(), 1024, nd.data_ptr(), want_chain=True)
     assert len(chain) == min(len(exp), 128) and np.array_equal(chain["l"], exp["l"][:128])
     c.close()
+
+
+@pytest.mark.gpu
+def test_device_yolo_candidate_overflow_is_reported(mot):
+    """more candidates above obj_thresh than the workspace holds (4096; the reference's vector is unbounded, yolo3.cpp:176-201): the call's
+    output is not the reference's, and that must not pass silently -- mot_yolo_status() / the host-chain form return MOT_ERR_CAPACITY
+    (round-3 advisor finding)."""
+    import torch
+    rng = np.random.default_rng(9)
+    th = tw = 416; nc = 80
+    heads = []
+    for s in range(3):
+        gh, gw = (th // 32) << s, (tw // 32) << s
+        heads.append(np.ascontiguousarray(rng.normal(3.0, 0.5, (gh, gw, 3, 5 + nc)).astype(np.float32).reshape(-1)))   # everything is an object of every class
+    c = mot.MotContext(max_tracks=64, max_dets=64)
+    assert c.yolo_status() == 0
+    hd = [torch.from_numpy(h).cuda() for h in heads]
+    dets = torch.zeros(1024 * 24, dtype=torch.uint8, device="cuda"); nd = torch.zeros(1, dtype=torch.int32, device="cuda")
+    c.yolo_postprocess([h.data_ptr() for h in hd], th, tw, nc, 720, 1280, 0.5, 0.45, ANCHORS, dets.data_ptr(), 1024, nd.data_ptr())
+    with pytest.raises(mot.MotError, match="dropped"):
+        c.yolo_status()
+    with pytest.raises(mot.MotError, match="did not fit"):
+        c.yolo_postprocess([h.data_ptr() for h in hd], th, tw, nc, 720, 1280, 0.5, 0.45, ANCHORS, dets.data_ptr(), 1024, nd.data_ptr(), want_chain=True)
+    c.close()
