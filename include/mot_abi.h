@@ -279,6 +279,13 @@ int mot_get_lap_stats(mot_ctx* ctx, int* out32);
 int mot_debug_assoc_trace(mot_ctx* ctx, long long* out, int n);
 /* FHOG only (libhog/fhog.h:16-38): H[32][w/4][h/4] for one column-major h x w patch. */
 int mot_fhog_extract(mot_ctx* ctx, const float* patch, int h, int w, float* H_out, int windowed);
+/* The three C helpers of the reference's tracker thread (top/td.cpp:235-261, top/drawlib.c:97-151, 192-240, 542-637) on the device, with the
+ * reference's own argument meaning -- HOST pointers in and out, synchronous; the drop-in libraries export them under the reference's names
+ * (rgb2Gray, bilinearInterpolationGray, drawRect), so a td.cpp link needs no object of the reference.  Boxes outside the 1280 x 720 frame are
+ * MOT_ERR_ARG (the reference reads / writes unchecked). */
+int mot_helper_rgb2gray(mot_ctx* ctx, float* pgra, const uint8_t* prgb, int left, int top, int right, int bottom);
+int mot_helper_bilinear_gray(mot_ctx* ctx, float* pdst, const float* psrc, int rows_s, int cols_s, int rows_d, int cols_d);
+int mot_helper_draw_rect(mot_ctx* ctx, uint8_t* fbuf, int left, int top, int right, int bottom, unsigned RGB);
 /* crop + gray + resize only (top/td.cpp:348-364) on the bound frame. */
 int mot_crop_patch(mot_ctx* ctx, const bbox_t* box, int rows, int cols, float* patch_out);
 

@@ -1,6 +1,7 @@
 // dropin.cpp -- per-object drop-in layer (see include/mot_dropin.hpp).
 // Built twice: -DMOT_DROPIN_KIND=0 (KCF) and =1 (Kalman).
 #include "../../include/mot_dropin.hpp"
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -66,4 +67,21 @@ void tracker_delete(void* ptracker)
 void assignmentoptimal(int* assignment, double* cost, double* distMatrixIn, int nOfRows, int nOfColumns)
 {
     if (mot_assignment_optimal(ctx(), assignment, cost, distMatrixIn, nOfRows, nOfColumns) != MOT_OK) die("assignmentoptimal");
+}
+
+// The C helpers of the reference's tracker thread (td.cpp:235-261; the reference implements them in top/drawlib.c): exported under the
+// reference's names with C linkage, so that linking td.cpp against this library leaves nothing of the reference's tracker side to compile.
+extern "C" void rgb2Gray(float* pgra, uint8_t* prgb, int32_t left, int32_t top, int32_t right, int32_t bottom)
+{
+    if (mot_helper_rgb2gray(ctx(), pgra, prgb, left, top, right, bottom) != MOT_OK) die("rgb2Gray");
+}
+
+extern "C" void bilinearInterpolationGray(float* pdst, const float* psrc, int rows_s, int cols_s, int rows_d, int cols_d)
+{
+    if (mot_helper_bilinear_gray(ctx(), pdst, psrc, rows_s, cols_s, rows_d, cols_d) != MOT_OK) die("bilinearInterpolationGray");
+}
+
+extern "C" void drawRect(uint8_t* fbuf, int32_t left, int32_t top, int32_t right, int32_t bottom, uint32_t RGB)
+{
+    if (mot_helper_draw_rect(ctx(), fbuf, left, top, right, bottom, RGB) != MOT_OK) die("drawRect");
 }

@@ -81,6 +81,8 @@ struct mot_ctx {
     mot_impl::YoloWs* yolo = nullptr;
     // overlay (td.cpp:647-733): per-pixel "last track to draw here" stamps, tagged with a per-call epoch
     mot_impl::DevBuf<unsigned> ov_stamp; unsigned ov_epoch = 0; mot_impl::DevBuf<bbox_t> ov_boxes; mot_impl::DevBuf<unsigned> ov_tids;
+    // per-call staging of the td.cpp helper entry points (helper_kernels.hip)
+    mot_impl::DevBuf<uint8_t> hlp_bytes; mot_impl::DevBuf<float> hlp_f0, hlp_f1;
     // timers / debug
     std::vector<hipEvent_t> events;
     mot_impl::DevBuf<long long> dbg; bool dbg_on = false;

@@ -6,8 +6,9 @@ stand-in for OpenCV / the detector DLL is written: the test reads the undefined 
 
   * the five tracker symbols it wants (td.cpp:229-234, C++ linkage, Itanium-mangled) are exactly what
     libmot_dropin_kcf.so / libmot_dropin_kalman.so export,
-  * the C helpers it wants (td.cpp:236-261: rgb2Gray, bilinearInterpolationGray, drawRect) are exported by the reference's
-    own top/drawlib.c (the maintainer keeps compiling that file; it is not part of the replaced path),
+  * the C helpers it wants (td.cpp:236-261: rgb2Gray, bilinearInterpolationGray, drawRect; the reference compiles top/drawlib.c for
+    them) are exported by the drop-in libraries as well (device kernels behind the reference's signatures), so no object of the
+    reference besides td.o takes part in the link,
   * everything else it wants belongs to OpenCV, the detector DLL (tensor*), or the C/C++ runtime -- i.e. there is no
     tracker-side symbol left that the drop-in libraries fail to provide.
 """
@@ -66,27 +67,37 @@ def test_unmodified_td_cpp_links_against_dropin(tmp_path, kind, defs, lib):
     assert TRACKER_SYMS <= und, f"td.cpp no longer references {TRACKER_SYMS - und}"
     exp = _exports(os.path.join(PKG, lib))
     assert TRACKER_SYMS <= exp, f"{lib} lacks {TRACKER_SYMS - exp}"
-    # 2. the C helpers come from the reference's own drawlib.c
-    draw = str(tmp_path / "drawlib.o")
-    subprocess.check_call(["gcc", "-O1", "-fPIC", "-w", "-include", os.path.join(ROOT, "oracle", "ref_platform.h"), "-c", f"{REF}/top/drawlib.c", "-o", draw])
-    dexp = _exports(draw, dynamic=False)
+    # 2. the C helpers (td.cpp:235-261; the reference compiles top/drawlib.c for them) are exported by the drop-in library too, with C linkage
     want_helpers = und & HELPER_SYMS
     assert want_helpers == (HELPER_SYMS if kind == "kcf" else {"drawRect"}), want_helpers
-    assert want_helpers <= dexp
+    assert HELPER_SYMS <= exp, f"{lib} lacks {HELPER_SYMS - exp}"
     # 3. nothing tracker-side is left: the rest is OpenCV, the detector DLL, or the runtime
     rest = und - TRACKER_SYMS - HELPER_SYMS
     runtime = _runtime_exports()
     foreign = {s for s in rest if not (s.startswith(("_ZN2cv", "_ZNK2cv", "tensor")) or s in runtime
                                        or s in ("_GLOBAL_OFFSET_TABLE_", "__dso_handle"))}
     assert not foreign, f"td.cpp wants symbols nobody provides: {sorted(foreign)}"
-    # 4. and the object really links: a shared object from td.o + drawlib.o + the drop-in library leaves only OpenCV / detector
-    # symbols undefined (no stand-ins are written for those)
+    # 4. and the object really links WITHOUT any other object of the reference: a shared object from td.o + the drop-in library leaves only
+    # OpenCV / detector symbols undefined (the running harness, harness/td_stubs.cpp + tests/test_td_harness.py, provides those)
     so = str(tmp_path / f"td_{kind}.so")
-    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", so, obj, draw, f"-L{PKG}", f"-l:{lib}", f"-Wl,-rpath,{PKG}", "-lpthread"])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", so, obj, f"-L{PKG}", f"-l:{lib}", f"-Wl,-rpath,{PKG}", "-lpthread"])
     left = {s.split("@")[0] for s in _undefined(so)}
-    left_tracker = left & (TRACKER_SYMS | HELPER_SYMS)
     dyn = subprocess.check_output(["readelf", "-d", so], text=True)
     assert lib in dyn, "the linked object does not depend on the drop-in library"
-    assert left_tracker <= TRACKER_SYMS                                  # helpers are resolved statically from drawlib.o
-    unresolved = {s for s in left if not (s in TRACKER_SYMS or s in runtime or s.startswith(("_ZN2cv", "_ZNK2cv", "tensor", "_ITM_", "__gmon")))}
+    unresolved = {s for s in left if not (s in TRACKER_SYMS or s in HELPER_SYMS or s in runtime or s.startswith(("_ZN2cv", "_ZNK2cv", "tensor", "_ITM_", "__gmon")))}
     assert not unresolved, sorted(unresolved)
+
+
+def test_harness_executables_build_from_the_unmodified_td_cpp():
+    """oracle/Makefile `harness`: td.cpp (by path, both builds) + harness/td_stubs.cpp + the drop-in library link into executables with no
+    undefined symbol left besides the C / C++ runtime -- in particular none of OpenCV, of the detector DLL or of drawlib.c."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "harness"], stdout=subprocess.DEVNULL)
+    runtime = _runtime_exports()
+    for kind, lib in (("kcf", "libmot_dropin_kcf.so"), ("kalman", "libmot_dropin_kalman.so")):
+        exe = os.path.join(ROOT, "oracle", "_ref", f"td_harness_{kind}")
+        assert os.path.exists(exe)
+        und = {s.split("@")[0] for s in _undefined(exe)}
+        exp = _exports(os.path.join(PKG, lib))
+        missing = {s for s in und if not (s in exp or s in runtime or s.startswith(("_ITM_", "__gmon")))}
+        assert not missing, sorted(missing)
+        assert TRACKER_SYMS <= und and (und & HELPER_SYMS) == (HELPER_SYMS if kind == "kcf" else {"drawRect"})

@@ -415,7 +415,7 @@ def test_device_loop_one_buffer_reused_in_stream_order(mot, oracle):
     src_f = torch.from_numpy(np.stack(frames)).cuda()                  # staging copies (device to device on the context's stream)
     _, src_d, _ = _dev(frames, dets, mot)
     c = mot.MotContext(max_tracks=1024, max_dets=1024)
-    ext = torch.cuda.ExternalStream(c.stream())
+    ext = torch.cuda.ExternalStream(c.stream)
     buf_f = torch.empty_like(src_f[0]); buf_d = torch.empty_like(src_d[0])
     m = orc.OracleMot(oracle, 0, 0, 1024)
     torch.cuda.synchronize()

@@ -469,6 +469,39 @@ def test_dropin_per_object_interface(mot):
         assert np.array_equal(a, gm[f"m{i}_a"]) and cost.value == float(gm[f"m{i}_c"])
 
 
+def test_dropin_c_helpers_on_device(mot, oracle):
+    """rgb2Gray / bilinearInterpolationGray / drawRect (td.cpp:235-261, C linkage) as exported by the drop-in libraries: device kernels
+    behind the reference's host-pointer signatures.  Crop + resize composed as td.cpp:346-364 does must reproduce the reference-generated
+    crop fixtures bit for bit; three nested outlines per track as td.cpp:701-731 draws them must reproduce the reference-generated overlay
+    frames byte for byte."""
+    import sys
+    sys.path.insert(0, os.path.join(orc.ROOT, "tests", "golden"))
+    from make_overlay_golden import hashcolor
+    for path in (mot.DROPIN_KCF_PATH, mot.DROPIN_KALMAN_PATH):
+        lib = C.CDLL(path)
+        lib.rgb2Gray.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 4; lib.rgb2Gray.restype = None
+        lib.bilinearInterpolationGray.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4; lib.bilinearInterpolationGray.restype = None
+        lib.drawRect.argtypes = [C.c_void_p] + [C.c_int32] * 4 + [C.c_uint32]; lib.drawRect.restype = None
+        g = load("crop_cases.npz")
+        frame = np.random.default_rng(int(g["seed"])).integers(0, 256, size=(720, 1280, 3), dtype=np.uint8)
+        for i in range(int(g["n"])):
+            l, t, r, b, rows, cols = map(int, g[f"c{i}_box"])
+            scratch = np.zeros((b - t + 1) * (r - l + 1), np.float32); patch = np.zeros(rows * cols, np.float32)
+            lib.rgb2Gray(P(scratch), P(frame), l, t, r, b)
+            lib.bilinearInterpolationGray(P(patch), P(scratch), b - t + 1, r - l + 1, rows, cols)
+            assert np.array_equal(patch.view(np.uint32), g[f"c{i}_patch"].view(np.uint32)), f"crop case {i}"
+        go = np.load(os.path.join(orc.ROOT, "tests", "golden", "overlay_cases.npz"))
+        cm = go["colormap"]
+        for k in range(int(go["n"])):
+            fr = np.zeros(720 * 1280 * 3, np.uint8)
+            for bb, tid in zip(go[f"boxes_{k}"], go[f"tids_{k}"]):
+                color = int(cm[hashcolor((int(tid) + 1) & 0xFFFFFFFF) & 255])
+                for d in range(3):
+                    lib.drawRect(P(fr), int(bb["l"]) + d, int(bb["t"]) + d, int(bb["r"]) - d, int(bb["b"]) - d, color)
+            exp = np.zeros(720 * 1280 * 3, np.uint8); exp[go[f"idx_{k}"]] = go[f"val_{k}"]
+            assert np.array_equal(fr, exp), f"overlay case {k}"
+
+
 _VARIANT_CODE = r'''
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
