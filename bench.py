@@ -302,7 +302,8 @@ def main():
             for _, cx in extra:
                 cx.step_frame_device_ahead(fp, dp, det_counts[f], nf, nd, nn)
         else:
-            seg_ptr, spr = ctx.step_begin_device(fp)
+            nf, nd, nn = (fp + frame_bytes, dp + det_bytes, det_counts[f + 1]) if f + 1 < n_frames else (0, 0, 0)
+            seg_ptr, spr = ctx.step_begin_device_ahead(fp, dp, det_counts[f], nf, nd, nn)   # look-ahead of the detection features, as on one GPU
             nonlocal gathered
             if gathered is None:
                 gathered = torch.empty(mot_world * spr * 24, dtype=torch.uint8, device="cuda")

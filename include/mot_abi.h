@@ -211,6 +211,13 @@ int mot_step_frame_host(mot_ctx* ctx, const uint8_t* host_bgr, const bbox_t* hos
  * for this rank, created with world = cfg.world ranks), replicated association + lifecycle, local updates -- all enqueued on the
  * context's stream, no host synchronisation.  librccl is bound at run time (dlopen), so single-GPU builds and hosts need no RCCL. */
 int mot_step_frame_sharded(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD, void* nccl_comm);
+/* The sharded step with one frame of look-ahead (as mot_step_frame_device_ahead): every rank computes the NEXT frame's detection features
+ * beside this frame's replicated association chain instead of inside the frame.  Same results; the next call must pass the announced
+ * pointers and count to benefit.  mot_step_begin_device_ahead is the two-call form (the caller runs the all-gather itself). */
+int mot_step_frame_sharded_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
+                                 const void* next_frame_dev, const void* next_dets_dev, int next_nD, void* nccl_comm);
+int mot_step_begin_device_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
+                                const void* next_frame_dev, const void* next_dets_dev, int next_nD, void** local_boxes_dev, int* slots_per_rank);
 int mot_live_count(mot_ctx* ctx, int* n_live);
 int mot_live_tracks(mot_ctx* ctx, bbox_t* boxes, unsigned* tids, int* ages, int* n_live);
 

@@ -241,6 +241,13 @@ class MotContext:
         self._chk(self.lib.mot_step_begin_device(self._h, C.c_void_p(frame_dev), C.byref(ptr), C.byref(spr)))
         return int(ptr.value or 0), spr.value
 
+    def step_begin_device_ahead(self, frame_dev: int, dets_dev: int, n_dets: int, next_frame_dev: int, next_dets_dev: int, next_n_dets: int):
+        """sharded step, first half, with the frame's detection list and the NEXT frame announced (look-ahead of the detection features)"""
+        ptr, spr = C.c_void_p(), C.c_int(0)
+        self._chk(self.lib.mot_step_begin_device_ahead(self._h, C.c_void_p(frame_dev), C.c_void_p(dets_dev), n_dets, C.c_void_p(next_frame_dev), C.c_void_p(next_dets_dev),
+                                                       next_n_dets, C.byref(ptr), C.byref(spr)))
+        return int(ptr.value or 0), spr.value
+
     def step_finish_device(self, gathered_dev: int, dets_dev: int, n_dets: int):
         self._chk(self.lib.mot_step_finish_device(self._h, C.c_void_p(gathered_dev), C.c_void_p(dets_dev), n_dets))
 

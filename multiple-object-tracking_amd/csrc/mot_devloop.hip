@@ -382,6 +382,21 @@ int mot_step_begin_device(mot_ctx* c, const void* frame_dev, void** local_boxes_
     return MOT_OK;
 }
 
+// the same with the frame's detection list known at the start and one frame of look-ahead (see mot_step_frame_device_ahead): a sharded rank
+// then computes the NEXT frame's detection features beside this frame's association chain as well, instead of inside the frame
+int mot_step_begin_device_ahead(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, const void* next_frame_dev, const void* next_dets_dev, int next_nD,
+                                void** local_boxes_dev, int* slots_per_rank)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    int rc = ensure_device(c); if (rc) return rc;
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    if (mot_impl::env().lookahead) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
+    rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
+    if (local_boxes_dev) *local_boxes_dev = d->S.gather + (size_t)d->S.rank * d->S.spr;
+    if (slots_per_rank) *slots_per_rank = d->S.spr;
+    return MOT_OK;
+}
+
 int mot_step_finish_device(mot_ctx* c, const void* gathered_boxes_dev, const void* dets_dev, int nD)
 {
     if (!c || !c->devloop) return fail(MOT_ERR_STATE, "mot_step_finish_device without mot_step_begin_device");
@@ -418,7 +433,13 @@ const RcclBinding* rccl_binding()
 }
 } // namespace
 
+int mot_step_frame_sharded_ahead(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, const void* next_frame_dev, const void* next_dets_dev, int next_nD, void* nccl_comm);
 int mot_step_frame_sharded(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, void* nccl_comm)
+{
+    return mot_step_frame_sharded_ahead(c, frame_dev, dets_dev, nD, nullptr, nullptr, 0, nccl_comm);
+}
+
+int mot_step_frame_sharded_ahead(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, const void* next_frame_dev, const void* next_dets_dev, int next_nD, void* nccl_comm)
 {
     if (!c || !nccl_comm) return fail(MOT_ERR_ARG, "null argument");
     int rc = ensure_device(c); if (rc) return rc;
@@ -426,6 +447,7 @@ int mot_step_frame_sharded(mot_ctx* c, const void* frame_dev, const void* dets_d
     nccl_all_gather_fn all_gather = rb.fn;
     if (!all_gather) return fail(MOT_ERR_DEVICE, "librccl.so.1 / ncclAllGather not available: %s", rb.why.c_str());
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    if (mot_impl::env().lookahead && next_frame_dev) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
     rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
     // the frame's single collective: every rank's segment of predicted boxes, in place (send = recv + rank * count), on the SAME stream
     // as the kernels on both sides of it -- stream order is the only synchronisation

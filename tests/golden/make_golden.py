@@ -79,7 +79,7 @@ def patches_for(rng, h, w, kind):
     return np.ascontiguousarray(I)
 
 
-def gen_fhog(hog):
+def gen_fhog(hog, name="fhog_cases.npz"):
     rng = np.random.default_rng(21)
     out = {}
     cases = [(80, 80, 0), (80, 80, 1), (80, 80, 2), (80, 80, 3), (150, 150, 1), (90, 70, 0), (33, 47, 2), (64, 96, 1)]
@@ -91,7 +91,7 @@ def gen_fhog(hog):
         hog.refhog_extract(P(I), h, w, P(H))
         out[f"c{i}_hw"] = np.array([h, w]); out[f"c{i}_I"] = I.ravel(); out[f"c{i}_M"] = M; out[f"c{i}_O"] = O; out[f"c{i}_H"] = H
     out["n"] = np.array(len(cases))
-    save("fhog_cases.npz", **out)
+    save(name, **out)
 
 
 def gen_crop(draw):
@@ -247,8 +247,11 @@ def main():
     if not orc.ref_available():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     hog, hung, draw, kal, kcf = (orc.load_ref(n) for n in ["hog", "hungarian", "drawlib", "kalman", "kcf"])
-    gen_sse(); gen_acos(hog); gen_fhog(hog); gen_crop(draw); gen_kalman(kal); gen_munkres(hung)
+    gen_sse(); gen_acos(hog); gen_fhog(hog)
+    gen_fhog(C.CDLL(os.path.join(orc.REF_DIR, "libref_hog_exact.so")), "fhog_cases_exact.npz")   # the reference with correctly rounded 1/x, 1/sqrt(x) (oracle/ref_exact_sse.h)
+    gen_crop(draw); gen_kalman(kal); gen_munkres(hung)
     gen_kcf(kcf, 80, 5, "kcf_seq_80.npz"); gen_kcf(kcf, 64, 4, "kcf_seq_64.npz"); gen_kcf(kcf, 148, 2, "kcf_seq_148.npz")
+    gen_kcf(kcf, 200, 2, "kcf_seq_200.npz")                           # above 41 cells per line: the device's general-size DFT path (kcf.cpp:178-195 plans any size)
     gen_frameloops((kcf, kal, hung, draw))
 
 

@@ -150,17 +150,27 @@ def test_device_loop_eight_ranks_on_one_gpu(mot, oracle):
         c.close()
 
 
-def test_device_loop_sharded_two_ranks(mot, oracle):
+@pytest.mark.parametrize("n,ahead", [(30, False), (30, True), (700, True)])
+def test_device_loop_sharded_two_ranks(mot, oracle, n, ahead):
+    """two ranks (tid % 2) on one GPU, the all-gather emulated by copies: both reproduce the unsharded oracle.  ahead: the two-call form with
+    the detection list and the NEXT frame announced (mot_step_begin_device_ahead) -- at 700 tracks the next frame's detection features are
+    then computed one frame early on the side stream of every rank"""
     from multiple_object_tracking_amd import synth
     hip = C.CDLL("libamdhip64.so")
-    scene = synth.Scene(30, 80, stream_id=31, miss_pct=6, fp_pct=4)
+    scene = synth.Scene(n, 80, stream_id=31, miss_pct=6, fp_pct=4)
     items = list(scene.frames(7))
     frames = [f for f, _ in items]; dets = [d for _, d in items]
     fd, dd, da = _dev(frames, dets, mot)
-    ranks = [mot.MotContext(max_tracks=64, max_dets=64, rank=r, world=2) for r in range(2)]
-    m = orc.OracleMot(oracle, 0, 0, 64)
+    cap = 64 if n <= 60 else 1024
+    ranks = [mot.MotContext(max_tracks=cap, max_dets=cap, rank=r, world=2) for r in range(2)]
+    m = orc.OracleMot(oracle, 0, 0, cap)
     for f in range(len(frames)):
-        segs = [c.step_begin_device(fd[f].data_ptr()) for c in ranks]
+        if ahead:
+            nxt = f + 1 if f + 1 < len(frames) else None
+            segs = [c.step_begin_device_ahead(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]), fd[nxt].data_ptr() if nxt is not None else 0,
+                                              dd[nxt].data_ptr() if nxt is not None else 0, len(dets[nxt]) if nxt is not None else 0) for c in ranks]
+        else:
+            segs = [c.step_begin_device(fd[f].data_ptr()) for c in ranks]
         spr = segs[0][1]
         for c in ranks:
             c.sync()

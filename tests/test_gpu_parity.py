@@ -51,12 +51,16 @@ def _patch(rng, h, w, kind):
 
 
 # ---------------------------------------------------------------- FHOG ------
-def test_fhog_golden_bit_exact(kcf_ctx):
-    g = load("fhog_cases.npz")
+@pytest.mark.parametrize("name,mode", [("fhog_cases.npz", 0), ("fhog_cases_exact.npz", 1)])
+def test_fhog_golden_bit_exact(mot, name, mode):
+    """both flavours of the reference (as is / correctly rounded 1 / x and 1 / sqrt(x): oracle/ref_exact_sse.h), bit for bit"""
+    g = load(name)
+    c = mot.MotContext(fhog_mode=mode, max_tracks=4, max_dets=4)
     for i in range(int(g["n"])):
         h, w = map(int, g[f"c{i}_hw"])
-        H = kcf_ctx.fhog_extract(g[f"c{i}_I"], h, w)
+        H = c.fhog_extract(g[f"c{i}_I"], h, w)
         assert np.array_equal(H.view(np.uint32), g[f"c{i}_H"].view(np.uint32)), f"golden FHOG case {i} ({h}x{w})"
+    c.close()
 
 
 @pytest.mark.parametrize("h,w", [(80, 80), (64, 64), (96, 48), (40, 120), (148, 148), (150, 150), (200, 120), (9, 8), (83, 77)])
@@ -92,7 +96,7 @@ def test_crop_resize_bit_exact(kcf_ctx, oracle):
 
 
 # ---------------------------------------------------------------- KCF -------
-@pytest.mark.parametrize("name", ["kcf_seq_80.npz", "kcf_seq_64.npz", "kcf_seq_148.npz"])
+@pytest.mark.parametrize("name", ["kcf_seq_80.npz", "kcf_seq_64.npz", "kcf_seq_148.npz", "kcf_seq_200.npz"])
 @pytest.mark.parametrize("fft_mode", [0, 1])
 def test_kcf_sequence_golden(mot, name, fft_mode):
     """tracker_new / tracker_update / tracker_predict semantics with caller-supplied patches

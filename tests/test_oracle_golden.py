@@ -54,16 +54,19 @@ def test_bin_thresholds_match_reference_table():
         assert np.array_equal(rec, o0)
 
 
-def test_fhog_bit_exact(oracle):
-    g = load("fhog_cases.npz")
+@pytest.mark.parametrize("name,mode", [("fhog_cases.npz", 0), ("fhog_cases_exact.npz", 1)])
+def test_fhog_bit_exact(oracle, name, mode):
+    """mode 0: the reference as it is (rcpps / rsqrtps, libhog/sse.hpp:40-41); mode 1: its exact-math flavour (the same sources compiled with
+    correctly rounded 1 / x and 1 / sqrt(x), oracle/ref_exact_sse.h) -- SURVEY 8c asks for fixtures of both"""
+    g = load(name)
     for i in range(int(g["n"])):
         h, w = map(int, g[f"c{i}_hw"])
         I = np.ascontiguousarray(g[f"c{i}_I"])
         M = np.zeros(h * w, np.float32); O = np.zeros(h * w, np.float32)
-        oracle.orc_grad_mag(P(I), P(M), P(O), h, w, 0)
+        oracle.orc_grad_mag(P(I), P(M), P(O), h, w, mode)
         assert np.array_equal(M.view(np.uint32), g[f"c{i}_M"].view(np.uint32)), f"case {i} M"
         assert np.array_equal(O.view(np.uint32), g[f"c{i}_O"].view(np.uint32)), f"case {i} O"
-        H = orc.fhog(oracle, I, h, w, 0)
+        H = orc.fhog(oracle, I, h, w, mode)
         assert np.array_equal(H.view(np.uint32), g[f"c{i}_H"].view(np.uint32)), f"case {i} H"
         assert not H[31 * (h // 4) * (w // 4):].any()
 
@@ -135,7 +138,7 @@ def test_munkres_bit_exact(oracle):
         assert c == float(g[f"big{i}_c"])
 
 
-@pytest.mark.parametrize("name", ["kcf_seq_80.npz", "kcf_seq_64.npz", "kcf_seq_148.npz"])
+@pytest.mark.parametrize("name", ["kcf_seq_80.npz", "kcf_seq_64.npz", "kcf_seq_148.npz", "kcf_seq_200.npz"])
 def test_kcf_sequence(oracle, name):
     g = load(name)
     S = int(g["S"]); fr = S // 4; nf = fr * fr; nh = fr * (fr // 2 + 1)
