@@ -259,6 +259,10 @@ int mot_get_pos(mot_ctx* ctx, int id, bbox_t* pos);
 int mot_live_response(mot_ctx* ctx, int live_index, float* out, int* f_rows, int* f_cols);
 /* debug: enable / read the per-phase time stamps (100 MHz ticks) of workgroup 0 of the device-loop KCF kernels:
  * [0] start [1] crop [2] gradient [3] histogram [4] norm [5] channels [6] DFT [7] end */
+/* debug: duration of the predict launch itself (the kernel's own begin / end stamps) while the ordinary device-resident step calls run:
+ * arm n pairs, step n frames, read the n durations (synchronises).  What rocprofv3 reports for the launch in the timed configuration. */
+int mot_debug_predict_timing(mot_ctx* ctx, int n_pairs);
+int mot_debug_predict_times(mot_ctx* ctx, float* out_ms, int cap, int* n);
 int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long long* update8);
 /* Host-side scheduling state machine that decides whether a launch also submits the dense LAP solver's kernels (never a result):
  * one step on a caller-owned int[16] (h[0] bit 1 = "a recent launch needed the dense solver", written by the device in the product);

@@ -356,6 +356,15 @@ class MotContext:
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
         return out
 
+    def debug_predict_timing(self, n_pairs: int):
+        self._chk(self.lib.mot_debug_predict_timing(self._h, int(n_pairs)))
+
+    def debug_predict_times(self, cap: int = 256) -> np.ndarray:
+        """durations (ms) of the predict launches since debug_predict_timing() armed them, measured while the ordinary step calls ran"""
+        out = np.zeros(cap, np.float32); n = C.c_int(0)
+        self._chk(self.lib.mot_debug_predict_times(self._h, _vp(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
     def assoc_trace(self, n: int = 8192) -> np.ndarray:
         """(debug, MOT_MK_TIMING=1) thread 0's (tag, 10 ns ticks) along the sparse emulation's cycles of the most recent launch"""
         out = np.zeros(n, np.int64)

@@ -15,6 +15,7 @@
 #include "dl_lifecycle.h"
 #include <dlfcn.h>
 #include <string>
+#include <vector>
 
 // Events that order work between this context's streams on ONE device: no timing, and a DEVICE-scope release when recorded.  The
 // default (system-scope) release writes back and invalidates the caches at every record; the consumers here are kernels of the same
@@ -86,6 +87,9 @@ struct DevLoop {
     int host_spec[2] = {-1, -1};  // spectra buffer the frame in host buffer b wrote (its side-stream feature launch reads the host buffer too)
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
     bool feat_joined = false;     // ... inside the predict launch itself (no side stream, no event to wait for)
+    // (debug) in-loop timing of the predict launch: pairs of events that receive the kernel's own begin / end stamps while the normal
+    // step calls run (look-ahead, side stream and all) -- what rocprofv3 reports for the launch in the timed configuration
+    std::vector<hipEvent_t> pt; int pt_used = 0;
 };
 
 void devloop_destroy(DevLoop* d)
@@ -95,6 +99,7 @@ void devloop_destroy(DevLoop* d)
     if (d->side) (void)hipStreamSynchronize(d->side);
     if (d->copy) (void)hipStreamSynchronize(d->copy);
     if (d->ev_ok) for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->pt) (void)hipEventDestroy(e);
     if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     for (hipEvent_t e : d->ev_spec) if (e) (void)hipEventDestroy(e);
@@ -274,7 +279,9 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
             // profiling (single template size): the kernel's own begin / end stamps go to ev[0] / ev[1]
             ext_timed = ev && S.ncls <= 1;
             if (ev && !ext_timed) HIPCHK(hipEventRecord(ev[0], c->stream));
-            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream, ext_timed ? ev[0] : nullptr, ext_timed ? ev[1] : nullptr));
+            hipEvent_t t0 = ext_timed ? ev[0] : nullptr, t1 = ext_timed ? ev[1] : nullptr;
+            if (!ev && S.ncls <= 1 && (size_t)(2 * d->pt_used + 1) < d->pt.size()) { t0 = d->pt[2 * d->pt_used]; t1 = d->pt[2 * d->pt_used + 1]; d->pt_used++; }   // (debug) in-loop timing
+            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream, t0, t1));
         }
     } else { if (ev) HIPCHK(hipEventRecord(ev[0], c->stream)); HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream)); }
     if (ev && !ext_timed) HIPCHK(hipEventRecord(ev[1], c->stream));
@@ -529,6 +536,29 @@ int mot_step_frame_device_ahead(mot_ctx* c, const void* frame_dev, const void* d
     if (ahead_on) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
     rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
     return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
+}
+
+// (debug) the predict launch's own duration while the ordinary step calls run: arm n pairs of events, step n frames, read the times
+int mot_debug_predict_timing(mot_ctx* c, int n_pairs)
+{
+    if (!c || n_pairs < 0) return fail(MOT_ERR_ARG, "bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (hipEvent_t e : d->pt) (void)hipEventDestroy(e);
+    d->pt.assign((size_t)2 * n_pairs, nullptr); d->pt_used = 0;
+    for (hipEvent_t& e : d->pt) HIPCHK(hipEventCreate(&e));
+    return MOT_OK;
+}
+int mot_debug_predict_times(mot_ctx* c, float* out_ms, int cap, int* n)
+{
+    if (!c || !c->devloop || !out_ms || !n) return fail(MOT_ERR_ARG, "bad argument");
+    DevLoop* d = c->devloop;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int k = 0;
+    for (; k < d->pt_used && k < cap; k++) HIPCHK(hipEventElapsedTime(&out_ms[k], d->pt[2 * k], d->pt[2 * k + 1]));
+    *n = k; d->pt_used = 0;
+    return MOT_OK;
 }
 
 int mot_profile_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD, float* stage_ms5)
