@@ -1,16 +1,25 @@
 #!/bin/bash
-# copies the newest outputs of tools/collect_profiles.sh (gpurun_out/r03) into profiles/ under their committed names
+# copies the outputs of tools/collect_profiles.sh (gpurun_out/r04/final) into profiles/ under their committed names.  Every rocprofv3 run
+# has a directory of its own holding exactly one result set: `one` fails loudly if that is ever not so.
 set -e
 cd "$(dirname "$0")/.."
-R=gpurun_out/r03; newest() { ls -t $1 | head -1; }
-cp $R/bench_n1024.json profiles/r03_bench_n1024.json; cp $R/bench_n1024_driver.json profiles/r03_bench_n1024_driver_style.json
-for n in 64 256 512; do cp $R/bench_n$n.json profiles/r03_bench_n$n.json; done
-for f in bench_n256_s148_multiscale bench_n256_per_track_sizes_120_180 bench_n1024_per_track_sizes_64_96 bench_n256_detector_noise bench_n1000_detector_noise bench_n1024_no_lookahead bench_n1024_no_deferred_blend bench_n1024_fused_update; do cp $R/$f.json profiles/r03_$f.json; done
-cp $R/kcf_probe_n1024.log profiles/r03_kcf_probe_n1024.log
-cp $(newest "$R/kstats_default/runc/*_kernel_stats.csv") profiles/r03_kernel_stats_n1024.csv
-cp $(newest "$R/kstats_driver/runc/*_kernel_stats.csv") profiles/r03_kernel_stats_n1024_driver_style.csv
-cp $(newest "$R/kstats_s148/runc/*_kernel_stats.csv") profiles/r03_kernel_stats_n256_s148_multiscale.csv
-cp $(newest "$R/pmc_fetch/runc/*_counter_collection.csv") profiles/r03_pmc_fetch_size.csv
-cp $(newest "$R/pmc_write/runc/*_counter_collection.csv") profiles/r03_pmc_write_size.csv
-python tools/derive_traffic.py profiles/r03_pmc_fetch_size.csv profiles/r03_pmc_write_size.csv 1024 > profiles/r03_traffic.json
-python tools/derive_sq.py $(newest "$R/pmc_sq/runc/*_counter_collection.csv") > profiles/r03_sq_counters.json
+R=gpurun_out/r04/final
+one() { local n; n=$(ls $1 2>/dev/null | wc -l); if [ "$n" != "1" ]; then echo "expected exactly one file for $1, found $n" >&2; exit 1; fi; ls $1; }
+cp $R/bench_n1024.json profiles/r04_bench_n1024.json; cp $R/bench_n1024_driver.json profiles/r04_bench_n1024_driver_style.json
+for n in 64 256 512; do cp $R/bench_n$n.json profiles/r04_bench_n$n.json; done
+for f in bench_n256_s148_multiscale bench_n256_per_track_sizes_120_180 bench_n1024_per_track_sizes_64_96 bench_n256_detector_noise bench_n1000_detector_noise bench_n1024_driver_full_reset bench_n1024_full_reset bench_n64_s164 bench_n64_s168 bench_n64_s200; do cp $R/$f.json profiles/r04_$f.json; done
+cp $R/kcf_probe_n1024.log profiles/r04_kcf_probe_n1024.log
+cp $R/assoc_probe_n1024.log profiles/r04_assoc_probe_n1024.log
+cp $R/assoc_trace_n1024_frame23.log profiles/r04_assoc_trace_n1024_frame23.log; cp $R/assoc_trace_n1024_frame7.log profiles/r04_assoc_trace_n1024_frame7.log
+cp $R/ubench_latency.log profiles/r04_ubench_latency.log
+cp $(one "$R/kstats_default/*/*_kernel_stats.csv") profiles/r04_kernel_stats_n1024.csv
+cp $(one "$R/kstats_driver/*/*_kernel_stats.csv") profiles/r04_kernel_stats_n1024_driver_style.csv
+cp $(one "$R/kstats_s148/*/*_kernel_stats.csv") profiles/r04_kernel_stats_n256_s148_multiscale.csv
+cp $(one "$R/pmc_fetch/*/*_counter_collection.csv") profiles/r04_pmc_fetch_size.csv
+cp $(one "$R/pmc_write/*/*_counter_collection.csv") profiles/r04_pmc_write_size.csv
+python tools/derive_traffic.py profiles/r04_pmc_fetch_size.csv profiles/r04_pmc_write_size.csv 1024 > profiles/r04_traffic.json
+python tools/derive_sq.py $(one "$R/pmc_sq/*/*_counter_collection.csv") > profiles/r04_sq_counters.json
+cp $(one "$R/pmc_fetch_s148/*/*_counter_collection.csv") profiles/r04_pmc_fetch_size_s148.csv
+cp $(one "$R/pmc_write_s148/*/*_counter_collection.csv") profiles/r04_pmc_write_size_s148.csv
+python tools/derive_traffic.py profiles/r04_pmc_fetch_size_s148.csv profiles/r04_pmc_write_size_s148.csv 256 > profiles/r04_traffic_s148.json
+python tools/derive_sq.py $(one "$R/pmc_sq_s148/*/*_counter_collection.csv") > profiles/r04_sq_counters_s148.json
