@@ -39,8 +39,9 @@ def test_device_loop_vs_oracle(mot, oracle, kind, n, size, nframes):
         c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
         ref = m.step(frames[f], dets[f])
         boxes, tids, ages = c.live_tracks()
-        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
-        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+        diag = lambda: f"frame {f}: lap {c.lap_stats()[:16].tolist()} assoc {c.assoc_stats()[:4].tolist()} differing {[(i, bnp(boxes)[i].tolist(), bnp(ref['live'])[i].tolist()) for i in range(min(len(boxes), len(ref['live']))) if not np.array_equal(bnp(boxes)[i], bnp(ref['live'])[i])][:4]}"
+        assert np.array_equal(tids, ref["tids"]), "tids: " + diag()
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), "live boxes: " + diag()
     m.close(); c.close()
 
 
@@ -87,8 +88,9 @@ def test_device_loop_multiscale_150(mot, oracle):
         c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
         ref = m.step(frames[f], dets[f])
         boxes, tids, ages = c.live_tracks()
-        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
-        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+        diag = lambda: f"frame {f}: lap {c.lap_stats()[:16].tolist()} assoc {c.assoc_stats()[:4].tolist()} differing {[(i, bnp(boxes)[i].tolist(), bnp(ref['live'])[i].tolist()) for i in range(min(len(boxes), len(ref['live']))) if not np.array_equal(bnp(boxes)[i], bnp(ref['live'])[i])][:4]}"
+        assert np.array_equal(tids, ref["tids"]), "tids: " + diag()
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), "live boxes: " + diag()
     m.close(); c.close()
 
 
@@ -406,8 +408,9 @@ def test_device_loop_lookahead_vs_oracle(mot, oracle, n, miss, fp):
                                       fd[nxt].data_ptr() if nxt is not None else 0, dd[nxt].data_ptr() if nxt is not None else 0, len(dets[nxt]) if nxt is not None else 0)
         ref = m.step(frames[f], dets[f])
         boxes, tids, ages = c.live_tracks()
-        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
-        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+        diag = lambda: f"frame {f}: lap {c.lap_stats()[:16].tolist()} assoc {c.assoc_stats()[:4].tolist()} differing {[(i, bnp(boxes)[i].tolist(), bnp(ref['live'])[i].tolist()) for i in range(min(len(boxes), len(ref['live']))) if not np.array_equal(bnp(boxes)[i], bnp(ref['live'])[i])][:4]}"
+        assert np.array_equal(tids, ref["tids"]), "tids: " + diag()
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), "live boxes: " + diag()
     m.close(); c.close()
 
 
