@@ -203,8 +203,10 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
 // Phase 1: gradMag (gradientMex.cpp:15-37, 59-100) + orientation quantisation
 // (:119-143) -> Mq = M*(1/16) (float), bin (u8)
 // ---------------------------------------------------------------------------
+// Stripes (R1-resident HBM-slab templates): only the pixel columns [xb, xb + xn) are produced; Mq / bins are then the stripe's VIRTUAL bases
+// (stripe buffer - xb * ldp), so the column indexing below and in the histogram is the same for a stripe and a full plane.
 __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, float* __restrict__ Mq,
-                              uint8_t* __restrict__ bins, const uint16_t* __restrict__ tab, int tid, int nt)
+                              uint8_t* __restrict__ bins, const uint16_t* __restrict__ tab, int tid, int nt, int xb = 0, int xn = -1)
 {
     // one thread = 4 vertically adjacent pixels (y0..y0+3) of column x: three aligned 16-byte LDS reads + two scalars.
     // Mq / bins are stored as [x][2 + y] with column stride ldp so the 8-pixel footprint of a cell starts 16-byte aligned.
@@ -214,8 +216,10 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
     if (thr0[4] != 1) __builtin_trap();
     for (int j = 0; j < 4; j++) if (thr0[5 + j] != -thr0[3 - j] + 1) __builtin_trap();                           // the mirror structure the bin count relies on
     const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
-    for (int it = tid; it < w * ng; it += nt) {
+    if (xn < 0) xn = w;
+    for (int it = tid; it < xn * ng; it += nt) {
         uint32_t x, kq; p.d_ng.divmod((uint32_t)it, x, kq);
+        x += (uint32_t)xb;
         const int y0 = 4 * (int)kq;
         const float* Pc = P + x * LP;
         const float4 c4 = *reinterpret_cast<const float4*>(Pc + y0);
@@ -260,8 +264,8 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
         *reinterpret_cast<uint16_t*>(bo + 2) = (uint16_t)(bq[2] | (bq[3] << 8));
     }
     // the two pad slots above and below every column are read (with weight 0) by the histogram: finite magnitude, bin 0
-    for (int i = tid; i < 4 * w; i += nt) {
-        const int x = i >> 2, k = i & 3, idx = x * LP + (k < 2 ? k : LP - 4 + k);
+    for (int i = tid; i < 4 * xn; i += nt) {
+        const int x = xb + (i >> 2), k = i & 3, idx = x * LP + (k < 2 ? k : LP - 4 + k);
         Mq[idx] = 0.0f; bins[idx] = 0;
     }
 }
@@ -276,12 +280,13 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // load is an L2 round trip; the LDS-resident kernels load column by column.
 template <int NPRE, bool LDSACC = true>   // LDSACC: the accumulators live in LDS (false only for the FHOG-only test kernel of templates beyond the LDS)
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
-                           float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt)
+                           float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt, int cell_lo = 0, int cell_hi = -1)
 {
     const int hb = p.hb, wb = p.wb, nb = p.nb, LP = p.ldp;
     const int h0 = hb * 4, w0 = wb * 4;
     constexpr int GRP = NPRE ? NPRE : 1;                               // footprint columns whose loads are in flight together
-    for (int cell = tid; cell < nb; cell += nt) {
+    if (cell_hi < 0) cell_hi = nb;
+    for (int cell = cell_lo + tid; cell < cell_hi; cell += nt) {
         uint32_t cx, cy; p.d_hb.divmod((uint32_t)cell, cx, cy);
         // HBM-slab templates accumulate in a per-thread LDS scratch (the read-modify-write chain would otherwise run at L2
         // latency) and copy the finished cell out
@@ -428,6 +433,73 @@ __device__ void phase_channels(const KcfPool& p, const float* __restrict__ R1, c
         if (HALF == 1) {
             PUT(27, tex0); PUT(28, tex1); PUT(29, tex2); PUT(30, tex3);
             if (feat_out) feat_out[31 * nb + cell] = 0.0f;
+        }
+#undef PUT
+    }
+}
+
+// The same channels for an arbitrary run [c0, c1) of the 31 (R1-resident HBM-slab templates: the DFTs take a few planes at a time).  Every value is
+// produced by the statements of phase_channels above, in their order; the run is served in up to three parts -- contrast-sensitive channels (one
+// orientation each), contrast-insensitive ones (two orientations each), the four texture channels (all 18) -- so a tile only pays for the
+// orientations it stores.  F[((ch - c0)*wb + x)*ldf + y].
+// win4: the cosine-window values of the thread's cells tid, tid + nt, ... (<= 4 of them), loaded once by the caller for all tiles.
+__device__ __forceinline__ void phase_channels_tile(const KcfPool& p, const float* __restrict__ R1, const float* __restrict__ N,
+                                                    float* __restrict__ F, int c0, int c1, float* __restrict__ feat_out, int feat_windowed, int tid, int nt,
+                                                    const float (&win4)[4])
+{
+    const int hb = p.hb, wb = p.wb, nb = p.nb, hb1 = hb + 1, ldf = 2 * p.fh;
+    const float clip = 0.2f, r = .2357f;
+    const int s_lo = c0, s_hi = min(c1, MOT_NORI);                       // contrast-sensitive part: channel o = orientation o
+    const int i_lo = max(c0, MOT_NORI) - MOT_NORI, i_hi = min(c1, 27) - MOT_NORI;   // contrast-insensitive part: channel 18 + j = orientations j, j + 9
+    const bool tex = c1 > 27;
+    int jc = 0;
+#pragma unroll 1
+    for (int cell = tid; cell < nb; cell += nt, jc++) {
+        uint32_t x, y; p.d_hb.divmod((uint32_t)cell, x, y);
+        const float n0 = N[(x + 1) * hb1 + y + 1], n1 = N[(x + 1) * hb1 + y], n2 = N[x * hb1 + y + 1], n3 = N[x * hb1 + y];
+        const float win = jc == 0 ? win4[0] : (jc == 1 ? win4[1] : (jc == 2 ? win4[2] : win4[3]));
+        const float* Rc = R1 + R1W(cell, 0);                            // orientation o at Rc[o * 64]
+        float* Fc = F + x * ldf + y;                                    // channel ch at Fc[(ch - c0) * wb * ldf]
+#define PUT(ch, val) do { Fc[((ch) - c0) * wb * ldf] = (val) * win; \
+                          if (feat_out) feat_out[(ch) * nb + cell] = feat_windowed ? (val) * win : (val); } while (0)
+#pragma unroll 1
+        for (int o = s_lo; o < s_hi; o++) {
+            const float v = Rc[o * 64];
+            float t0 = v * n0; if (t0 > clip) t0 = clip;
+            float t1 = v * n1; if (t1 > clip) t1 = clip;
+            float t2 = v * n2; if (t2 > clip) t2 = clip;
+            float t3 = v * n3; if (t3 > clip) t3 = clip;
+            float hv = 0.0f;
+            hv += t0 * .5f; hv += t1 * .5f; hv += t2 * .5f; hv += t3 * .5f;
+            PUT(o, hv);
+        }
+#pragma unroll 1
+        for (int j = i_lo; j < i_hi; j++) {
+            const float v2 = Rc[j * 64] + Rc[(j + 9) * 64];             // R2 (:309)
+            float u0 = v2 * n0; if (u0 > clip) u0 = clip;
+            float u1 = v2 * n1; if (u1 > clip) u1 = clip;
+            float u2 = v2 * n2; if (u2 > clip) u2 = clip;
+            float u3 = v2 * n3; if (u3 > clip) u3 = clip;
+            float hi = 0.0f;
+            hi += u0 * .5f; hi += u1 * .5f; hi += u2 * .5f; hi += u3 * .5f;
+            PUT(MOT_NORI + j, hi);
+        }
+        if (tex) {
+            float tex0 = 0.f, tex1 = 0.f, tex2 = 0.f, tex3 = 0.f;
+#pragma unroll
+            for (int o = 0; o < MOT_NORI; o++) {
+                const float v = Rc[o * 64];
+                float t0 = v * n0; if (t0 > clip) t0 = clip;
+                float t1 = v * n1; if (t1 > clip) t1 = clip;
+                float t2 = v * n2; if (t2 > clip) t2 = clip;
+                float t3 = v * n3; if (t3 > clip) t3 = clip;
+                tex0 += t0 * r; tex1 += t1 * r; tex2 += t2 * r; tex3 += t3 * r;
+            }
+            if (27 >= c0) PUT(27, tex0);
+            if (28 >= c0 && 28 < c1) PUT(28, tex1);
+            if (29 >= c0 && 29 < c1) PUT(29, tex2);
+            if (30 >= c0 && 30 < c1) PUT(30, tex3);
+            if (feat_out && c1 == MOT_NCHAN) feat_out[31 * nb + cell] = 0.0f;
         }
 #undef PUT
     }
@@ -700,6 +772,105 @@ __device__ __attribute__((noinline)) void dft2_mfma_fixed(const KcfPool& p, int 
     }
 }
 
+// R1-resident HBM-slab templates: channels [c_lo, c_hi) -> windowed feature planes -> spectra, p.tile_T planes at a time through the LDS work area
+// (offW on).  The transform of a plane is the MFMA chain of dft2_mfma_fixed (same products, same order:
+// bit-identical spectra); what differs is the work split -- the unit is (plane, pass of 16 output floats), spread over the waves, so a tile of
+// 5 planes still feeds all 8 waves -- and that the 8 * XTL * XTL column fragments are loaded once for all tiles of the call.
+// out[((ch - c_lo)*wb + x')*ldf + n].
+template <int XTL, int KSR>
+__device__ __attribute__((noinline)) void spectrum_tiles_r1(const KcfPool& p, int c_lo, int c_hi, float* __restrict__ out,
+                                                            float* __restrict__ feat_out, int feat_windowed, int tid, int nt_, long long* dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) float dft2_smem[];
+    const float* __restrict__ R1 = dft2_smem + p.offR1c;
+    float* __restrict__ F = dft2_smem + p.offW;
+    const float* __restrict__ N = dft2_smem + p.offR1c + MOT_NORI * 64 * ((p.nb + 63) >> 6) + 2048 + 2 * p.hb + 2 * p.wb + 32;   // carve(), R1-resident order
+    const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6, q = lane >> 4, m = lane & 15;
+    const int hb = p.hb, wb = p.wb, ldf = 2 * p.fh, ntl = (ldf + 15) >> 4;
+    float cwr[XTL][XTL][4][2];
+#pragma unroll
+    for (int mt = 0; mt < XTL; mt++)
+#pragma unroll
+        for (int xt = 0; xt < XTL; xt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                cwr[mt][xt][r][0] = p.mf_cols2[(((mt * 3 + xt) * 4 + r) * 2 + 0) * 64 + lane];
+                cwr[mt][xt][r][1] = p.mf_cols2[(((mt * 3 + xt) * 4 + r) * 2 + 1) * 64 + lane];
+            }
+    // the row fragments of all (<= 3) passes and the window values of the thread's cells: no global load inside the tile loop
+    float bw0[KSR], bw1[KSR], bw2[KSR], win4[4];
+#pragma unroll
+    for (int s = 0; s < KSR; s++) { bw0[s] = p.mf_rows[lane + s * 3 * 64]; bw1[s] = p.mf_rows[64 + lane + s * 3 * 64]; bw2[s] = ntl > 2 ? p.mf_rows[128 + lane + s * 3 * 64] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) win4[j] = p.cos_win[min(tid + j * nt_, p.nb - 1)];
+#define TSTAMP(i) do { if (dbg && blockIdx.x == 0 && tid == 0 && c0 == 0) dbg[i] = wall_clock64(); } while (0)
+    for (int c0 = c_lo; c0 < c_hi; c0 += p.tile_T) {
+        const int c1 = min(c0 + p.tile_T, c_hi), nch = c1 - c0;
+        TSTAMP(12);
+        phase_channels_tile(p, R1, N, F, c0, c1, feat_out, feat_windowed, tid, nt_, win4);
+        __syncthreads();
+        TSTAMP(13);
+        const int units = nch * ntl;
+        for (int u = wave; u < units; u += nw) {
+            const int t = u / nch, ch = u - t * nch;
+            float bw[KSR];
+#pragma unroll
+            for (int s = 0; s < KSR; s++) bw[s] = t == 0 ? bw0[s] : (t == 1 ? bw1[s] : bw2[s]);
+            const int n = t * 16 + m;
+            const float* Fc = F + ch * wb * ldf;
+            float v[XTL][4], v2[XTL][4];
+#pragma unroll
+            for (int xt = 0; xt < XTL; xt++) {
+                f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+                const int x = xt * 16 + m;
+                const float* in = Fc + min(x, wb - 1) * ldf;
+                float a[KSR];
+#pragma unroll
+                for (int s = 0; s < KSR; s++) { const int k = 4 * s + q; a[s] = in[min(k, hb - 1)]; a[s] = (x < wb && k < hb) ? a[s] : 0.f; }
+#pragma unroll
+                for (int s = 0; s < KSR; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[xt][r] = acc[r];
+                    const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0xB1, 0xF, 0xF, false));   // lane ^ 1
+                    v2[xt][r] = (n & 1) ? -pv : pv;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < XTL; mt++) {
+                f32x4 o = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int xt = 0; xt < XTL; xt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(cwr[mt][xt][r][0], v[xt][r], o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(cwr[mt][xt][r][1], v2[xt][r], o, 0, 0, 0);
+                    }
+                if (n < ldf) {
+                    float* op = out + (size_t)(c0 - c_lo + ch) * wb * ldf + n;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const int xp = mt * 16 + q * 4 + r; if (xp < wb) op[xp * ldf] = o[r]; }
+                }
+            }
+        }
+        TSTAMP(14);
+        __syncthreads();
+        TSTAMP(15);
+    }
+#undef TSTAMP
+}
+// the instances: XTL = tiles of 16 lines (wb), KSR = k-steps of 4 rows (hb)
+__device__ __forceinline__ bool r1_spectrum_dispatch(const KcfPool& p, int c_lo, int c_hi, float* out, float* fo, int fw, int tid, int nt, long long* dbg)
+{
+    const int xtl = (p.wb + 15) >> 4, ksr = (p.hb + 3) >> 2;
+    if (xtl == 3 && ksr == 10) { spectrum_tiles_r1<3, 10>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 3 && ksr == 9) { spectrum_tiles_r1<3, 9>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 2 && ksr == 8) { spectrum_tiles_r1<2, 8>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 2 && ksr == 7) { spectrum_tiles_r1<2, 7>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 2 && ksr == 10) { spectrum_tiles_r1<2, 10>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    return false;
+}
+
 // ---- radix 4x5 prime-factor 20-point transforms, one thread per transform ----
 #define C1_5 0.30901699437494742f   /* cos(2pi/5) */
 #define C2_5 (-0.80901699437494742f) /* cos(4pi/5) */
@@ -899,7 +1070,7 @@ struct Regions {
     uint16_t* tab;
 };
 
-__device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* cbase = nullptr)
+__device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* cbase = nullptr, bool r1_order = false)
 {
     Regions r;
     r.A = base + p.offA; r.B = base + p.offB; r.C = cbase ? cbase : base + p.offC; r.T = base + p.offT;
@@ -907,6 +1078,17 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* c
     r.tab = reinterpret_cast<uint16_t*>(c); c += 2048;               // 4096 u16
     r.twr = reinterpret_cast<float2*>(c); c += 2 * p.hb;
     r.twc = reinterpret_cast<float2*>(c); c += 2 * p.wb;
+    if (r1_order) {
+        // R1-resident HBM-slab templates: what the gradient / histogram stripes may overwrite (E, zf, tmp) comes last, next to the work area
+        r.red_v = c; c += 16;
+        r.red_i = reinterpret_cast<int*>(c); c += 16;
+        r.N = c; c += (p.hb + 1) * (p.wb + 1);
+        c = r.C + (p.offX - p.offR1c - MOT_NORI * 64 * ((p.nb + 63) >> 6));
+        r.E = c; r.resp = c; c += (p.nb + 3) & ~3;
+        r.zf = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
+        r.tmp = reinterpret_cast<float2*>(c);
+        return r;
+    }
     r.zf = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
     r.tmp = reinterpret_cast<float2*>(c); c += 2 * p.nbins;
     r.E = c; r.resp = c; c += p.nb;                                 // the cell energies are dead long before the response exists
@@ -927,6 +1109,45 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     for (int i = tid; i < p.hb; i += nt) r.twr[i] = p.tw_r[i];
     for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
     const float* patch = l.patches ? l.patches + (size_t)item * p.rows * p.cols : nullptr;
+    if (SLAB && p.r1_lds) {
+        // R1-resident HBM-slab template.  Crop: the gray scratch of a resized box is the whole LDS (the constants above are staged again behind it),
+        // the patch goes to the slab.  Then stripes of stripe_k cell columns: gradient of the stripe's pixel columns (+ 2 / + 1 of halo) into LDS,
+        // histogram of its cells into the resident R1 -- the additions of a cell are those of phase_hist over a full plane, in the same order.
+        float* lds = smem_base();
+        const int total = (int)(MOT_LDS_LIMIT / sizeof(float));
+        const int nsrc = (box.b - box.t + 1) * (box.r - box.l + 1);
+        const bool in_lds = nsrc <= total;
+        __syncthreads();                                               // the constants staged above are not read before they are staged again
+        phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(lds), tid, nt, total * 4, in_lds ? lds : r.B, in_lds ? total : p.lds_floats - p.offB);
+        __syncthreads();
+        DBG_STAMP(1);
+        for (int i = tid; i < 2048; i += nt) reinterpret_cast<uint32_t*>(r.tab)[i] = reinterpret_cast<const uint32_t*>(p.sse_tab)[i];
+        for (int i = tid; i < p.hb; i += nt) r.twr[i] = p.tw_r[i];
+        for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
+        __syncthreads();
+        DBG_STAMP(2);
+        float* R1l = lds + p.offR1c; float* X = lds + p.offX;
+        const int k = p.stripe_k, w0 = p.wb * 4;
+        for (int cx0 = 0; cx0 < p.wb; cx0 += k) {
+            const int cx1 = min(cx0 + k, p.wb);
+            const int xb = max(0, 4 * cx0 - 2), xe = min(w0 - 1, 4 * cx1 + 1);
+            float* Mq = X - xb * p.ldp;                                // virtual bases: column x of the plane is column x - xb of the stripe
+            uint8_t* bins = reinterpret_cast<uint8_t*>(X + (4 * k + 4) * p.ldp) - xb * p.ldp;
+            phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt, xb, xe - xb + 1);
+            __syncthreads();
+            if (cx0 == 0) DBG_STAMP(10);
+            phase_hist<0, true>(p, Mq, bins, R1l, nullptr, tid, nt, cx0 * p.hb, cx1 * p.hb);
+            __syncthreads();
+            if (cx0 == 0) DBG_STAMP(11);
+        }
+        DBG_STAMP(3);
+        phase_energy<false>(p, R1l, r.E, tid, nt);
+        __syncthreads();
+        phase_norm(p, r.E, r.N, tid, nt);
+        __syncthreads();
+        DBG_STAMP(4);
+        return;
+    }
     // byte staging area of the crop: region B, or the LDS staging area of an HBM-slab template
     if (stage) {
         // gray scratch of a resized crop: the LDS staging area, or (source boxes beyond 175 x 175 at 148 px) regions B..T of the slab
@@ -953,9 +1174,15 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
 
 // one half of the channels -> windowed features -> spectrum in region B (overlays Mq / bins, then itself)
 template <int HALF, bool SLAB>
-__device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum, float* stage = nullptr)
+__device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum, float* stage = nullptr,
+                              float* out_override = nullptr)
 {
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
+    if (SLAB && p.r1_lds) {                                            // R1-resident: a few planes at a time, R1 -> features -> spectra (slab region B, or the caller's buffer)
+        if (!r1_spectrum_dispatch(p, HALF ? MOT_HALF0 : 0, HALF ? MOT_NCHAN : MOT_HALF0, out_override ? out_override : r.B, fo, l.feat_windowed, tid, nt, l.dbg)) __builtin_trap();
+        DBG_STAMP(8 + HALF);
+        return;
+    }
     // HBM-slab templates with MFMA tables: the half's feature planes go straight into the LDS staging area and both DFT
     // passes run from there (no slab round trip of the planes, no row-spectrum buffer)
     const bool fused = SLAB && spectrum && stage && p.mf && p.stage_floats >= MOT_HALF0 * p.wb * 2 * p.fh + MOT_MF_CW_FLOATS;
@@ -975,8 +1202,9 @@ template <bool kLds, bool kStagger = false>
 __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;      // HBM-slab templates: region C + staging in LDS
-    const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
+    const bool r1m = !kLds && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
+    const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int slot = l.slots[item];
     if (l.dbg && threadIdx.x == 0 && item < 4096) l.dbg[32 + 3 * item] = wall_clock64();
@@ -1092,6 +1320,11 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         }
 #pragma unroll
         for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) xmr[ch - MOT_HALF0] = xm[ch * p.nbins + bpre];   // second half: lands during its features
+    } else if (r1m && p.nbins <= nt) {
+        // R1-resident HBM-slab templates with one bin per thread: the partial sums stay in registers
+        if (tid < p.nbins) {
+            for (int ch = 0; ch < MOT_HALF0; ch++) { const float2 a = S[ch * p.nbins + tid]; const float2 m = xm[ch * p.nbins + tid]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
+        }
     } else {
         for (int b = tid; b < p.nbins; b += nt) {      // generic sizes: partial sums parked in zf
             float pr = 0.f, pi = 0.f;
@@ -1107,6 +1340,12 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
 #pragma unroll
             for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = S[(ch - MOT_HALF0) * p.nbins + tid]; const float2 m = xmr[ch - MOT_HALF0]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
             r.zf[tid] = make_float2((zr * alr) * p.norm, (zi * alr) * p.norm);
+        }
+    } else if (r1m && p.nbins <= nt) {
+        if (tid < p.nbins) {
+            for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = S[(ch - MOT_HALF0) * p.nbins + tid]; const float2 m = xm[ch * p.nbins + tid]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
+            const float al = p.alpha[(size_t)slot * p.nbins + tid];
+            r.zf[tid] = make_float2((zr * al) * p.norm, (zi * al) * p.norm);
         }
     } else {
         for (int b = tid; b < p.nbins; b += nt) {
@@ -1176,8 +1415,9 @@ template <bool kLds>
 __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
-    const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
+    const bool r1m = !kLds && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
+    const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
     const bool feat_only = l.spec_out != nullptr;                      // launch-uniform
     const int slot = feat_only ? 0 : l.slots[item];
@@ -1309,13 +1549,19 @@ template <bool kLds>
 __device__ __forceinline__ void kcf_features_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    float* stage = (!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr;
-    const Regions r = carve(p, base, (!kLds && p.szC > 0) ? smem : nullptr);
+    const bool r1m = !kLds && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
+    const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
     const bbox_t box = l.boxes_in[item];
     features_prepare<!kLds>(p, l, item, box, r, tid, nt, stage);
     const float2* S = reinterpret_cast<const float2*>(r.B);
     float2* so = l.spec_out + (size_t)item * MOT_NCHAN * p.nbins;
+    if (r1m) {                                                         // the transforms store straight into the launch's spectrum buffer
+        half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so));
+        half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so + (size_t)MOT_HALF0 * p.nbins));
+        return;
+    }
     half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
     for (int i = tid; i < MOT_HALF0 * p.nbins; i += nt) so[i] = S[i];
     __syncthreads();
@@ -1390,7 +1636,8 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_crop_kernel(const KcfPool
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-void kcf_pool_layout(KcfPool& p)
+void kcf_pool_layout_r1(KcfPool& p, bool allow);
+void kcf_pool_layout(KcfPool& p, bool allow_r1)
 {
     p.hb = p.rows / MOT_CELL; p.wb = p.cols / MOT_CELL; p.fh = p.hb / 2 + 1;
     p.nb = p.hb * p.wb; p.nbins = p.wb * p.fh;
@@ -1424,6 +1671,35 @@ void kcf_pool_layout(KcfPool& p)
             p.stage_floats = up4(G * plane2 > hist ? G * plane2 : hist);
         }
     }
+    kcf_pool_layout_r1(p, allow_r1);
+}
+
+// R1-resident mode of an HBM-slab template (see KcfPool): taken when the MFMA transform has an instance for the plane shape and the LDS holds
+// R1 + region C + a work area of >= 3 channel planes.  zf / tmp are float2 arrays: offX keeps them 8-byte aligned (up4).
+void kcf_pool_layout_r1(KcfPool& p, bool allow)
+{
+    p.r1_lds = 0; p.offR1c = 0; p.offX = 0; p.offW = 0; p.tile_T = 0; p.stripe_k = 0;
+    if (!allow || p.use_lds || p.fft20 || p.hb > MOT_DFT_MFMA_MAX || p.wb > MOT_DFT_MFMA_MAX || !mot_impl::env().kcf_r1_lds) return;
+    const int xtl = (p.wb + 15) >> 4, ksr = (p.hb + 3) >> 2;
+    if (!((xtl == 3 && (ksr == 9 || ksr == 10)) || (xtl == 2 && (ksr == 7 || ksr == 8 || ksr == 10)))) return;
+    auto up4 = [](int v) { return (v + 3) & ~3; };
+    const int total = (int)(MOT_LDS_LIMIT / sizeof(float));
+    const int r1f = MOT_NORI * 64 * ((p.nb + 63) / 64);
+    const int head = up4(2048 + 2 * p.hb + 2 * p.wb + 32 + (p.hb + 1) * (p.wb + 1));
+    const int tail = up4(p.nb) + 4 * p.nbins;                        // E / resp, zf, tmp
+    const int offX = r1f + head;
+    const int offW = up4(offX + tail);                                // the transform's tile area: behind zf / tmp (a 512-thread workgroup parks partial sums there)
+    if (offW >= total || p.nb > 4 * MOT_KCF_THREADS_SLAB) return;     // <= 4 cells per thread (window values in registers)
+    const int plane = p.wb * 2 * p.fh;
+    int T = (total - offW) / plane; if (T > 8) T = 8;
+    const int cols_max = (int)(((size_t)(total - offX) * 4) / (5 * (size_t)p.ldp));   // Mq (float) + bin (byte) per pixel
+    int k = (cols_max - 4) / 4;
+    if (T < 3 || k < 4) return;
+    const int ns = (p.wb + k - 1) / k;
+    k = (p.wb + ns - 1) / ns;                                         // same number of stripes, evenly wide
+    p.r1_lds = 1; p.offR1c = 0; p.offX = offX; p.offW = offW; p.tile_T = T; p.stripe_k = k;
+    p.szC = offX + tail - r1f;                                       // carve() takes region C at smem + r1f
+    p.stage_floats = total - p.szC; p.stage_G = 0;                   // "staging area" = everything else (kcf_lds_bytes = the whole LDS)
 }
 
 size_t kcf_lds_bytes(const KcfPool& p) { return p.use_lds ? (size_t)p.lds_floats * sizeof(float) : (size_t)(p.szC + p.stage_floats) * sizeof(float); }

@@ -2,6 +2,7 @@
 // (include/mot_abi.h).  There is no CPU compute path in this file: every stage
 // is a HIP kernel launch; when no device is available the calls fail.
 #include "mot_ctx.h"
+#include "mot_env.h"
 #include <dlfcn.h>
 
 #include "sse_tables.inc"
@@ -169,8 +170,9 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
         HIPCHK(hipMemcpy(ph->mf_rows.p, mr.data(), mr.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ph->mf_cols.p, mc.data(), mc.size() * sizeof(float), hipMemcpyHostToDevice));
         p.mf_rows = ph->mf_rows.p; p.mf_cols = ph->mf_cols.p;
-        const char* ev = getenv("MOT_DFT_MFMA"); p.mf = (ev && atoi(ev) == 0) ? 0 : 1;
+        p.mf = mot_impl::env().dft_mfma;
     }
+    if (p.r1_lds && !p.mf) kcf_pool_layout(p, false);               // the R1-resident mode is built on the MFMA transform
     if (!p.use_lds && !shared_scratch) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
     p.xm = ph->xm.p; p.alpha = ph->alpha.p; p.pos = ph->pos.p; p.scale = ph->scale.p; p.first_update = ph->first.p; p.response = ph->response.p;
     p.cos_win = ph->cos_win.p; p.yf_re = ph->yf_re.p; p.tw_r = ph->tw_r.p; p.tw_c = ph->tw_c.p; p.sse_tab = c->sse_tab.p; p.gscratch = ph->gscratch.p;
@@ -727,6 +729,18 @@ int mot_fhog_extract(mot_ctx* c, const float* patch, int h, int w, float* H_out,
     HIPCHK(hipMemcpy(dp.p, patch, npx * sizeof(float), hipMemcpyHostToDevice));
     KcfLaunch l{}; int zero = 0; HIPCHK(hipMemcpy(c->d_slots.p, &zero, sizeof(int), hipMemcpyHostToDevice));
     l.slots = c->d_slots.p; l.patches = dp.p; l.feat_out = dh.p; l.feat_windowed = windowed;
+    if (p.r1_lds) {
+        // R1-resident HBM-slab templates: the channels come out of the tracker's own feature launch (striped gradient / histogram, tiled channels), so
+        // the bit-exactness tests of the FHOG see the pipeline the device loop runs
+        DevBuf<float2> spec; HIPCHK(spec.alloc((size_t)MOT_NCHAN * p.nbins));
+        const bbox_t b0 = { 0, 0, h - 1, w - 1, 0, 0.f };
+        HIPCHK(hipMemcpy(c->d_boxes_a.p, &b0, sizeof(bbox_t), hipMemcpyHostToDevice));
+        l.boxes_in = c->d_boxes_a.p; l.spec_out = spec.p;
+        HIPCHK(launch_kcf_update(p, l, 1, c->stream, false));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(H_out, dh.p, nout * sizeof(float), hipMemcpyDeviceToHost));
+        return MOT_OK;
+    }
     HIPCHK(launch_kcf_fhog_only(p, l, 1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(H_out, dh.p, nout * sizeof(float), hipMemcpyDeviceToHost));
@@ -760,6 +774,7 @@ int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long*
     HIPCHK(hipStreamSynchronize(c->stream));
     if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (predict8 && getenv("MOT_DBG_CHANNELS")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "channels phase: half0 %lld half1 %lld ticks (of %lld, %lld)\n", t[8] - t[4], t[9] - t[5], t[5] - t[4], t[6] - t[5]); }
+    if (predict8 && getenv("MOT_DBG_EXTRA")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "extra stamps (us after stamp 0):"); for (int i = 8; i < 16; i++) fprintf(stderr, " [%d] %.1f", i, (double)(t[i] - t[0]) * 0.01); fprintf(stderr, "\n"); }
     if (update8) HIPCHK(hipMemcpy(update8, c->dbg.p + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (const char* wf = getenv("MOT_DBG_WG")) {                        // per-workgroup start / end of the last predict launch -> text file
         std::vector<long long> t(3 * 4096); HIPCHK(hipMemcpy(t.data(), c->dbg.p + 32, t.size() * sizeof(long long), hipMemcpyDeviceToHost));

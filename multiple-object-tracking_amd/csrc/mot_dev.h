@@ -40,6 +40,10 @@ struct KcfPool {
     int offA, offB, offC, offT, lds_floats;   // offT: ping-pong buffer of the generic DFT (unused by the 20x20 register FFT)
     int use_lds;              // 1: scratch in LDS, 0: per-workgroup slab in HBM, with region C and a staging area in LDS
     int szC, stage_floats, stage_G;   // !use_lds: LDS floats of region C / of the staging area, channel planes per DFT stage
+    // !use_lds, R1-resident mode (r1_lds): LDS = [R1, wave-interleaved | region C in the order tab, tw, red, N, E/resp, zf, tmp | rest].  The gradient /
+    // histogram run in stripes of stripe_k cell columns whose Mq / bins live in LDS from offX (= E) on; the DFTs take tile_T channel planes at a time
+    // through the area from offW on (behind tmp).  Only the patch and the spectra go through the slab.
+    int r1_lds, offR1c, offX, offW, tile_T, stripe_k;
     float* gscratch;          // [grid][lds_floats] when !use_lds
     // state, indexed by slot
     float2* xm;               // [cap][31][nbins]
@@ -160,7 +164,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
 hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s);
 size_t kcf_lds_bytes(const KcfPool& p);
-void kcf_pool_layout(KcfPool& p);
+void kcf_pool_layout(KcfPool& p, bool allow_r1 = true);
 
 hipError_t launch_kalman_predict(const KalmanPool& p, const int* slots, const int* count, int n, bbox_t* boxes_out, int clamp, hipStream_t s);
 hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int* count, int n, const bbox_t* boxes, hipStream_t s);

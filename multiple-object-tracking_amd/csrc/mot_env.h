@@ -24,6 +24,8 @@ struct EnvSwitches {
     int h2d_mode;            // MOT_H2D_MODE: 2 (default) copy kernel, 0 hipMemcpyAsync on the copy stream, 1 on the context's stream
     int lookahead;           // MOT_LOOKAHEAD=0: mot_step_frame_device_ahead ignores its hint
     int split_update;        // MOT_SPLIT_UPDATE=0: fused update kernel
+    int dft_mfma;            // MOT_DFT_MFMA=0: HBM-slab templates use the generic DFT instead of the MFMA products
+    int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
 };
@@ -47,6 +49,8 @@ inline const EnvSwitches& env()
         s.h2d_mode = geti("MOT_H2D_MODE", 2);
         s.lookahead = off("MOT_LOOKAHEAD") ? 0 : 1;
         s.split_update = off("MOT_SPLIT_UPDATE") ? 0 : 1;
+        s.dft_mfma = off("MOT_DFT_MFMA") ? 0 : 1;
+        s.kcf_r1_lds = off("MOT_KCF_R1LDS") ? 0 : 1;
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
         s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
         return s;
