@@ -773,7 +773,7 @@ __device__ __attribute__((noinline)) void dft2_mfma_fixed(const KcfPool& p, int 
 }
 
 // R1-resident HBM-slab templates: channels [c_lo, c_hi) -> windowed feature planes -> spectra, p.tile_T planes at a time through the LDS work area
-// (offW on).  The transform of a plane is the MFMA chain of dft2_mfma_fixed (same products, same order:
+// (offW on: E, zf, tmp are dead while this runs).  The transform of a plane is the MFMA chain of dft2_mfma_fixed (same products, same order:
 // bit-identical spectra); what differs is the work split -- the unit is (plane, pass of 16 output floats), spread over the waves, so a tile of
 // 5 planes still feeds all 8 waves -- and that the 8 * XTL * XTL column fragments are loaded once for all tiles of the call.
 // out[((ch - c_lo)*wb + x')*ldf + n].
@@ -1310,6 +1310,8 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
+    // partial sums of the first half wait here for the second: zf, or -- R1-resident templates, whose transform tiles run over zf -- slab region T
+    float2* zpark = r1m ? reinterpret_cast<float2*>(r.T) : r.zf;
     float zr = 0.f, zi = 0.f;
     half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
@@ -1329,7 +1331,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         for (int b = tid; b < p.nbins; b += nt) {      // generic sizes: partial sums parked in zf
             float pr = 0.f, pi = 0.f;
             for (int ch = 0; ch < MOT_HALF0; ch++) { const float2 a = S[ch * p.nbins + b]; const float2 m = xm[ch * p.nbins + b]; pr += a.x * m.x + a.y * m.y; pi += a.y * m.x - a.x * m.y; }
-            r.zf[b] = make_float2(pr, pi);
+            zpark[b] = make_float2(pr, pi);
         }
     }
     __syncthreads();
@@ -1349,7 +1351,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         }
     } else {
         for (int b = tid; b < p.nbins; b += nt) {
-            float pr = r.zf[b].x, pi = r.zf[b].y;
+            float pr = zpark[b].x, pi = zpark[b].y;
             for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = S[(ch - MOT_HALF0) * p.nbins + b]; const float2 m = xm[ch * p.nbins + b]; pr += a.x * m.x + a.y * m.y; pi += a.y * m.x - a.x * m.y; }
             const float al = p.alpha[(size_t)slot * p.nbins + b];
             r.zf[b] = make_float2((pr * al) * p.norm, (pi * al) * p.norm);
@@ -1439,6 +1441,7 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
+    float2* tpark = r1m ? reinterpret_cast<float2*>(r.T) : r.tmp;     // see kcf_predict_body
     const int tot0 = MOT_HALF0 * p.nbins;
     float kf = 0.f;                                                    // kcf_linear_correlation_kf (kcf.cpp:269-304), one bin per thread
     // per half: kf partial sums, then kcf_update_xf (kcf.cpp:380-395) for the channels of this half
@@ -1453,9 +1456,9 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
         if (p.nbins <= nt) {                                                                                      \
             if (tid < p.nbins) for (int ch = (C0); ch < (C1); ch++) { const float2 a = S[(ch - (C0)) * p.nbins + tid]; kf = (a.x * a.x + a.y * a.y) + kf; } \
         } else {                                                                                                  \
-            for (int b = tid; b < p.nbins; b += nt) { float q = ((C0) == 0) ? 0.f : r.tmp[b].x;                   \
+            for (int b = tid; b < p.nbins; b += nt) { float q = ((C0) == 0) ? 0.f : tpark[b].x;                   \
                 for (int ch = (C0); ch < (C1); ch++) { const float2 a = S[(ch - (C0)) * p.nbins + b]; q = (a.x * a.x + a.y * a.y) + q; } \
-                r.tmp[b].x = q; }                                                                                 \
+                tpark[b].x = q; }                                                                                 \
         }                                                                                                         \
         if (pre) {                                                                                                \
             _Pragma("unroll") for (int j = 0; j < 16; j++) {                                                      \
@@ -1503,7 +1506,7 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
     if (feat_only) return;
     // kcf_update_alpha (kcf.cpp:364-378)
     for (int b = tid; b < p.nbins; b += nt) {
-        float kq = (p.nbins <= nt) ? kf : r.tmp[b].x;
+        float kq = (p.nbins <= nt) ? kf : tpark[b].x;
         kq = kq * p.norm;
         const float a = p.yf_re[b] / (kq + p.lambda);
         const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
@@ -1688,8 +1691,8 @@ void kcf_pool_layout_r1(KcfPool& p, bool allow)
     const int head = up4(2048 + 2 * p.hb + 2 * p.wb + 32 + (p.hb + 1) * (p.wb + 1));
     const int tail = up4(p.nb) + 4 * p.nbins;                        // E / resp, zf, tmp
     const int offX = r1f + head;
-    const int offW = up4(offX + tail);                                // the transform's tile area: behind zf / tmp (a 512-thread workgroup parks partial sums there)
-    if (offW >= total || p.nb > 4 * MOT_KCF_THREADS_SLAB) return;     // <= 4 cells per thread (window values in registers)
+    const int offW = offX;                                            // the transform's tile area: E, zf, tmp are dead while it runs (partial sums wait in the slab)
+    if (offX + tail >= total || p.nb > 4 * MOT_KCF_THREADS_SLAB) return;     // <= 4 cells per thread (window values in registers)
     const int plane = p.wb * 2 * p.fh;
     int T = (total - offW) / plane; if (T > 8) T = 8;
     const int cols_max = (int)(((size_t)(total - offX) * 4) / (5 * (size_t)p.ldp));   // Mq (float) + bin (byte) per pixel

@@ -42,7 +42,7 @@ struct KcfPool {
     int szC, stage_floats, stage_G;   // !use_lds: LDS floats of region C / of the staging area, channel planes per DFT stage
     // !use_lds, R1-resident mode (r1_lds): LDS = [R1, wave-interleaved | region C in the order tab, tw, red, N, E/resp, zf, tmp | rest].  The gradient /
     // histogram run in stripes of stripe_k cell columns whose Mq / bins live in LDS from offX (= E) on; the DFTs take tile_T channel planes at a time
-    // through the area from offW on (behind tmp).  Only the patch and the spectra go through the slab.
+    // through the same area (offW).  Only the patch, the spectra and the partial correlation sums go through the slab.
     int r1_lds, offR1c, offX, offW, tile_T, stripe_k;
     float* gscratch;          // [grid][lds_floats] when !use_lds
     // state, indexed by slot
