@@ -94,7 +94,7 @@ struct Ctx {
 // ---------------------------------------------------------------------------
 __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, const float* __restrict__ patch,
                            bbox_t box, float* __restrict__ P, uint8_t* __restrict__ raw, int tid, int nt, int raw_cap = 1 << 30,
-                           float* __restrict__ gbuf = nullptr, int gcap = 0)
+                           float* __restrict__ gbuf = nullptr, int gcap = 0, long long* dbg = nullptr)
 {
     const int rows = p.rows, cols = p.cols, npx = rows * cols;
     // the pad floats below every patch column are read by the gradient of the rounded-up last 4-pixel group; those pixels
@@ -159,11 +159,13 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
     const int nsrc = hs * ws;
     if (gbuf && hs > 0 && ws > 0 && nsrc <= gcap && rows_s == hs) {
         const uint32_t uws = (uint32_t)ws;
+#pragma unroll 4
         for (int i = tid; i < nsrc; i += nt) {
             const uint32_t r = (uint32_t)i / uws, c = (uint32_t)i - r * uws;       // frame-row major: consecutive threads, consecutive pixels
             gbuf[c * urs + r] = gray_of(frame, top + (int)r, left + (int)c);
         }
         __syncthreads();
+        if (dbg && blockIdx.x == 0 && tid == 0) dbg[16] = wall_clock64();
         for (int d = tid; d < npx; d += nt) {
             uint32_t y, x; p.d_cols.divmod((uint32_t)d, y, x);
             float sy = (float)y * ys; int y0 = (int)sy; float fracy = sy - (float)y0, ifracy = 1.0f - fracy;
@@ -205,6 +207,7 @@ __device__ void phase_crop(const KcfPool& p, const uint8_t* __restrict__ frame, 
 // ---------------------------------------------------------------------------
 // Stripes (R1-resident HBM-slab templates): only the pixel columns [xb, xb + xn) are produced; Mq / bins are then the stripe's VIRTUAL bases
 // (stripe buffer - xb * ldp), so the column indexing below and in the histogram is the same for a stripe and a full plane.
+template <int UNR = 1>   // iterations the compiler may interleave (R1-resident templates: 8 waves per CU, the table look-ups of one group hide behind the next)
 __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, float* __restrict__ Mq,
                               uint8_t* __restrict__ bins, const uint16_t* __restrict__ tab, int tid, int nt, int xb = 0, int xn = -1)
 {
@@ -217,6 +220,7 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
     for (int j = 0; j < 4; j++) if (thr0[5 + j] != -thr0[3 - j] + 1) __builtin_trap();                           // the mirror structure the bin count relies on
     const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
     if (xn < 0) xn = w;
+#pragma unroll UNR
     for (int it = tid; it < xn * ng; it += nt) {
         uint32_t x, kq; p.d_ng.divmod((uint32_t)it, x, kq);
         x += (uint32_t)xb;
@@ -540,6 +544,7 @@ __device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in
         uint32_t xp, k; p.d_fh.divmod(b, xp, k);
         const float2* src = in + ch * plane + k;
         float re = 0.f, im = 0.f; int j = 0;
+#pragma unroll 4
         for (int x = 0; x < wb; x++) {
             const float2 w = twc[j]; const float2 v = src[x * fh];
             const float wi = (SIGN < 0) ? -w.y : w.y;
@@ -1024,6 +1029,7 @@ __device__ void fft_inverse_plane(const KcfPool& p, const float2* __restrict__ Z
         uint32_t x, y; p.d_hb.divmod((uint32_t)i, x, y);
         const float2* src = tmp + x * fh;
         float acc = src[0].x; int j = 0;
+#pragma unroll 4
         for (int k = 1; k < fh; k++) {
             j += (int)y; if (j >= hb) j -= hb;
             const float2 w = twr[j]; const float2 v = src[k];
@@ -1118,7 +1124,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
         const int nsrc = (box.b - box.t + 1) * (box.r - box.l + 1);
         const bool in_lds = nsrc <= total;
         __syncthreads();                                               // the constants staged above are not read before they are staged again
-        phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(lds), tid, nt, total * 4, in_lds ? lds : r.B, in_lds ? total : p.lds_floats - p.offB);
+        phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(lds), tid, nt, total * 4, in_lds ? lds : r.B, in_lds ? total : p.lds_floats - p.offB, l.dbg);
         __syncthreads();
         DBG_STAMP(1);
         for (int i = tid; i < 2048; i += nt) reinterpret_cast<uint32_t*>(r.tab)[i] = reinterpret_cast<const uint32_t*>(p.sse_tab)[i];
@@ -1133,7 +1139,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
             const int xb = max(0, 4 * cx0 - 2), xe = min(w0 - 1, 4 * cx1 + 1);
             float* Mq = X - xb * p.ldp;                                // virtual bases: column x of the plane is column x - xb of the stripe
             uint8_t* bins = reinterpret_cast<uint8_t*>(X + (4 * k + 4) * p.ldp) - xb * p.ldp;
-            phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt, xb, xe - xb + 1);
+            phase_gradmag<2>(p, r.A, Mq, bins, r.tab, tid, nt, xb, xe - xb + 1);
             __syncthreads();
             if (cx0 == 0) DBG_STAMP(10);
             phase_hist<0, true>(p, Mq, bins, R1l, nullptr, tid, nt, cx0 * p.hb, cx1 * p.hb);
@@ -1358,9 +1364,12 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         }
     }
     __syncthreads();
+    DBG_STAMP(17);
     fft_inverse_plane(p, r.zf, r.tmp, r.resp, r.twr, r.twc, tid, nt);
+    DBG_STAMP(18);
     for (int i = tid; i < p.nb; i += nt) p.response[(size_t)slot * p.nb + i] = r.resp[i];
     const int best = block_argmax_first(r.resp, p.nb, r.red_v, r.red_i, tid, nt);
+    DBG_STAMP(19);
     if (tid == 0) {
         int vd = 1, hd = 1;
         if (best >= 0) { hd = best / p.hb + 1; vd = best - (hd - 1) * p.hb + 1; }

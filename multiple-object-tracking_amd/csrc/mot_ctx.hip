@@ -774,7 +774,7 @@ int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long*
     HIPCHK(hipStreamSynchronize(c->stream));
     if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (predict8 && getenv("MOT_DBG_CHANNELS")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "channels phase: half0 %lld half1 %lld ticks (of %lld, %lld)\n", t[8] - t[4], t[9] - t[5], t[5] - t[4], t[6] - t[5]); }
-    if (predict8 && getenv("MOT_DBG_EXTRA")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "extra stamps (us after stamp 0):"); for (int i = 8; i < 16; i++) fprintf(stderr, " [%d] %.1f", i, (double)(t[i] - t[0]) * 0.01); fprintf(stderr, "\n"); }
+    if (predict8 && getenv("MOT_DBG_EXTRA")) { long long t[24]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "extra stamps (us after stamp 0):"); for (int i = 8; i < 20; i++) fprintf(stderr, " [%d] %.1f", i, (double)(t[i] - t[0]) * 0.01); fprintf(stderr, "\n"); }
     if (update8) HIPCHK(hipMemcpy(update8, c->dbg.p + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (const char* wf = getenv("MOT_DBG_WG")) {                        // per-workgroup start / end of the last predict launch -> text file
         std::vector<long long> t(3 * 4096); HIPCHK(hipMemcpy(t.data(), c->dbg.p + 32, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
