@@ -220,8 +220,7 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
     for (int j = 0; j < 4; j++) if (thr0[5 + j] != -thr0[3 - j] + 1) __builtin_trap();                           // the mirror structure the bin count relies on
     const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
     if (xn < 0) xn = w;
-#pragma unroll UNR
-    for (int it = tid; it < xn * ng; it += nt) {
+    auto group = [&](int it) {
         uint32_t x, kq; p.d_ng.divmod((uint32_t)it, x, kq);
         x += (uint32_t)xb;
         const int y0 = 4 * (int)kq;
@@ -266,6 +265,12 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
         uint8_t* bo = bins + x * LP + 2 + y0;                          // 2-byte aligned
         *reinterpret_cast<uint16_t*>(bo) = (uint16_t)(bq[0] | (bq[1] << 8));
         *reinterpret_cast<uint16_t*>(bo + 2) = (uint16_t)(bq[2] | (bq[3] << 8));
+    };
+    if (UNR > 1) {
+#pragma unroll UNR
+        for (int it = tid; it < xn * ng; it += nt) group(it);
+    } else {
+        for (int it = tid; it < xn * ng; it += nt) group(it);       // the compiler's own choice, as before the stripes existed
     }
     // the two pad slots above and below every column are read (with weight 0) by the histogram: finite magnitude, bin 0
     for (int i = tid; i < 4 * xn; i += nt) {
@@ -1105,7 +1110,7 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* c
 }
 
 // Everything up to R1 (region A) and the norm matrix: shared by predict / update.
-template <bool SLAB, bool LDSR1 = true>
+template <bool SLAB, bool LDSR1 = true, bool R1 = false>
 __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt, float* stage = nullptr)
 {
 #define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
@@ -1115,7 +1120,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     for (int i = tid; i < p.hb; i += nt) r.twr[i] = p.tw_r[i];
     for (int i = tid; i < p.wb; i += nt) r.twc[i] = p.tw_c[i];
     const float* patch = l.patches ? l.patches + (size_t)item * p.rows * p.cols : nullptr;
-    if (SLAB && p.r1_lds) {
+    if (SLAB && R1 && p.r1_lds) {
         // R1-resident HBM-slab template.  Crop: the gray scratch of a resized box is the whole LDS (the constants above are staged again behind it),
         // the patch goes to the slab.  Then stripes of stripe_k cell columns: gradient of the stripe's pixel columns (+ 2 / + 1 of halo) into LDS,
         // histogram of its cells into the resident R1 -- the additions of a cell are those of phase_hist over a full plane, in the same order.
@@ -1179,12 +1184,12 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
 }
 
 // one half of the channels -> windowed features -> spectrum in region B (overlays Mq / bins, then itself)
-template <int HALF, bool SLAB>
+template <int HALF, bool SLAB, bool R1 = false>
 __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum, float* stage = nullptr,
                               float* out_override = nullptr)
 {
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
-    if (SLAB && p.r1_lds) {                                            // R1-resident: a few planes at a time, R1 -> features -> spectra (slab region B, or the caller's buffer)
+    if (SLAB && R1 && p.r1_lds) {                                      // R1-resident: a few planes at a time, R1 -> features -> spectra (slab region B, or the caller's buffer)
         if (!r1_spectrum_dispatch(p, HALF ? MOT_HALF0 : 0, HALF ? MOT_NCHAN : MOT_HALF0, out_override ? out_override : r.B, fo, l.feat_windowed, tid, nt, l.dbg)) __builtin_trap();
         DBG_STAMP(8 + HALF);
         return;
@@ -1204,11 +1209,12 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
     else if (spectrum) fft_forward<SLAB>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
 }
 
-template <bool kLds, bool kStagger = false>
+template <int kMode, bool kStagger = false>   // kMode 0: HBM slab, 1: LDS, 2: HBM slab with the R1-resident pipeline compiled in (kernels of their own: the other sizes keep their code)
 __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
+    constexpr bool kLds = kMode == 1;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    const bool r1m = !kLds && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    const bool r1m = kMode == 2 && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
     float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1311,7 +1317,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
-    features_prepare<!kLds>(p, l, item, pos, r, tid, nt, stage);
+    features_prepare<!kLds, true, kMode == 2>(p, l, item, pos, r, tid, nt, stage);
     if (late) blend();
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
@@ -1319,7 +1325,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     // partial sums of the first half wait here for the second: zf, or -- R1-resident templates, whose transform tiles run over zf -- slab region T
     float2* zpark = r1m ? reinterpret_cast<float2*>(r.T) : r.zf;
     float zr = 0.f, zi = 0.f;
-    half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     if (pre) {
         if (tid < p.nbins) {
@@ -1341,7 +1347,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         }
     }
     __syncthreads();
-    half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(6);
     if (pre) {
         if (tid < p.nbins) {
@@ -1400,33 +1406,34 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     DBG_STAMP(7);
 }
 
-template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    kcf_predict_body<kLds, kLds>(p, l, item, smem);
+    kcf_predict_body<kMode, kMode == 1>(p, l, item, smem);
 }
 // size classes (device loop with per-track template sizes, kcf.cpp:148-152): the workgroup's pool descriptor comes from a device
 // table, indexed by the class of its track
-template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
     const KcfPool p = l.pools[l.cls[item]];
-    kcf_predict_body<kLds>(p, l, item, smem);
+    kcf_predict_body<kMode>(p, l, item, smem);
 }
 
-template <bool kLds>
+template <int kMode>
 __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
+    constexpr bool kLds = kMode == 1;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    const bool r1m = !kLds && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    const bool r1m = kMode == 2 && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
     float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1446,7 +1453,7 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
 #pragma unroll
         for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
     }
-    if (!dspec) features_prepare<!kLds>(p, l, item, box, r, tid, nt, stage);
+    if (!dspec) features_prepare<!kLds, true, kMode == 2>(p, l, item, box, r, tid, nt, stage);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -1500,12 +1507,12 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
             }
         }
     } else {
-    if (!dspec) half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
+    if (!dspec) half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     UPDATE_HALF(0, MOT_HALF0);
     if (!dspec) {
         __syncthreads();
-        half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
+        half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
     }
     DBG_STAMP(6);
     UPDATE_HALF(MOT_HALF0, MOT_NCHAN);
@@ -1529,84 +1536,85 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
     DBG_STAMP(7);
 }
 
-template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (l.grid_stride) {                                               // few items, count known on the device only: a small grid loops
         const int cnt = min(n, l.count ? *l.count : n);
-        for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kLds>(p, l, item, smem); __syncthreads(); }
+        for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode>(p, l, item, smem); __syncthreads(); }
         return;
     }
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    kcf_update_body<kLds>(p, l, item, smem);
+    kcf_update_body<kMode>(p, l, item, smem);
 }
-template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
     const KcfPool p = l.pools[l.cls[item]];
-    kcf_update_body<kLds>(p, l, item, smem);
+    kcf_update_body<kMode>(p, l, item, smem);
 }
 
 // Feature-only launch of the split update (device loop): crop -> FHOG -> 31 spectra of every DETECTION box, written to l.spec_out.
 // A kernel of its own: inside kcf_update_kernel the model prefetch and the blend paths it never takes cost it 300 spilled VGPRs
 // (1 KB of scratch per lane) -- and this launch is the one that shares the chip with the association chain every frame.
-template <bool kLds>
+template <int kMode>
 __device__ __forceinline__ void kcf_features_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
+    constexpr bool kLds = kMode == 1;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    const bool r1m = !kLds && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    const bool r1m = kMode == 2 && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
     float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
     const bbox_t box = l.boxes_in[item];
-    features_prepare<!kLds>(p, l, item, box, r, tid, nt, stage);
+    features_prepare<!kLds, true, kMode == 2>(p, l, item, box, r, tid, nt, stage);
     const float2* S = reinterpret_cast<const float2*>(r.B);
     float2* so = l.spec_out + (size_t)item * MOT_NCHAN * p.nbins;
     if (r1m) {                                                         // the transforms store straight into the launch's spectrum buffer
-        half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so));
-        half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so + (size_t)MOT_HALF0 * p.nbins));
+        half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so));
+        half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so + (size_t)MOT_HALF0 * p.nbins));
         return;
     }
-    half_spectrum<0, !kLds>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
     for (int i = tid; i < MOT_HALF0 * p.nbins; i += nt) so[i] = S[i];
     __syncthreads();
-    half_spectrum<1, !kLds>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
     so += (size_t)MOT_HALF0 * p.nbins;
     for (int i = tid; i < (MOT_NCHAN - MOT_HALF0) * p.nbins; i += nt) so[i] = S[i];
 }
 
-template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    kcf_features_body<kLds>(p, l, item, smem);
+    kcf_features_body<kMode>(p, l, item, smem);
 }
 
 // Small frames (predict + feature workgroups fit the chip together): ONE launch carries both -- workgroups [0, n_pred) predict the
 // tracks, workgroups [n_pred, n_pred + n_feat) compute the detection spectra of the split update.  No side stream, no event pair, no
 // cross-stream wait: at 64 tracks those cost more than the kernels' own work.
-template <bool kLds>
-__global__ void __launch_bounds__(kLds ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kLds || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < n_pred) {
         const int item = blockIdx.x;
         if (lp.count && item >= *lp.count) return;
-        kcf_predict_body<kLds>(p, lp, item, smem);
+        kcf_predict_body<kMode>(p, lp, item, smem);
     } else {
         const int item = (int)blockIdx.x - n_pred;
         if (item >= n_feat) return;
-        kcf_features_body<kLds>(p, lf, item, smem);
+        kcf_features_body<kMode>(p, lf, item, smem);
     }
 }
 
@@ -1725,25 +1733,40 @@ static hipError_t set_lds_attr(K kern, size_t bytes)
     return mot_impl::func_lds_once(reinterpret_cast<const void*>(kern), MOT_LDS_LIMIT);
 }
 
+// kernel mode of a launch: 1 = LDS-resident template, 2 = HBM slab with the R1-resident pipeline (the pool's, or any pool's of a size-class
+// launch: l.r1_any), 0 = plain HBM slab
+#define KCF_LAUNCH3(KERN, R1, GRID, LDSB, STREAM, ...)                                                                          \
+    do {                                                                                                                        \
+        if (p.use_lds)  { hipError_t e_ = set_lds_attr(KERN<1>, LDSB); if (e_ != hipSuccess) return e_;                         \
+                          hipLaunchKernelGGL(KERN<1>, dim3(GRID), dim3(MOT_KCF_THREADS), LDSB, STREAM, __VA_ARGS__); }          \
+        else if (R1)    { hipError_t e_ = set_lds_attr(KERN<2>, LDSB); if (e_ != hipSuccess) return e_;                         \
+                          hipLaunchKernelGGL(KERN<2>, dim3(GRID), dim3(MOT_KCF_THREADS_SLAB), LDSB, STREAM, __VA_ARGS__); }     \
+        else            { hipError_t e_ = set_lds_attr(KERN<0>, LDSB); if (e_ != hipSuccess) return e_;                         \
+                          hipLaunchKernelGGL(KERN<0>, dim3(GRID), dim3(MOT_KCF_THREADS_SLAB), LDSB, STREAM, __VA_ARGS__); }     \
+    } while (0)
+
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)
 {
     if (n <= 0) return hipSuccess;
     if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
         const size_t ldsm = l.lds_bytes;
-        if (p.use_lds) { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<true>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
-        else { hipError_t e = set_lds_attr(kcf_predict_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_predict_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), ldsm, s, l, n); }
+        KCF_LAUNCH3(kcf_predict_multi_kernel, l.r1_any, n, ldsm, s, l, n);
         return hipGetLastError();
     }
     const size_t lds = kcf_lds_bytes(p);
-    if (p.use_lds) {
-        hipError_t e = set_lds_attr(kcf_predict_kernel<true>, lds); if (e != hipSuccess) return e;
-        if (t_start && t_stop) hipExtLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n);
-        else hipLaunchKernelGGL(kcf_predict_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
-    } else {
-        hipError_t e = set_lds_attr(kcf_predict_kernel<false>, lds); if (e != hipSuccess) return e;
-        if (t_start && t_stop) hipExtLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), (unsigned)lds, s, t_start, t_stop, 0, p, l, n);
-        else hipLaunchKernelGGL(kcf_predict_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
+    if (t_start && t_stop && p.use_lds) {                              // (debug) the launch brackets itself with the caller's events
+        hipError_t e = set_lds_attr(kcf_predict_kernel<1>, lds); if (e != hipSuccess) return e;
+        hipExtLaunchKernelGGL(kcf_predict_kernel<1>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n);
+        return hipGetLastError();
     }
+    if (t_start && t_stop) {
+        if (p.r1_lds) { hipError_t e = set_lds_attr(kcf_predict_kernel<2>, lds); if (e != hipSuccess) return e;
+                        hipExtLaunchKernelGGL(kcf_predict_kernel<2>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_predict_kernel<0>, lds); if (e != hipSuccess) return e;
+               hipExtLaunchKernelGGL(kcf_predict_kernel<0>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
+        return hipGetLastError();
+    }
+    KCF_LAUNCH3(kcf_predict_kernel, p.r1_lds, n, lds, s, p, l, n);
     return hipGetLastError();
 }
 
@@ -1751,13 +1774,7 @@ hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp, in
 {
     if (n_pred + n_feat <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
-    if (p.use_lds) {
-        hipError_t e = set_lds_attr(kcf_predict_features_kernel<true>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_predict_features_kernel<true>, dim3(n_pred + n_feat), dim3(MOT_KCF_THREADS), lds, s, p, lp, lf, n_pred, n_feat);
-    } else {
-        hipError_t e = set_lds_attr(kcf_predict_features_kernel<false>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_predict_features_kernel<false>, dim3(n_pred + n_feat), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, lp, lf, n_pred, n_feat);
-    }
+    KCF_LAUNCH3(kcf_predict_features_kernel, p.r1_lds, n_pred + n_feat, lds, s, p, lp, lf, n_pred, n_feat);
     return hipGetLastError();
 }
 
@@ -1766,8 +1783,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     if (n <= 0) return hipSuccess;
     if (l.pools) {
         const size_t ldsm = l.lds_bytes;
-        if (p.use_lds) { hipError_t e = set_lds_attr(kcf_update_multi_kernel<true>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), ldsm, s, l, n); }
-        else { hipError_t e = set_lds_attr(kcf_update_multi_kernel<false>, ldsm); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_update_multi_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), ldsm, s, l, n); }
+        KCF_LAUNCH3(kcf_update_multi_kernel, l.r1_any, n, ldsm, s, l, n);
         return hipGetLastError();
     }
     size_t lds = kcf_lds_bytes(p);
@@ -1777,19 +1793,13 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     // grid_stride: the workgroups loop over up to n items (device-side count, usually zero): a grid of n / 8 workgroups, 4 .. 128
     const int grid = l.grid_stride ? (n / 8 < 4 ? (n < 4 ? n : 4) : (n / 8 > 128 ? 128 : n / 8)) : n;
     if (l.spec_out) {                                                  // feature-only launch: the lean kernel
-        if (p.use_lds) { hipError_t e = set_lds_attr(kcf_features_kernel<true>, lds); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_features_kernel<true>, dim3(n), dim3(MOT_KCF_THREADS), lds, s, p, l, n); }
-        else { hipError_t e = set_lds_attr(kcf_features_kernel<false>, lds); if (e != hipSuccess) return e; hipLaunchKernelGGL(kcf_features_kernel<false>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n); }
+        KCF_LAUNCH3(kcf_features_kernel, p.r1_lds, n, lds, s, p, l, n);
         return hipGetLastError();
     }
-    if (p.use_lds) {
-        hipError_t e = set_lds_attr(kcf_update_kernel<true>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_update_kernel<true>, dim3(grid), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
-    } else {
-        hipError_t e = set_lds_attr(kcf_update_kernel<false>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kcf_update_kernel<false>, dim3(grid), dim3(MOT_KCF_THREADS_SLAB), lds, s, p, l, n);
-    }
+    KCF_LAUNCH3(kcf_update_kernel, p.r1_lds, grid, lds, s, p, l, n);
     return hipGetLastError();
 }
+#undef KCF_LAUNCH3
 
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
 {

@@ -97,6 +97,7 @@ struct KcfLaunch {
     const int* cls;           // [n] class of every item
     int slab_stride;          // floats per slab of the shared HBM scratch (0: the pool's own lds_floats)
     unsigned lds_bytes;       // dynamic LDS of the launch = the largest need of any class
+    int r1_any;               // some class runs the R1-resident pipeline (KcfPool::r1_lds): the launch takes the kernels built with it
 };
 
 struct KalmanPool {

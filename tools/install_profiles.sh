@@ -3,12 +3,14 @@
 # has a directory of its own holding exactly one result set: `one` fails loudly if that is ever not so.
 set -e
 cd "$(dirname "$0")/.."
+# NOTE: gpurun MERGES into gpurun_out/: delete gpurun_out/r04/final locally before a new collection, or `one` below trips over the previous run
 R=gpurun_out/r04/final
 one() { local n; n=$(ls $1 2>/dev/null | wc -l); if [ "$n" != "1" ]; then echo "expected exactly one file for $1, found $n" >&2; exit 1; fi; ls $1; }
 cp $R/bench_n1024.json profiles/r04_bench_n1024.json; cp $R/bench_n1024_driver.json profiles/r04_bench_n1024_driver_style.json
 for n in 64 256 512; do cp $R/bench_n$n.json profiles/r04_bench_n$n.json; done
 for f in bench_n256_s148_multiscale bench_n256_per_track_sizes_120_180 bench_n1024_per_track_sizes_64_96 bench_n256_detector_noise bench_n1000_detector_noise bench_n1024_driver_full_reset bench_n1024_full_reset bench_n64_s164 bench_n64_s168 bench_n64_s200; do cp $R/$f.json profiles/r04_$f.json; done
 cp $R/kcf_probe_n1024.log profiles/r04_kcf_probe_n1024.log
+cp $R/kcf_probe_n256_s148.log profiles/r04_kcf_probe_n256_s148.log; cp $R/bench_n256_s148_multiscale_slab_pipeline.json profiles/r04_bench_n256_s148_multiscale_slab_pipeline.json
 cp $R/assoc_probe_n1024.log profiles/r04_assoc_probe_n1024.log
 cp $R/assoc_trace_n1024_frame23.log profiles/r04_assoc_trace_n1024_frame23.log; cp $R/assoc_trace_n1024_frame7.log profiles/r04_assoc_trace_n1024_frame7.log
 cp $R/ubench_latency.log profiles/r04_ubench_latency.log
