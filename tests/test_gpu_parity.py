@@ -662,3 +662,14 @@ def test_step_frame_chain_entry_point(mot, oracle):
     bad = Chain(); bad.nbox = 129
     assert lib.mot_step_frame_chain(c._h, C.byref(bad), None, None, None, None, None, None) == -1
     m.close(); c.close()
+
+
+def test_kcf_hbm_slab_pipeline_subprocess():
+    """MOT_KCF_R1LDS=0: templates of 104..164 px run round 3's pipeline (patch, gradient planes, R1 and spectra in the per-workgroup HBM slab,
+    dft2_mfma_fixed) instead of the R1-resident one -- the same parity tests at those sizes, in a child process with the switch set."""
+    import subprocess, sys
+    env = dict(os.environ, MOT_KCF_R1LDS="0")
+    sel = "kcf_seq_148 or (test_fhog_vs_oracle_bit_exact and 148) or (test_fhog_vs_oracle_bit_exact and 150) or test_kcf_nonsquare_templates_vs_oracle"
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", sel, "-p", "no:cacheprovider"],
+                         cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
