@@ -399,8 +399,8 @@ def main():
             stage = acc / n_prof
 
         # third timed window: the frame and its detections arrive from pinned host memory INSIDE the timed region (SURVEY 8d:
-        # "frame-level costs (H2D of the frame ...) are included in wall time").  Copy stream + two device buffers: the upload of
-        # frame f + 1 overlaps the kernels of frame f; a buffer is reused only after the frame that read it has finished.
+        # "frame-level costs (H2D of the frame ...) are included in wall time").  Copy stream + three device buffers: the upload of
+        # frame f + 2 overlaps the association chain of frame f; a buffer is reused only after the frame that read it has finished.
         h2d = None
         if n_h2d:
             # a FRESH context over the SAME frames as `value`: frames 0 .. warmup host-fed and untimed, then exactly `steps` frames timed
@@ -421,7 +421,7 @@ def main():
             th = time.perf_counter() - th0
             h2d = {"h2d": "included", "value": hctx.live_count() * args.steps / th, "unit": "tracker-updates/s", "ms_per_step": th / args.steps * 1e3, "frames": args.steps,
                    "first_frame": 1 + args.warmup, "same_frames_as_value": True, "bytes_per_frame": frame_bytes + det_counts[1 + args.warmup] * 24,
-                   "how": "a fresh context fed through mot_step_frame_host over the same frames as `value`: pinned host frames, copy kernel on the context's copy stream, two device buffers (upload of frame f+1 overlaps the kernels of frame f); no look-ahead (the next frame is not resident yet)"}
+                   "how": "a fresh context fed through mot_step_frame_host over the same frames as `value`: pinned host frames, copy kernel on the context's copy stream, three device buffers: the upload of frame f + 2 and the detection features of frame f + 1 run beside the association chain of frame f"}
             hctx.close()
 
     if rank == 0:

@@ -202,8 +202,9 @@ int mot_step_frame_device_ahead(mot_ctx* ctx, const void* frame_dev, const void*
 int mot_step_begin_device(mot_ctx* ctx, const void* frame_dev, void** local_boxes_dev, int* slots_per_rank);
 int mot_step_finish_device(mot_ctx* ctx, const void* gathered_boxes_dev, const void* dets_dev, int nD);
 /* The same frame step fed from HOST memory (td.cpp:326-333: the tracker thread receives each frame and its detection list from the
- * capture / detector side): the 2.76 MB frame and the boxes are uploaded on a copy stream of the context into one of two device
- * buffers, so the upload of frame f + 1 overlaps the kernels of frame f; the call only enqueues.  host_bgr / host_dets should be
+ * capture / detector side): the 2.76 MB frame and the boxes are uploaded on a copy stream of the context into one of three device
+ * buffers, so the upload of frame f + 2 (and the detection features of frame f + 1) overlap the association of frame f; the call only
+ * enqueues.  host_bgr / host_dets should be
  * pinned (hipHostMalloc / cudaHostAlloc'ed) and must stay valid until the frame has been executed (mot_ctx_sync / mot_live_*). */
 int mot_step_frame_host(mot_ctx* ctx, const uint8_t* host_bgr, const bbox_t* host_dets, int nD);
 /* The sharded frame as ONE native call (multi-GPU hosts written in C/C++, e.g. a td.cpp-style tracker thread per GPU): predict of the

@@ -83,10 +83,12 @@ struct DevLoop {
     const void* next_frame = nullptr; const void* next_dets = nullptr; int next_nD = 0;
     hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_in = nullptr; bool split = false;
     // mot_step_frame_host: copy stream + two device buffers (frame, detections); up[b]: upload of buffer b done, done[b]: the frame that read it finished
-    hipStream_t copy = nullptr; DevBuf<uint8_t> hbuf[2]; DevBuf<bbox_t> dbuf[2]; hipEvent_t ev_up[2]{}, ev_done[2]{}; unsigned host_no = 0; bool host_ok = false;
-    int host_spec[2] = {-1, -1};  // spectra buffer the frame in host buffer b wrote (its side-stream feature launch reads the host buffer too)
+    // host-fed loop (mot_step_frame_host): three device buffers for frame + boxes, an upload event per buffer, and a ring of the chain events of the last
+    // three frames (ev_mid points at the current one); ev_mid0 is the event the device-resident calls use
+    hipStream_t copy = nullptr; DevBuf<uint8_t> hbuf[3]; DevBuf<bbox_t> dbuf[3]; hipEvent_t ev_up[3]{}, ev_ring[3]{}, ev_mid0 = nullptr; unsigned host_no = 0; bool host_ok = false;
     bool feat_early = false;      // this frame's detection features were launched at the start of the frame
     bool feat_joined = false;     // ... inside the predict launch itself (no side stream, no event to wait for)
+    bool want_mid = false, mid_valid = false;   // host-fed loop: every frame records ev_mid in its chain (the next call's feature launch is ordered behind it)
     // (debug) in-loop timing of the predict launch: pairs of events that receive the kernel's own begin / end stamps while the normal
     // step calls run (look-ahead, side stream and all) -- what rocprofv3 reports for the launch in the timed configuration
     std::vector<hipEvent_t> pt; int pt_used = 0;
@@ -100,11 +102,11 @@ void devloop_destroy(DevLoop* d)
     if (d->copy) (void)hipStreamSynchronize(d->copy);
     if (d->ev_ok) for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->pt) (void)hipEventDestroy(e);
-    if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     for (hipEvent_t e : d->ev_spec) if (e) (void)hipEventDestroy(e);
     if (d->side) (void)hipStreamDestroy(d->side);
-    if (d->host_ok) { for (int b = 0; b < 2; b++) { (void)hipEventDestroy(d->ev_up[b]); (void)hipEventDestroy(d->ev_done[b]); } (void)hipStreamDestroy(d->copy); }
+    if (d->host_ok) { d->ev_mid = d->ev_mid0; for (int b = 0; b < 3; b++) { (void)hipEventDestroy(d->ev_up[b]); (void)hipEventDestroy(d->ev_ring[b]); } (void)hipStreamDestroy(d->copy); }
+    if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
     delete d;
 }
 
@@ -313,7 +315,8 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
                        (S.cap + S.world - 1) / S.world + d->next_nD > split_early_max();
     // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
     LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
-    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (feat_here || ahead) ? d->ev_mid : nullptr, &life));
+    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, (feat_here || ahead || d->want_mid) ? d->ev_mid : nullptr, &life));
+    d->mid_valid = feat_here || ahead || d->want_mid;
     if (feat_here || ahead) HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
     if (feat_here) {
         // features of every detection box, on the side stream, from the moment the association chain starts (its one-workgroup kernels
@@ -476,13 +479,23 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
     const size_t fbytes = (size_t)MOT_FRAME_W * MOT_FRAME_H * 3;
     if (!d->host_ok) {
         HIPCHK(hipStreamCreateWithFlags(&d->copy, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < 3; b++) {
             HIPCHK(d->hbuf[b].alloc(fbytes)); HIPCHK(d->dbuf[b].alloc((size_t)c->cfg.max_dets));
-            HIPCHK(hipEventCreateWithFlags(&d->ev_up[b], MOT_EVENT_FLAGS)); HIPCHK(hipEventCreateWithFlags(&d->ev_done[b], MOT_EVENT_FLAGS));
+            HIPCHK(hipEventCreateWithFlags(&d->ev_up[b], MOT_EVENT_FLAGS)); HIPCHK(hipEventCreateWithFlags(&d->ev_ring[b], MOT_EVENT_FLAGS));
         }
+        d->ev_mid0 = d->ev_mid;
         d->host_ok = true;
     }
-    const int b = (int)(d->host_no & 1);
+    // Frame f lives in buffer f % 3.  Schedule (the host runs ahead of the GPU, so these orderings decide where things execute):
+    //   copy stream:  upload(f)   behind the chain event of frame f - 2  -> beside the association chain of frame f - 2
+    //   side stream:  features(f) behind the chain event of frame f - 1 and the upload -> beside the chain of frame f - 1 (one frame of look-ahead
+    //                 without the caller's help: the features need only the uploaded frame and boxes; dl_begin recognises the buffer, pf_*)
+    //   main stream:  predict(f) behind the upload -- nothing but the predict runs in a predict's window, as in the device-resident loop.
+    // The chain event of frame g is recorded behind predict(g), and predict(g) starts behind everything of frame g - 1 (its blend prologue waited for
+    // features(g - 1), the residual update of g - 1 precedes it in stream order): so event(f - 2) says buffer (f - 3) % 3 = f % 3 is free, and event(f - 1)
+    // says the spectra buffer features(f) overwrites (last read by predict(f - 1)'s blend) is free.
+    const unsigned f = d->host_no;
+    const int b = (int)(f % 3);
     // MOT_H2D_MODE: 2 (default) copy KERNEL on the copy stream (pinned, device-mapped host memory; anything else falls back to 0),
     // 0 hipMemcpyAsync on the copy stream, 1 hipMemcpyAsync on the context's own stream (no overlap, no cross-stream events)
     const int h2d_mode = mot_impl::env().h2d_mode;
@@ -495,15 +508,14 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         if (okf && okd) { by_kernel = true; src_f = af.devicePointer; if (nD) src_d = ad.devicePointer; }
         else (void)hipGetLastError();                                  // pageable / unregistered memory: the runtime's staged copy below
     }
+    const bool lookahead = h2d_mode != 1 && d->split && d->S.kind == MOT_TRACKER_KCF && d->S.ncls <= 1 && mot_impl::env().lookahead;
+    // without the look-ahead launches (Kalman, size classes, switched off) a frame's own feature launch may still read its buffer when the chain event
+    // of the next frame is recorded: those configurations order the upload behind the END of frame f - 3 instead (its last event on the side stream too)
     if (h2d_mode == 1) {
-        if (d->host_no >= 2 && d->host_spec[b] >= 0 && d->spec_side[d->host_spec[b]]) HIPCHK(hipStreamWaitEvent(c->stream, d->ev_spec[d->host_spec[b]], 0));
         HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, c->stream));
         if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
     } else {
-        if (d->host_no >= 2) {
-            HIPCHK(hipStreamWaitEvent(d->copy, d->ev_done[b], 0));       // the frame that read this buffer has finished on the main stream ...
-            if (d->host_spec[b] >= 0 && d->spec_side[d->host_spec[b]]) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_spec[d->host_spec[b]], 0));   // ... and its feature launch on the side stream
-        }
+        if (f >= 3) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_ring[(f - 2) % 3], 0));
         if (by_kernel) {
             const size_t n16 = fbytes / 16, n8 = (size_t)nD * sizeof(bbox_t) / 8;
             hipLaunchKernelGGL(h2d_copy_kernel, dim3(32), dim3(256), 0, d->copy, reinterpret_cast<uint4*>(d->hbuf[b].p), reinterpret_cast<const uint4*>(src_f), n16,
@@ -516,12 +528,22 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         HIPCHK(hipEventRecord(d->ev_up[b], d->copy));
         HIPCHK(hipStreamWaitEvent(c->stream, d->ev_up[b], 0));
     }
+    d->want_mid = h2d_mode != 1;                                       // every frame's chain records its event (the uploads two frames on wait for it)
+    if (lookahead && nD > 0 && f >= 1 && d->mid_valid && !d->pf_valid && (d->S.cap + d->S.world - 1) / d->S.world + nD > split_early_max()) {
+        const int nb = (d->buf_prev + 1) % 3;
+        // (order matters: a wait for an already-complete event queued BEHIND the pending one started the launch 45 us after the event fired)
+        HIPCHK(hipStreamWaitEvent(d->side, d->ev_up[b], 0));
+        HIPCHK(hipStreamWaitEvent(d->side, d->ev_ring[(f - 1) % 3], 0));
+        KcfLaunch lf{}; lf.frame = (const uint8_t*)d->hbuf[b].p; lf.boxes_in = d->dbuf[b].p; lf.spec_out = d->det_spec.p + (size_t)nb * d->spec_stride; lf.slab_base = d->S.cap;
+        HIPCHK(launch_kcf_update(c->pools[d->pool]->dev, lf, nD, d->side));
+        HIPCHK(hipEventRecord(d->ev_spec[nb], d->side)); d->spec_side[nb] = true;
+        d->pf_frame = d->hbuf[b].p; d->pf_dets = d->dbuf[b].p; d->pf_nD = nD; d->pf_buf = nb; d->pf_valid = true;
+    }
+    if (d->want_mid) d->ev_mid = d->ev_ring[b];                        // this frame's chain event
     rc = dl_begin(c, d, d->hbuf[b].p, nullptr, d->dbuf[b].p, nD); if (rc) return rc;
-    rc = dl_finish(c, d, nullptr, d->dbuf[b].p, nD, nullptr, false); if (rc) return rc;
-    // with the deferred blend the NEXT frame's predict still reads nothing of this frame's buffers (spectra live in their own buffers),
-    // so the buffer is free once this frame's stream work is done
-    HIPCHK(hipEventRecord(d->ev_done[b], c->stream));
-    d->host_spec[b] = d->split ? d->buf_prev : -1;                       // (dl_finish has already rotated: buf_prev is this frame's buffer)
+    // a frame whose features were NOT computed ahead launches them inside dl_finish, on the side stream, reading this frame's buffer: the upload that
+    // reuses the buffer (three calls on) is behind the chain event of frame f + 1, and predict(f + 1) waits for that launch (release_inputs below)
+    rc = dl_finish(c, d, nullptr, d->dbuf[b].p, nD, nullptr, true); if (rc) return rc;
     d->host_no++;
     return MOT_OK;
 }

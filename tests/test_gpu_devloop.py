@@ -357,12 +357,13 @@ def test_device_loop_response_peaks_1024(mot, oracle):
     m.close(); c.close()
 
 
-def test_device_loop_fed_from_host_memory(mot, oracle):
-    """mot_step_frame_host: frames and detection lists come from pinned host memory, uploaded on the context's copy stream into two
-    alternating device buffers -- several frames enqueued back to back without synchronising (so uploads overlap the previous frame's
-    kernels and buffers are reused) must still reproduce the oracle"""
+@pytest.mark.parametrize("n,cap,nframes", [(150, 256, 8), (600, 1024, 9)])
+def test_device_loop_fed_from_host_memory(mot, oracle, n, cap, nframes):
+    """mot_step_frame_host: frames and detection lists come from pinned host memory, uploaded on the context's copy stream into three
+    rotating device buffers -- several frames enqueued back to back without synchronising (so uploads run two frames ahead, buffers are
+    reused, and at the larger size every frame's detection features are launched one frame early on the side stream) must still
+    reproduce the oracle"""
     from multiple_object_tracking_amd import synth
-    n, nframes = 150, 8
     scene = synth.Scene(n, 80, stream_id=33, miss_pct=6, fp_pct=4)
     items = list(scene.frames(nframes))
     frames = [f for f, _ in items]; dets = [d for _, d in items]
@@ -372,8 +373,8 @@ def test_device_loop_fed_from_host_memory(mot, oracle):
         da[i, :len(d)] = mot.boxes_array(d)
     pf = torch.from_numpy(np.stack(frames)).pin_memory()
     pd = torch.from_numpy(da.view(np.uint8).reshape(nframes, -1)).pin_memory()
-    c = mot.MotContext(max_tracks=256, max_dets=256)
-    m = orc.OracleMot(oracle, 0, 0, 256)
+    c = mot.MotContext(max_tracks=cap, max_dets=cap)
+    m = orc.OracleMot(oracle, 0, 0, cap)
     refs = [m.step(frames[f], dets[f]) for f in range(nframes)]
     for f in range(nframes):                                            # all frames enqueued; read back only at the end and in the middle
         c.step_frame_host(pf[f].data_ptr(), pd[f].data_ptr(), len(dets[f]))
