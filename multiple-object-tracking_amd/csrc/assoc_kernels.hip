@@ -352,9 +352,22 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
         if (a.user) return a.user[(size_t)r + (size_t)nR * c];
         return rowsTrk ? pair_cost(rowb, colb[c]) : pair_cost(colb[c], rowb);
     };
+    // a thread's costs are kept for the second pass when they fit eight registers (64 x 64: four per thread): the float64 divide / sqrt chains
+    // of pair_cost are what this phase costs, and they ran twice
+    const bool keep = (nC + NPART - 1) / NPART <= 8;                   // workgroup-uniform
+    double cv[8];
     u64 best = ~0ull;                                                  // pass 1 (hungarian.cpp:69-81 / :107-119)
-    for (int c = part; c < nC; c += NPART) {
-        const u64 kk = r < nR ? dkey(cost(c)) : ~0ull;
+    if (keep) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int c = part + q * NPART; cv[q] = (r < nR && c < nC) ? cost(c) : 0.0; }
+    }
+    for (int c = part, q = 0; c < nC; c += NPART, q++) {
+        double cq = 0.0;
+        if (keep) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) cq = (t == q) ? cv[t] : cq;
+        }
+        const u64 kk = r < nR ? dkey(keep ? cq : cost(c)) : ~0ull;
         if (perRow) { if (kk < best) best = kk; }
         else {
             u64 m = kk;
@@ -366,10 +379,15 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
     if (perRow && r < nR && best != ~0ull) atomicMin(&lm[r], best);
     __syncthreads();
     const double rmin = (perRow && r < nR) ? dunkey(lm[r]) : 0.0;      // pass 2
-    for (int c = part; c < nC; c += NPART) {
+    for (int c = part, q = 0; c < nC; c += NPART, q++) {
         bool z = false;
         if (r < nR) {
-            const double v = cost(c);
+            double cq = 0.0;
+            if (keep) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) cq = (t == q) ? cv[t] : cq;
+            }
+            const double v = keep ? cq : cost(c);
             const double dv = v - (perRow ? rmin : dunkey(lm[c]));
             a.ws.dist[(size_t)r + (size_t)nR * c] = dv;
             z = fabs(dv) < DBL_EPSILON;
