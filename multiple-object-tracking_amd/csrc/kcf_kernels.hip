@@ -560,6 +560,64 @@ __device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in
     }
 }
 
+// The forward transforms of many planes, register-blocked: the twiddle of a row term depends on (k, y) but not on the line, the twiddle of a column
+// term on (x', x) but not on k -- so a thread owns four lines (rows pass) / four adjacent bins (columns pass) of one twiddle sequence and pays
+// one twiddle fetch and one index update for four complex multiply-adds.  Every output is the same sum in the same order as in the plain loops.
+__device__ void dft_rows_generic4(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
+                                  const float2* __restrict__ twr, int nch, int tid, int nt)
+{
+    const int hb = p.hb, fh = p.fh, ldf = 2 * fh, lines = nch * p.wb, total = ((lines + 3) >> 2) * fh;
+    for (int i = tid; i < total; i += nt) {
+        uint32_t g, k; p.d_fh.divmod((uint32_t)i, g, k);
+        const int l0 = 4 * (int)g;
+        const float* in0 = F + l0 * ldf;
+        const float* in1 = F + min(l0 + 1, lines - 1) * ldf;
+        const float* in2 = F + min(l0 + 2, lines - 1) * ldf;
+        const float* in3 = F + min(l0 + 3, lines - 1) * ldf;
+        float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;
+#pragma unroll 2
+        for (int y = 0; y < hb; y++) {
+            const float2 w = twr[j];
+            const float v0 = in0[y], v1 = in1[y], v2 = in2[y], v3 = in3[y];
+            re0 += v0 * w.x; im0 -= v0 * w.y; re1 += v1 * w.x; im1 -= v1 * w.y;
+            re2 += v2 * w.x; im2 -= v2 * w.y; re3 += v3 * w.x; im3 -= v3 * w.y;
+            j += (int)k; if (j >= hb) j -= hb;
+        }
+        float2* o = T + (size_t)l0 * fh + k;
+        o[0] = make_float2(re0, im0);
+        if (l0 + 1 < lines) o[fh] = make_float2(re1, im1);
+        if (l0 + 2 < lines) o[2 * fh] = make_float2(re2, im2);
+        if (l0 + 3 < lines) o[3 * fh] = make_float2(re3, im3);
+    }
+}
+__device__ void dft_cols_generic4(const KcfPool& p, const float2* __restrict__ in, float2* __restrict__ out,
+                                  const float2* __restrict__ twc, int nch, int tid, int nt)
+{
+    const int wb = p.wb, fh = p.fh, plane = wb * fh, kb = (fh + 3) >> 2, per = wb * kb, total = nch * per;
+    for (int i = tid; i < total; i += nt) {
+        const int ch = i / per, rem = i - ch * per, xp = rem / kb, k0 = 4 * (rem - xp * kb);
+        const int k1 = min(k0 + 1, fh - 1), k2 = min(k0 + 2, fh - 1), k3 = min(k0 + 3, fh - 1);
+        const float2* src = in + ch * plane;
+        float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;
+#pragma unroll 2
+        for (int x = 0; x < wb; x++) {
+            const float2 w = twc[j]; const float wi = -w.y;             // forward
+            const float2* sx = src + x * fh;
+            const float2 a = sx[k0], b = sx[k1], c = sx[k2], d = sx[k3];
+            re0 += a.x * w.x - a.y * wi; im0 += a.x * wi + a.y * w.x;
+            re1 += b.x * w.x - b.y * wi; im1 += b.x * wi + b.y * w.x;
+            re2 += c.x * w.x - c.y * wi; im2 += c.x * wi + c.y * w.x;
+            re3 += d.x * w.x - d.y * wi; im3 += d.x * wi + d.y * w.x;
+            j += xp; if (j >= wb) j -= wb;
+        }
+        float2* o = out + ch * plane + xp * fh;
+        o[k0] = make_float2(re0, im0);
+        if (k0 + 1 < fh) o[k0 + 1] = make_float2(re1, im1);
+        if (k0 + 2 < fh) o[k0 + 2] = make_float2(re2, im2);
+        if (k0 + 3 < fh) o[k0 + 3] = make_float2(re3, im3);
+    }
+}
+
 // ---- DFTs as f32 matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 multiply-adds, k-ordered) ----
 // A line transform of prime length (37 cells at 148 px) has no butterfly; as a product with the constant twiddle matrix
 // it runs at the MFMA rate instead of one multiply-add and one twiddle fetch per VALU slot.  The constant operand comes
@@ -1007,16 +1065,16 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
                 __syncthreads();
                 continue;
             }
-            dft_rows_generic(p, sF, sT, twr, g, tid, nt);                 // lines longer than MOT_DFT_MFMA_MAX cells (templates beyond 164 px)
+            dft_rows_generic4(p, sF, sT, twr, g, tid, nt);                // lines longer than MOT_DFT_MFMA_MAX cells (templates beyond 164 px)
             __syncthreads();
-            dft_cols_generic<-1>(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
+            dft_cols_generic4(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
             __syncthreads();
         }
     } else {
         float2* T = reinterpret_cast<float2*>(regT);
-        dft_rows_generic(p, regB, T, twr, nch, tid, nt);
+        dft_rows_generic4(p, regB, T, twr, nch, tid, nt);
         __syncthreads();
-        dft_cols_generic<-1>(p, T, reinterpret_cast<float2*>(regB), twc, nch, tid, nt);
+        dft_cols_generic4(p, T, reinterpret_cast<float2*>(regB), twc, nch, tid, nt);
         __syncthreads();
     }
 }
