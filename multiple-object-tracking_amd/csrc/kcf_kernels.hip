@@ -846,13 +846,12 @@ __device__ __attribute__((noinline)) void dft2_mfma_fixed(const KcfPool& p, int 
 // 5 planes still feeds all 8 waves -- and that the 8 * XTL * XTL column fragments are loaded once for all tiles of the call.
 // out[((ch - c_lo)*wb + x')*ldf + n].
 template <int XTL, int KSR>
-__device__ __attribute__((noinline)) void spectrum_tiles_r1(const KcfPool& p, int c_lo, int c_hi, float* __restrict__ out,
+__device__ __attribute__((noinline)) void spectrum_tiles_r1(const KcfPool& p, const float* __restrict__ N, int c_lo, int c_hi, float* __restrict__ out,
                                                             float* __restrict__ feat_out, int feat_windowed, int tid, int nt_, long long* dbg)
 {
     extern __shared__ __attribute__((aligned(16))) float dft2_smem[];
-    const float* __restrict__ R1 = dft2_smem + p.offR1c;
+    const float* __restrict__ R1 = dft2_smem + p.offR1c;               // N: the norm matrix (region C, LDS), from the caller's carve()
     float* __restrict__ F = dft2_smem + p.offW;
-    const float* __restrict__ N = dft2_smem + p.offR1c + MOT_NORI * 64 * ((p.nb + 63) >> 6) + 2048 + 2 * p.hb + 2 * p.wb + 32;   // carve(), R1-resident order
     const int lane = tid & 63, wave = tid >> 6, nw = nt_ >> 6, q = lane >> 4, m = lane & 15;
     const int hb = p.hb, wb = p.wb, ldf = 2 * p.fh, ntl = (ldf + 15) >> 4;
     float cwr[XTL][XTL][4][2];
@@ -928,14 +927,14 @@ __device__ __attribute__((noinline)) void spectrum_tiles_r1(const KcfPool& p, in
 #undef TSTAMP
 }
 // the instances: XTL = tiles of 16 lines (wb), KSR = k-steps of 4 rows (hb)
-__device__ __forceinline__ bool r1_spectrum_dispatch(const KcfPool& p, int c_lo, int c_hi, float* out, float* fo, int fw, int tid, int nt, long long* dbg)
+__device__ __forceinline__ bool r1_spectrum_dispatch(const KcfPool& p, const float* N, int c_lo, int c_hi, float* out, float* fo, int fw, int tid, int nt, long long* dbg)
 {
     const int xtl = (p.wb + 15) >> 4, ksr = (p.hb + 3) >> 2;
-    if (xtl == 3 && ksr == 10) { spectrum_tiles_r1<3, 10>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
-    if (xtl == 3 && ksr == 9) { spectrum_tiles_r1<3, 9>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
-    if (xtl == 2 && ksr == 8) { spectrum_tiles_r1<2, 8>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
-    if (xtl == 2 && ksr == 7) { spectrum_tiles_r1<2, 7>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
-    if (xtl == 2 && ksr == 10) { spectrum_tiles_r1<2, 10>(p, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 3 && ksr == 10) { spectrum_tiles_r1<3, 10>(p, N, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 3 && ksr == 9) { spectrum_tiles_r1<3, 9>(p, N, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 2 && ksr == 8) { spectrum_tiles_r1<2, 8>(p, N, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 2 && ksr == 7) { spectrum_tiles_r1<2, 7>(p, N, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
+    if (xtl == 2 && ksr == 10) { spectrum_tiles_r1<2, 10>(p, N, c_lo, c_hi, out, fo, fw, tid, nt, dbg); return true; }
     return false;
 }
 
@@ -1248,7 +1247,7 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
 {
     float* fo = l.feat_out ? l.feat_out + (size_t)item * 32 * p.nb : nullptr;
     if (SLAB && R1 && p.r1_lds) {                                      // R1-resident: a few planes at a time, R1 -> features -> spectra (slab region B, or the caller's buffer)
-        if (!r1_spectrum_dispatch(p, HALF ? MOT_HALF0 : 0, HALF ? MOT_NCHAN : MOT_HALF0, out_override ? out_override : r.B, fo, l.feat_windowed, tid, nt, l.dbg)) __builtin_trap();
+        if (!r1_spectrum_dispatch(p, r.N, HALF ? MOT_HALF0 : 0, HALF ? MOT_NCHAN : MOT_HALF0, out_override ? out_override : r.B, fo, l.feat_windowed, tid, nt, l.dbg)) __builtin_trap();
         DBG_STAMP(8 + HALF);
         return;
     }
