@@ -563,7 +563,7 @@ __device__ void dft_cols_generic(const KcfPool& p, const float2* __restrict__ in
 // The forward transforms of many planes, register-blocked: the twiddle of a row term depends on (k, y) but not on the line, the twiddle of a column
 // term on (x', x) but not on k -- so a thread owns four lines (rows pass) / four adjacent bins (columns pass) of one twiddle sequence and pays
 // one twiddle fetch and one index update for four complex multiply-adds.  Every output is the same sum in the same order as in the plain loops.
-__device__ void dft_rows_generic4(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
+__device__ __forceinline__ void dft_rows_generic4(const KcfPool& p, const float* __restrict__ F, float2* __restrict__ T,
                                   const float2* __restrict__ twr, int nch, int tid, int nt)
 {
     const int hb = p.hb, fh = p.fh, ldf = 2 * fh, lines = nch * p.wb, total = ((lines + 3) >> 2) * fh;
@@ -590,7 +590,7 @@ __device__ void dft_rows_generic4(const KcfPool& p, const float* __restrict__ F,
         if (l0 + 3 < lines) o[3 * fh] = make_float2(re3, im3);
     }
 }
-__device__ void dft_cols_generic4(const KcfPool& p, const float2* __restrict__ in, float2* __restrict__ out,
+__device__ __forceinline__ void dft_cols_generic4(const KcfPool& p, const float2* __restrict__ in, float2* __restrict__ out,
                                   const float2* __restrict__ twc, int nch, int tid, int nt)
 {
     const int wb = p.wb, fh = p.fh, plane = wb * fh, kb = (fh + 3) >> 2, per = wb * kb, total = nch * per;
@@ -1597,15 +1597,28 @@ template <int kMode>
 __global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (l.grid_stride) {                                               // few items, count known on the device only: a small grid loops
-        const int cnt = min(n, l.count ? *l.count : n);
-        for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode>(p, l, item, smem); __syncthreads(); }
-        return;
-    }
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
     kcf_update_body<kMode>(p, l, item, smem);
+}
+// Few items, count known on the device only (KcfLaunch::grid_stride): a small grid loops over them.  The device loop launches this every frame for
+// a list that is usually EMPTY (tracks that keep their predicted box), so the count test must come before anything else.  Out-of-line callees take
+// the pool descriptor by reference, which makes the compiler copy the by-value kernel arguments to private memory in the kernel's ENTRY block (19
+// scratch stores per lane: 20 MB and 4 us per empty launch when the body was inlined here); the body is therefore a function of its own that
+// receives the descriptors BY VALUE -- the copy happens at the call, behind the test.
+template <int kMode>
+__device__ __attribute__((noinline)) void kcf_update_sparse_run(KcfPool p, KcfLaunch l, int cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode>(p, l, item, smem); __syncthreads(); }
+}
+template <int kMode>
+__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    const int cnt = min(n, l.count ? *l.count : n);
+    if ((int)blockIdx.x >= cnt) return;
+    kcf_update_sparse_run<kMode>(p, l, cnt);
 }
 template <int kMode>
 __global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
@@ -1853,7 +1866,8 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
         KCF_LAUNCH3(kcf_features_kernel, p.r1_lds, n, lds, s, p, l, n);
         return hipGetLastError();
     }
-    KCF_LAUNCH3(kcf_update_kernel, p.r1_lds, grid, lds, s, p, l, n);
+    if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, p.r1_lds, grid, lds, s, p, l, n);
+    else KCF_LAUNCH3(kcf_update_kernel, p.r1_lds, grid, lds, s, p, l, n);
     return hipGetLastError();
 }
 #undef KCF_LAUNCH3
