@@ -618,6 +618,101 @@ __device__ __forceinline__ void dft_cols_generic4(const KcfPool& p, const float2
     }
 }
 
+// The same two passes IN PLACE (LDS-resident templates other than 20 x 20 cells, KcfPool::dft_inplace): a line's row spectrum occupies exactly the
+// floats of the line (fh complex = ldf floats), a plane's spectrum those of its row spectra -- so every thread first computes ALL its outputs of a
+// pass into registers (<= MOT_DFT_INPLACE_ITEMS items of 8 floats), the workgroup meets at a barrier, and only then the outputs overwrite the
+// inputs.  No second buffer: region T leaves the layout (72 / 76 px: 90 / 95 -> 68 / 71 KB, two workgroups per CU instead of one).
+#define MOT_DFT_INPLACE_ITEMS 3
+// (compiled into the single-pool kernels only, kMode 5: its 24 accumulators cost the size-class kernels spills, and a size-class launch takes the
+// largest class's LDS anyway; out of line it ran 40 % slower)
+__device__ __forceinline__ void dft2_generic_inplace(int hb, int wb, int fh, FastDiv d_fh, float* __restrict__ B, const float2* __restrict__ twr,
+                                                     const float2* __restrict__ twc, int nch, int tid, int nt)
+{
+    const int ldf = 2 * fh, lines = nch * wb, plane = wb * fh;
+    float acc[MOT_DFT_INPLACE_ITEMS][8];
+    {   // rows: item = (group of four lines, bin k)
+        const int total = ((lines + 3) >> 2) * fh;
+#pragma unroll
+        for (int it = 0; it < MOT_DFT_INPLACE_ITEMS; it++) {
+            const int i = tid + it * nt;
+            if (i < total) {
+                uint32_t g, k; d_fh.divmod((uint32_t)i, g, k);
+                const int l0 = 4 * (int)g;
+                const float* in0 = B + l0 * ldf;
+                const float* in1 = B + min(l0 + 1, lines - 1) * ldf;
+                const float* in2 = B + min(l0 + 2, lines - 1) * ldf;
+                const float* in3 = B + min(l0 + 3, lines - 1) * ldf;
+                float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;
+#pragma unroll 2
+                for (int y = 0; y < hb; y++) {
+                    const float2 w = twr[j];
+                    const float v0 = in0[y], v1 = in1[y], v2 = in2[y], v3 = in3[y];
+                    re0 += v0 * w.x; im0 -= v0 * w.y; re1 += v1 * w.x; im1 -= v1 * w.y;
+                    re2 += v2 * w.x; im2 -= v2 * w.y; re3 += v3 * w.x; im3 -= v3 * w.y;
+                    j += (int)k; if (j >= hb) j -= hb;
+                }
+                acc[it][0] = re0; acc[it][1] = im0; acc[it][2] = re1; acc[it][3] = im1; acc[it][4] = re2; acc[it][5] = im2; acc[it][6] = re3; acc[it][7] = im3;
+            }
+        }
+        __syncthreads();
+        float2* T = reinterpret_cast<float2*>(B);
+#pragma unroll
+        for (int it = 0; it < MOT_DFT_INPLACE_ITEMS; it++) {
+            const int i = tid + it * nt;
+            if (i < total) {
+                uint32_t g, k; d_fh.divmod((uint32_t)i, g, k);
+                const int l0 = 4 * (int)g;
+                float2* o = T + (size_t)l0 * fh + k;
+                o[0] = make_float2(acc[it][0], acc[it][1]);
+                if (l0 + 1 < lines) o[fh] = make_float2(acc[it][2], acc[it][3]);
+                if (l0 + 2 < lines) o[2 * fh] = make_float2(acc[it][4], acc[it][5]);
+                if (l0 + 3 < lines) o[3 * fh] = make_float2(acc[it][6], acc[it][7]);
+            }
+        }
+        __syncthreads();
+    }
+    {   // columns: item = (plane, output line x', group of four bins)
+        const int kb = (fh + 3) >> 2, per = wb * kb, total = nch * per;
+        float2* S = reinterpret_cast<float2*>(B);
+#pragma unroll
+        for (int it = 0; it < MOT_DFT_INPLACE_ITEMS; it++) {
+            const int i = tid + it * nt;
+            if (i < total) {
+                const int ch = i / per, rem = i - ch * per, xp = rem / kb, k0 = 4 * (rem - xp * kb);
+                const int k1 = min(k0 + 1, fh - 1), k2 = min(k0 + 2, fh - 1), k3 = min(k0 + 3, fh - 1);
+                const float2* src = S + ch * plane;
+                float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;
+#pragma unroll 2
+                for (int x = 0; x < wb; x++) {
+                    const float2 w = twc[j]; const float wi = -w.y;     // forward
+                    const float2* sx = src + x * fh;
+                    const float2 a = sx[k0], b = sx[k1], c = sx[k2], d = sx[k3];
+                    re0 += a.x * w.x - a.y * wi; im0 += a.x * wi + a.y * w.x;
+                    re1 += b.x * w.x - b.y * wi; im1 += b.x * wi + b.y * w.x;
+                    re2 += c.x * w.x - c.y * wi; im2 += c.x * wi + c.y * w.x;
+                    re3 += d.x * w.x - d.y * wi; im3 += d.x * wi + d.y * w.x;
+                    j += xp; if (j >= wb) j -= wb;
+                }
+                acc[it][0] = re0; acc[it][1] = im0; acc[it][2] = re1; acc[it][3] = im1; acc[it][4] = re2; acc[it][5] = im2; acc[it][6] = re3; acc[it][7] = im3;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MOT_DFT_INPLACE_ITEMS; it++) {
+            const int i = tid + it * nt;
+            if (i < total) {
+                const int ch = i / per, rem = i - ch * per, xp = rem / kb, k0 = 4 * (rem - xp * kb);
+                float2* o = S + ch * plane + xp * fh;
+                o[k0] = make_float2(acc[it][0], acc[it][1]);
+                if (k0 + 1 < fh) o[k0 + 1] = make_float2(acc[it][2], acc[it][3]);
+                if (k0 + 2 < fh) o[k0 + 2] = make_float2(acc[it][4], acc[it][5]);
+                if (k0 + 3 < fh) o[k0 + 3] = make_float2(acc[it][6], acc[it][7]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- DFTs as f32 matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 multiply-adds, k-ordered) ----
 // A line transform of prime length (37 cells at 148 px) has no butterfly; as a product with the constant twiddle matrix
 // it runs at the MFMA rate instead of one multiply-add and one twiddle fetch per VALU slot.  The constant operand comes
@@ -1031,8 +1126,8 @@ __device__ __forceinline__ void cfft20_inplace(float2* __restrict__ base, int st
 
 // forward 2-D r2c of `nch` feature planes; result S[(ch*wb + x')*fh + k] in region B.
 // F lives in region B (row stride ldf = 2*fh floats); T is the ping-pong buffer of the generic path.
-template <bool SLAB>
-__device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* __restrict__ regB,
+template <bool SLAB, bool GEN = true, bool INPL = false>   // GEN false: only the 20 x 20 register FFT is compiled in (kMode 1); INPL: the in-place passes too (kMode 5)
+__device__ __forceinline__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* __restrict__ regB,
                             const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt,
                             float* __restrict__ stage = nullptr)
 {
@@ -1069,6 +1164,11 @@ __device__ void fft_forward(const KcfPool& p, float* __restrict__ regT, float* _
             dft_cols_generic4(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
             __syncthreads();
         }
+    } else if (!GEN) {
+        __builtin_trap();                                              // launch_kcf_* pick mode 3 for every pool that is not 20 x 20 cells
+    } else if (!SLAB && p.dft_inplace) {
+        if (!INPL) __builtin_trap();                                   // only single-pool launches of such a pool exist (get_pool: size classes keep region T)
+        dft2_generic_inplace(p.hb, p.wb, p.fh, p.d_fh, regB, twr, twc, nch, tid, nt);
     } else {
         float2* T = reinterpret_cast<float2*>(regT);
         dft_rows_generic4(p, regB, T, twr, nch, tid, nt);
@@ -1130,6 +1230,13 @@ __device__ int block_argmax_first(const float* __restrict__ resp, int n, float* 
     }
     __syncthreads();
     return red_i[0];
+}
+
+template <bool SLAB, bool GEN, bool INPL>
+__device__ __attribute__((noinline)) void fft_forward_ool(const KcfPool& p, float* __restrict__ regT, float* __restrict__ regB,
+                                                          const float2* __restrict__ twr, const float2* __restrict__ twc, int nch, int tid, int nt, float* __restrict__ stage)
+{
+    fft_forward<SLAB, GEN, INPL>(p, regT, regB, twr, twc, nch, tid, nt, stage);
 }
 
 struct Regions {
@@ -1241,7 +1348,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
 }
 
 // one half of the channels -> windowed features -> spectrum in region B (overlays Mq / bins, then itself)
-template <int HALF, bool SLAB, bool R1 = false>
+template <int HALF, bool SLAB, bool R1 = false, bool GEN = true, bool OOL = false, bool INPL = false>   // OOL: the direct / staged transforms stay out of line
 __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, const Regions& r, int tid, int nt, bool spectrum, float* stage = nullptr,
                               float* out_override = nullptr)
 {
@@ -1263,15 +1370,23 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
         else dft2_mfma(p, (int)(stage - smem_base()), (int)(stage - smem_base()) + MOT_HALF0 * p.wb * 2 * p.fh, r.B, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt);
         __syncthreads();
     }
-    else if (spectrum) fft_forward<SLAB>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
+    else if (spectrum) {
+        // the single-pool kernels with the R1-resident pipeline (kMode 2) keep this, for them dead, path out of line: inlined it costs the shared
+        // phases registers (148 px: 586 -> 537 k updates/s); everywhere else -- also in the size-class kernels that mix R1-resident and larger
+        // templates (kMode 4) -- inlining it is what pays (168 / 200 px: 0.48 / 0.77 -> 0.37 / 0.55 ms per frame)
+        if (OOL) fft_forward_ool<SLAB, GEN, INPL>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
+        else fft_forward<SLAB, GEN, INPL>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
+    }
 }
 
-template <int kMode, bool kStagger = false>   // kMode 0: HBM slab, 1: LDS, 2: HBM slab with the R1-resident pipeline compiled in (kernels of their own: the other sizes keep their code)
+template <int kMode, bool kStagger = false>   // kMode 0: HBM slab, 1: LDS with the 20 x 20 register FFT only (80 px: the headline kernels), 2: HBM slab with the R1-resident pipeline compiled in,
+                                             // 3: LDS with the direct transforms compiled in as well (size-class launches), 5: as 3 plus their in-place form (single pool), 4: as 2 for size-class launches (the staged transforms inline: larger classes run them)
+                                             // (kernels of their own: the other modes keep their code and registers)
 __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
-    constexpr bool kLds = kMode == 1;
+    constexpr bool kLds = (kMode & 1) != 0;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    const bool r1m = kMode == 2 && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    const bool r1m = (kMode == 2 || kMode == 4) && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
     float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1374,7 +1489,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
-    features_prepare<!kLds, true, kMode == 2>(p, l, item, pos, r, tid, nt, stage);
+    features_prepare<!kLds, true, (kMode == 2 || kMode == 4)>(p, l, item, pos, r, tid, nt, stage);
     if (late) blend();
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
@@ -1382,7 +1497,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
     // partial sums of the first half wait here for the second: zf, or -- R1-resident templates, whose transform tiles run over zf -- slab region T
     float2* zpark = r1m ? reinterpret_cast<float2*>(r.T) : r.zf;
     float zr = 0.f, zi = 0.f;
-    half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<0, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     if (pre) {
         if (tid < p.nbins) {
@@ -1404,7 +1519,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
         }
     }
     __syncthreads();
-    half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<1, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(6);
     if (pre) {
         if (tid < p.nbins) {
@@ -1464,18 +1579,18 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& p, const KcfLaun
 }
 
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    kcf_predict_body<kMode, kMode == 1>(p, l, item, smem);
+    kcf_predict_body<kMode, (kMode & 1) != 0>(p, l, item, smem);
 }
 // size classes (device loop with per-track template sizes, kcf.cpp:148-152): the workgroup's pool descriptor comes from a device
 // table, indexed by the class of its track
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_multi_kernel(const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1488,9 +1603,9 @@ __global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS
 template <int kMode>
 __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
-    constexpr bool kLds = kMode == 1;
+    constexpr bool kLds = (kMode & 1) != 0;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    const bool r1m = kMode == 2 && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    const bool r1m = (kMode == 2 || kMode == 4) && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
     float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1510,7 +1625,7 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
 #pragma unroll
         for (int j = 0; j < 16; j++) xold[j] = first ? make_float2(0.f, 0.f) : xm[min(tid + j * nt, tot - 1)];
     }
-    if (!dspec) features_prepare<!kLds, true, kMode == 2>(p, l, item, box, r, tid, nt, stage);
+    if (!dspec) features_prepare<!kLds, true, (kMode == 2 || kMode == 4)>(p, l, item, box, r, tid, nt, stage);
     const float factor = first ? 1.0f : p.eta;                         // kcf.cpp:443
     const float keep = 1.0f - factor;
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -1564,12 +1679,12 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
             }
         }
     } else {
-    if (!dspec) half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
+    if (!dspec) half_spectrum<0, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     UPDATE_HALF(0, MOT_HALF0);
     if (!dspec) {
         __syncthreads();
-        half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
+        half_spectrum<1, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     }
     DBG_STAMP(6);
     UPDATE_HALF(MOT_HALF0, MOT_NCHAN);
@@ -1594,7 +1709,7 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& p, const KcfLaunc
 }
 
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1614,14 +1729,14 @@ __device__ __attribute__((noinline)) void kcf_update_sparse_run(KcfPool p, KcfLa
     for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode>(p, l, item, smem); __syncthreads(); }
 }
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     const int cnt = min(n, l.count ? *l.count : n);
     if ((int)blockIdx.x >= cnt) return;
     kcf_update_sparse_run<kMode>(p, l, cnt);
 }
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_multi_kernel(const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1637,31 +1752,31 @@ __global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS
 template <int kMode>
 __device__ __forceinline__ void kcf_features_body(const KcfPool& p, const KcfLaunch& l, const int item, float* smem)
 {
-    constexpr bool kLds = kMode == 1;
+    constexpr bool kLds = (kMode & 1) != 0;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
-    const bool r1m = kMode == 2 && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
+    const bool r1m = (kMode == 2 || kMode == 4) && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
     float* stage = r1m ? smem : ((!kLds && p.stage_floats > 0) ? smem + p.szC : nullptr);
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
     const bbox_t box = l.boxes_in[item];
-    features_prepare<!kLds, true, kMode == 2>(p, l, item, box, r, tid, nt, stage);
+    features_prepare<!kLds, true, (kMode == 2 || kMode == 4)>(p, l, item, box, r, tid, nt, stage);
     const float2* S = reinterpret_cast<const float2*>(r.B);
     float2* so = l.spec_out + (size_t)item * MOT_NCHAN * p.nbins;
     if (r1m) {                                                         // the transforms store straight into the launch's spectrum buffer
-        half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so));
-        half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so + (size_t)MOT_HALF0 * p.nbins));
+        half_spectrum<0, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so));
+        half_spectrum<1, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage, reinterpret_cast<float*>(so + (size_t)MOT_HALF0 * p.nbins));
         return;
     }
-    half_spectrum<0, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<0, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     for (int i = tid; i < MOT_HALF0 * p.nbins; i += nt) so[i] = S[i];
     __syncthreads();
-    half_spectrum<1, !kLds, kMode == 2>(p, l, item, r, tid, nt, true, stage);
+    half_spectrum<1, !kLds, (kMode == 2 || kMode == 4), kMode != 1, kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     so += (size_t)MOT_HALF0 * p.nbins;
     for (int i = tid; i < (MOT_NCHAN - MOT_HALF0) * p.nbins; i += nt) so[i] = S[i];
 }
 
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_features_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int item = blockIdx.x;
@@ -1674,7 +1789,7 @@ __global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS
 // tracks, workgroups [n_pred, n_pred + n_feat) compute the detection spectra of the split update.  No side stream, no event pair, no
 // cross-stream wait: at 64 tracks those cost more than the kernels' own work.
 template <int kMode>
-__global__ void __launch_bounds__(kMode == 1 ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, (kMode == 1 || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < n_pred) {
@@ -1727,7 +1842,7 @@ __global__ void __launch_bounds__(MOT_KCF_THREADS) kcf_crop_kernel(const KcfPool
 // host side
 // ---------------------------------------------------------------------------
 void kcf_pool_layout_r1(KcfPool& p, bool allow);
-void kcf_pool_layout(KcfPool& p, bool allow_r1)
+void kcf_pool_layout(KcfPool& p, bool allow_r1, bool allow_inplace)
 {
     p.hb = p.rows / MOT_CELL; p.wb = p.cols / MOT_CELL; p.fh = p.hb / 2 + 1;
     p.nb = p.hb * p.wb; p.nbins = p.wb * p.fh;
@@ -1747,6 +1862,17 @@ void kcf_pool_layout(KcfPool& p, bool allow_r1)
     p.offA = 0; p.offB = up4(szA); p.offC = p.offB + up4(szB); p.offT = p.offC + up4(szC);
     p.lds_floats = p.offT + up4(szT);
     p.use_lds = ((size_t)p.lds_floats * sizeof(float) <= MOT_LDS_LIMIT) ? 1 : 0;
+    // LDS-resident templates with the direct transforms: in place when a thread can hold all its outputs of a pass (dft2_generic_inplace); region T
+    // then leaves the layout.  (The split LDS-resident / HBM slab above is decided WITH region T, so no template size changes its path.)
+    p.dft_inplace = 0;
+    if (p.use_lds && !p.fft20 && allow_inplace && mot_impl::env().dft_inplace) {
+        const int lines = MOT_HALF0 * p.wb, items_r = ((lines + 3) / 4) * p.fh, items_c = MOT_HALF0 * p.wb * ((p.fh + 3) / 4);
+        // ... and only where it buys a second workgroup per CU (72 / 76 px: predict launch of 1024 tracks 207 -> 156 us); a third one is out of reach
+        // (128 registers per lane), and without an occupancy step the two extra barriers cost a few per cent (64 px: 117 -> 127 us, 88 px: 280 -> 289)
+        const size_t with_t = (size_t)p.lds_floats * sizeof(float), without_t = (size_t)p.offT * sizeof(float);
+        const bool fits = items_r <= MOT_DFT_INPLACE_ITEMS * MOT_KCF_THREADS && items_c <= MOT_DFT_INPLACE_ITEMS * MOT_KCF_THREADS;
+        if (fits && MOT_LDS_LIMIT / with_t < 2 && MOT_LDS_LIMIT / without_t >= 2) { p.dft_inplace = 1; p.lds_floats = p.offT; }
+    }
     // HBM-slab templates keep region C (tables, twiddles, the single-plane buffers) in LDS, plus a staging area: the
     // per-thread histogram scratch and G channel planes (features + row spectra) of the generic DFT
     p.szC = 0; p.stage_floats = 0; p.stage_G = 0;
@@ -1803,14 +1929,16 @@ static hipError_t set_lds_attr(K kern, size_t bytes)
     return mot_impl::func_lds_once(reinterpret_cast<const void*>(kern), MOT_LDS_LIMIT);
 }
 
-// kernel mode of a launch: 1 = LDS-resident template, 2 = HBM slab with the R1-resident pipeline (the pool's, or any pool's of a size-class
-// launch: l.r1_any), 0 = plain HBM slab
-#define KCF_LAUNCH3(KERN, R1, GRID, LDSB, STREAM, ...)                                                                          \
+// kernel mode of a launch: LDS-resident template: 1 when every pool involved is 20 x 20 cells (register FFT), else 3 (GEN: the pool's !fft20, or
+// l.gen_any of a size-class launch); HBM slab: 2 with the R1-resident pipeline (the pool's, or l.r1_any), else 0
+#define KCF_LAUNCH3(KERN, R1MODE, GENMODE, R1, GEN, GRID, LDSB, STREAM, ...)                                                                     \
     do {                                                                                                                        \
-        if (p.use_lds)  { hipError_t e_ = set_lds_attr(KERN<1>, LDSB); if (e_ != hipSuccess) return e_;                         \
+        if (p.use_lds && !(GEN)) { hipError_t e_ = set_lds_attr(KERN<1>, LDSB); if (e_ != hipSuccess) return e_;                \
                           hipLaunchKernelGGL(KERN<1>, dim3(GRID), dim3(MOT_KCF_THREADS), LDSB, STREAM, __VA_ARGS__); }          \
-        else if (R1)    { hipError_t e_ = set_lds_attr(KERN<2>, LDSB); if (e_ != hipSuccess) return e_;                         \
-                          hipLaunchKernelGGL(KERN<2>, dim3(GRID), dim3(MOT_KCF_THREADS_SLAB), LDSB, STREAM, __VA_ARGS__); }     \
+        else if (p.use_lds) { hipError_t e_ = set_lds_attr(KERN<GENMODE>, LDSB); if (e_ != hipSuccess) return e_;               \
+                          hipLaunchKernelGGL(KERN<GENMODE>, dim3(GRID), dim3(MOT_KCF_THREADS), LDSB, STREAM, __VA_ARGS__); }    \
+        else if (R1)    { hipError_t e_ = set_lds_attr(KERN<R1MODE>, LDSB); if (e_ != hipSuccess) return e_;                    \
+                          hipLaunchKernelGGL(KERN<R1MODE>, dim3(GRID), dim3(MOT_KCF_THREADS_SLAB), LDSB, STREAM, __VA_ARGS__); } \
         else            { hipError_t e_ = set_lds_attr(KERN<0>, LDSB); if (e_ != hipSuccess) return e_;                         \
                           hipLaunchKernelGGL(KERN<0>, dim3(GRID), dim3(MOT_KCF_THREADS_SLAB), LDSB, STREAM, __VA_ARGS__); }     \
     } while (0)
@@ -1820,13 +1948,15 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     if (n <= 0) return hipSuccess;
     if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
         const size_t ldsm = l.lds_bytes;
-        KCF_LAUNCH3(kcf_predict_multi_kernel, l.r1_any, n, ldsm, s, l, n);
+        KCF_LAUNCH3(kcf_predict_multi_kernel, 4, 3, l.r1_any, l.gen_any, n, ldsm, s, l, n);
         return hipGetLastError();
     }
     const size_t lds = kcf_lds_bytes(p);
     if (t_start && t_stop && p.use_lds) {                              // (debug) the launch brackets itself with the caller's events
-        hipError_t e = set_lds_attr(kcf_predict_kernel<1>, lds); if (e != hipSuccess) return e;
-        hipExtLaunchKernelGGL(kcf_predict_kernel<1>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n);
+        if (p.fft20) { hipError_t e = set_lds_attr(kcf_predict_kernel<1>, lds); if (e != hipSuccess) return e;
+                       hipExtLaunchKernelGGL(kcf_predict_kernel<1>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
+        else { hipError_t e = set_lds_attr(kcf_predict_kernel<5>, lds); if (e != hipSuccess) return e;
+               hipExtLaunchKernelGGL(kcf_predict_kernel<5>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
         return hipGetLastError();
     }
     if (t_start && t_stop) {
@@ -1836,7 +1966,7 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
                hipExtLaunchKernelGGL(kcf_predict_kernel<0>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
         return hipGetLastError();
     }
-    KCF_LAUNCH3(kcf_predict_kernel, p.r1_lds, n, lds, s, p, l, n);
+    KCF_LAUNCH3(kcf_predict_kernel, 2, 5, p.r1_lds, !p.fft20, n, lds, s, p, l, n);
     return hipGetLastError();
 }
 
@@ -1844,7 +1974,7 @@ hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp, in
 {
     if (n_pred + n_feat <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
-    KCF_LAUNCH3(kcf_predict_features_kernel, p.r1_lds, n_pred + n_feat, lds, s, p, lp, lf, n_pred, n_feat);
+    KCF_LAUNCH3(kcf_predict_features_kernel, 2, 5, p.r1_lds, !p.fft20, n_pred + n_feat, lds, s, p, lp, lf, n_pred, n_feat);
     return hipGetLastError();
 }
 
@@ -1853,7 +1983,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     if (n <= 0) return hipSuccess;
     if (l.pools) {
         const size_t ldsm = l.lds_bytes;
-        KCF_LAUNCH3(kcf_update_multi_kernel, l.r1_any, n, ldsm, s, l, n);
+        KCF_LAUNCH3(kcf_update_multi_kernel, 4, 3, l.r1_any, l.gen_any, n, ldsm, s, l, n);
         return hipGetLastError();
     }
     size_t lds = kcf_lds_bytes(p);
@@ -1863,11 +1993,11 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     // grid_stride: the workgroups loop over up to n items (device-side count, usually zero): a grid of n / 8 workgroups, 4 .. 128
     const int grid = l.grid_stride ? (n / 8 < 4 ? (n < 4 ? n : 4) : (n / 8 > 128 ? 128 : n / 8)) : n;
     if (l.spec_out) {                                                  // feature-only launch: the lean kernel
-        KCF_LAUNCH3(kcf_features_kernel, p.r1_lds, n, lds, s, p, l, n);
+        KCF_LAUNCH3(kcf_features_kernel, 2, 5, p.r1_lds, !p.fft20, n, lds, s, p, l, n);
         return hipGetLastError();
     }
-    if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, p.r1_lds, grid, lds, s, p, l, n);
-    else KCF_LAUNCH3(kcf_update_kernel, p.r1_lds, grid, lds, s, p, l, n);
+    if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, 2, 5, p.r1_lds, !p.fft20, grid, lds, s, p, l, n);
+    else KCF_LAUNCH3(kcf_update_kernel, 2, 5, p.r1_lds, !p.fft20, grid, lds, s, p, l, n);
     return hipGetLastError();
 }
 #undef KCF_LAUNCH3

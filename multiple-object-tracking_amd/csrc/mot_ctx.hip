@@ -97,7 +97,7 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
     p.rows = rows; p.cols = cols;
     p.fhog_mode = c->cfg.fhog_mode;
     p.fft20 = (c->cfg.fft_mode == MOT_FFT_AUTO && rows / MOT_CELL == 20 && cols / MOT_CELL == 20) ? 1 : 0;
-    kcf_pool_layout(p);
+    kcf_pool_layout(p, true, !shared_scratch);                        // size-class pools (shared_scratch): one launch serves all classes with the largest one's LDS -- they keep region T
     const int cap = c->cfg.max_tracks;
     ph->cap = cap;
     for (int s = cap - 1; s >= 0; s--) ph->free_slots.push_back(s);
@@ -172,7 +172,7 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
         p.mf_rows = ph->mf_rows.p; p.mf_cols = ph->mf_cols.p;
         p.mf = mot_impl::env().dft_mfma;
     }
-    if (p.r1_lds && !p.mf) kcf_pool_layout(p, false);               // the R1-resident mode is built on the MFMA transform
+    if (p.r1_lds && !p.mf) kcf_pool_layout(p, false, !shared_scratch);               // the R1-resident mode is built on the MFMA transform
     if (!p.use_lds && !shared_scratch) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
     p.xm = ph->xm.p; p.alpha = ph->alpha.p; p.pos = ph->pos.p; p.scale = ph->scale.p; p.first_update = ph->first.p; p.response = ph->response.p;
     p.cos_win = ph->cos_win.p; p.yf_re = ph->yf_re.p; p.tw_r = ph->tw_r.p; p.tw_c = ph->tw_c.p; p.sse_tab = c->sse_tab.p; p.gscratch = ph->gscratch.p;

@@ -39,6 +39,7 @@ struct KcfPool {
     // scratch carve (float offsets) and size
     int offA, offB, offC, offT, lds_floats;   // offT: ping-pong buffer of the generic DFT (unused by the 20x20 register FFT)
     int use_lds;              // 1: scratch in LDS, 0: per-workgroup slab in HBM, with region C and a staging area in LDS
+    int dft_inplace;          // LDS-resident, direct transforms: both passes in place (no region T in the layout)
     int szC, stage_floats, stage_G;   // !use_lds: LDS floats of region C / of the staging area, channel planes per DFT stage
     // !use_lds, R1-resident mode (r1_lds): LDS = [R1, wave-interleaved | region C in the order tab, tw, red, N, E/resp, zf, tmp | rest].  The gradient /
     // histogram run in stripes of stripe_k cell columns whose Mq / bins live in LDS from offX (= E) on; the DFTs take tile_T channel planes at a time
@@ -98,6 +99,7 @@ struct KcfLaunch {
     int slab_stride;          // floats per slab of the shared HBM scratch (0: the pool's own lds_floats)
     unsigned lds_bytes;       // dynamic LDS of the launch = the largest need of any class
     int r1_any;               // some class runs the R1-resident pipeline (KcfPool::r1_lds): the launch takes the kernels built with it
+    int gen_any;              // some LDS-resident class is not 20 x 20 cells: the launch takes the kernels with the direct transforms compiled in
 };
 
 struct KalmanPool {
@@ -165,7 +167,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s);
 hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s);
 size_t kcf_lds_bytes(const KcfPool& p);
-void kcf_pool_layout(KcfPool& p, bool allow_r1 = true);
+void kcf_pool_layout(KcfPool& p, bool allow_r1 = true, bool allow_inplace = true);
 
 hipError_t launch_kalman_predict(const KalmanPool& p, const int* slots, const int* count, int n, bbox_t* boxes_out, int clamp, hipStream_t s);
 hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int* count, int n, const bbox_t* boxes, hipStream_t s);

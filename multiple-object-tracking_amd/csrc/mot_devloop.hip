@@ -68,7 +68,7 @@ struct DevLoop {
     int pool = -1;
     DevBuf<int> ints; DevBuf<bbox_t> boxes; DevBuf<unsigned> tids;
     // size classes: pool index of every class, device table of their descriptors, one shared HBM scratch, LDS need of a launch
-    std::vector<int> cls_pool; DevBuf<KcfPool> pools_dev; DevBuf<float> shared_scratch; int slab_stride = 0; unsigned lds_bytes = 0; int r1_any = 0;
+    std::vector<int> cls_pool; DevBuf<KcfPool> pools_dev; DevBuf<float> shared_scratch; int slab_stride = 0; unsigned lds_bytes = 0; int r1_any = 0, gen_any = 0;
     bool begun = false; const void* frame = nullptr;
     hipEvent_t ev[8]{}; bool ev_ok = false;
     // split update (KCF): the spectra of all detection boxes are computed on a second, low-priority stream while the
@@ -135,7 +135,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             d->cls_pool.push_back(pi);
             const KcfPool& kp = c->pools[pi]->dev;
             if (use0 < 0) use0 = kp.use_lds; else if (use0 != kp.use_lds) return fail(MOT_ERR_ARG, "template sizes %d..%d straddle the LDS-resident / HBM-slab split", c->cfg.dev_size_lo, c->cfg.dev_size_hi);
-            maxf = std::max(maxf, (size_t)kp.lds_floats); maxlds = std::max(maxlds, (unsigned)kcf_lds_bytes(kp)); if (kp.r1_lds) d->r1_any = 1;
+            maxf = std::max(maxf, (size_t)kp.lds_floats); maxlds = std::max(maxlds, (unsigned)kcf_lds_bytes(kp)); if (kp.r1_lds) d->r1_any = 1; if (kp.use_lds && !kp.fft20) d->gen_any = 1;
         }
         if (!use0) { HIPCHK(d->shared_scratch.alloc((size_t)(cap + md) * maxf)); for (int pi : d->cls_pool) c->pools[pi]->dev.gscratch = d->shared_scratch.p; }
         for (int k = 0; k < S.ncls; k++) tab[k] = c->pools[d->cls_pool[k]]->dev;
@@ -259,7 +259,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     const int joined_on = mot_impl::env().joined_launch;
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
-        if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; l.r1_any = d->r1_any; }
+        if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; l.r1_any = d->r1_any; l.gen_any = d->gen_any; }
         if (d->defer) { l.pend_det = S.pend_det; l.pend_spec = spec_prev; }
         KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = spec_cur; lf.slab_base = S.cap;
         if (early && joined_on) {
@@ -340,7 +340,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const int upd_max = S.spr + nD;
     if (S.kind == MOT_TRACKER_KCF) {
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
-        if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; l.r1_any = d->r1_any; }
+        if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; l.r1_any = d->r1_any; l.gen_any = d->gen_any; }
         if (split) { l.det_spec = spec_cur; l.det_index = S.upd_det; }
         if (d->defer) {
             // only tracks that keep their PREDICTED box (unmatched, not lost: td.cpp:550-581) are left in the update list -- few or none,

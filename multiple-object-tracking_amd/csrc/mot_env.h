@@ -25,6 +25,7 @@ struct EnvSwitches {
     int lookahead;           // MOT_LOOKAHEAD=0: mot_step_frame_device_ahead ignores its hint
     int split_update;        // MOT_SPLIT_UPDATE=0: fused update kernel
     int dft_mfma;            // MOT_DFT_MFMA=0: HBM-slab templates use the generic DFT instead of the MFMA products
+    int dft_inplace;         // MOT_DFT_INPLACE=0: LDS-resident templates with the direct transforms keep the ping-pong buffer (region T)
     int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
@@ -51,6 +52,7 @@ inline const EnvSwitches& env()
         s.split_update = off("MOT_SPLIT_UPDATE") ? 0 : 1;
         s.dft_mfma = off("MOT_DFT_MFMA") ? 0 : 1;
         s.kcf_r1_lds = off("MOT_KCF_R1LDS") ? 0 : 1;
+        s.dft_inplace = off("MOT_DFT_INPLACE") ? 0 : 1;
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
         s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
         return s;
