@@ -90,7 +90,12 @@ namespace mot_impl {
 int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
 {
     for (size_t i = 0; i < c->pools.size(); i++)
-        if (c->pools[i]->dev.rows == rows && c->pools[i]->dev.cols == cols) { *out_idx = (int)i; return MOT_OK; }
+        if (c->pools[i]->dev.rows == rows && c->pools[i]->dev.cols == cols) {
+            // a pool created for single-pool launches (e.g. by mot_fhog_extract) may have dropped region T (in-place direct transforms); as a size class it
+            // needs the layout with it -- launches take the descriptor by value, so re-deriving the offsets is safe
+            if (shared_scratch && c->pools[i]->dev.dft_inplace) kcf_pool_layout(c->pools[i]->dev, c->pools[i]->dev.r1_lds != 0, false);
+            *out_idx = (int)i; return MOT_OK;
+        }
     if (rows < 8 || cols < 8 || rows > MOT_FRAME_H || cols > MOT_FRAME_W) return fail(MOT_ERR_ARG, "template size %dx%d unsupported (need 8..720 x 8..1280)", rows, cols);
     std::unique_ptr<PoolHost> ph(new PoolHost);
     KcfPool& p = ph->dev;

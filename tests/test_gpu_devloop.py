@@ -443,3 +443,27 @@ def test_device_loop_one_buffer_reused_in_stream_order(mot, oracle):
             assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
             assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
     m.close(); c.close()
+
+
+def test_size_class_after_single_pool_use(mot, oracle):
+    """a 72-px pool first created by a single-pool call (mot_fhog_extract: in-place direct transforms, no region T) and then used as a size class of the
+    device loop: get_pool re-derives the layout with region T for the size-class kernels -- same results as the oracle"""
+    from multiple_object_tracking_amd import synth
+    lo, hi, n, nframes = 72, 76, 40, 4
+    c = mot.MotContext(max_tracks=64, max_dets=64, dev_sizes=(lo, hi))
+    rng = np.random.default_rng(3)
+    I = rng.uniform(0, 255, size=(72, 72)).astype(np.float32)
+    H = c.fhog_extract(I, 72, 72)
+    assert np.array_equal(H.view(np.uint32), orc.fhog(oracle, I, 72, 72, 0).view(np.uint32))
+    scene = synth.Scene(n, (lo + hi) // 2, stream_id=46, det_sizes=(lo, hi))
+    items = list(scene.frames(nframes))
+    frames = [f for f, _ in items]; dets = [d[:64] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    m = orc.OracleMot(oracle, 0, 0, 64)
+    for f in range(nframes):
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+        ref = m.step(frames[f], dets[f])
+        boxes, tids, ages = c.live_tracks()
+        assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
+        assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
+    m.close(); c.close()
