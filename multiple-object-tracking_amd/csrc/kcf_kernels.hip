@@ -1979,7 +1979,7 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
         return hipGetLastError();
     }
     const size_t lds = kcf_lds_bytes(p);
-    if (t_start && t_stop && p.use_lds) {                              // (debug) the launch brackets itself with the caller's events
+    if ((t_start || t_stop) && p.use_lds) {                            // the launch carries the caller's events in its own packet (timing; the device loop's chain event)
         if (p.fft20 && p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1)) { hipError_t e = set_lds_attr(kcf_predict_kernel<7>, lds); if (e != hipSuccess) return e;
                        hipExtLaunchKernelGGL(kcf_predict_kernel<7>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
         else if (p.fft20) { hipError_t e = set_lds_attr(kcf_predict_kernel<1>, lds); if (e != hipSuccess) return e;
@@ -1988,7 +1988,7 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
                hipExtLaunchKernelGGL(kcf_predict_kernel<5>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
         return hipGetLastError();
     }
-    if (t_start && t_stop) {
+    if (t_start || t_stop) {
         if (p.r1_lds) { hipError_t e = set_lds_attr(kcf_predict_kernel<2>, lds); if (e != hipSuccess) return e;
                         hipExtLaunchKernelGGL(kcf_predict_kernel<2>, dim3(n), dim3(MOT_KCF_THREADS_SLAB), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }
         else { hipError_t e = set_lds_attr(kcf_predict_kernel<0>, lds); if (e != hipSuccess) return e;
