@@ -7,6 +7,9 @@ Prints, per frame, the duration of the predict launch (HIP events around mot_ste
 frame, and the phase stamps of workgroup 0 of the predict / update kernels (mot_debug_kcf_phases: crop, gradient,
 histogram, energy + norm, half 0, half 1, correlation + inverse + arg-max) in microseconds.  Workgroup 0 shares its CU with
 a second workgroup of the same launch, so the stamps are the CONTENDED phase times.
+MOT_DBG_EXTRA=1 adds, per frame on stderr, the sub-phase stamps of the R1-resident HBM-slab kernels (148 px) in microseconds after stamp 0: [8] / [9] end of
+the first / second half's transforms, [10] / [11] first stripe's gradient / histogram done, [12]..[15] first channel tile (start, channels done, transform done,
+barrier), [16] gray conversion of the crop done, [17] correlation done, [18] inverse transform done, [19] arg-max done.
 """
 import argparse, importlib, os, sys
 import numpy as np
