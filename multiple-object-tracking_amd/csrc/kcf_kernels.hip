@@ -1620,11 +1620,11 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
     kcf_predict_body<kMode>(p, l, item, smem);
 }
 
-template <int kMode>
+template <int kMode, bool kView = false>
 __device__ __forceinline__ void kcf_update_body(const KcfPool& pool_in, const KcfLaunch& l, const int item, float* smem)
 {
     constexpr bool kLds = (kMode & 1) != 0;
-    const KcfPool& p = pool_in;                                        // (the update kernels are never launched in mode 7, see launch_kcf_update)
+    const KcfPool p = kView ? pool_view<kMode>(pool_in) : pool_in;     // kView: see kcf_update_sparse_run
     const KcfPool& pc = p;
     float* base = kLds ? smem : p.gscratch + (size_t)(item + l.slab_base) * (l.slab_stride ? l.slab_stride : p.lds_floats);
     const bool r1m = (kMode == 2 || kMode == 4) && p.r1_lds;                                // R1-resident: LDS = [R1 | region C | work area], the crop's scratch is all of it
@@ -1737,13 +1737,17 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
     const int item = blockIdx.x;
     if (item >= n) return;
     if (l.count && item >= *l.count) return;
-    kcf_update_body<kMode>(p, l, item, smem);
+    kcf_update_body<kMode, true>(p, l, item, smem);
 }
 // Few items, count known on the device only (KcfLaunch::grid_stride): a small grid loops over them.  The device loop launches this every frame for
 // a list that is usually EMPTY (tracks that keep their predicted box), so the count test must come before anything else.  Out-of-line callees take
 // the pool descriptor by reference, which makes the compiler copy the by-value kernel arguments to private memory in the kernel's ENTRY block (19
 // scratch stores per lane: 20 MB and 4 us per empty launch when the body was inlined here); the body is therefore a function of its own that
 // receives the descriptors BY VALUE -- the copy happens at the call, behind the test.
+// kView stays false here (kMode 7): with the folded copy of the descriptor (pool_view) inside THIS function one residual update of a noisy stream
+// (tests/test_gpu_devloop.py::test_device_loop_vs_oracle[0-48-80-9], frame 8) came out two cells off, reproducibly, while the same folded copy in
+// the direct update kernel, the predict and the feature kernels passes every test and is bit-identical to the general kernels on every stream tried:
+// a code-generation issue around the by-value descriptor of an out-of-line function, not pursued.
 template <int kMode>
 __device__ __attribute__((noinline)) void kcf_update_sparse_run(KcfPool p, KcfLaunch l, int cnt)
 {
@@ -2019,9 +2023,8 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
     // exclusive_cu: ask for more than half of a CU's LDS so that no second workgroup (of this or of a concurrently running
     // KCF kernel) is placed on the same CU
     if (exclusive_cu && lds < MOT_LDS_LIMIT / 2 + 2048) lds = MOT_LDS_LIMIT / 2 + 2048;
-    // (the update kernels do not take the folded-geometry mode by default, MOT_KCF_K80 bit 2: with it one residual update of a noisy stream --
-    // tests/test_gpu_devloop.py::test_device_loop_vs_oracle[0-48-80-9], frame 8 -- came out two cells off, deterministically, and the cause was not found;
-    // the predict and feature kernels are bit-identical with and without it on every stream tried, and they are the ones that take the time)
+    // (folded geometry, MOT_KCF_K80 bit 2: the direct update kernel takes it; the sparse one below is launched in mode 7 too but keeps the run-time
+    // descriptor inside its out-of-line body -- see kcf_update_sparse_run)
     // grid_stride: the workgroups loop over up to n items (device-side count, usually zero): a grid of n / 8 workgroups, 4 .. 128
     const int grid = l.grid_stride ? (n / 8 < 4 ? (n < 4 ? n : 4) : (n / 8 > 128 ? 128 : n / 8)) : n;
     if (l.spec_out) {                                                  // feature-only launch: the lean kernel

@@ -26,7 +26,7 @@ struct EnvSwitches {
     int split_update;        // MOT_SPLIT_UPDATE=0: fused update kernel
     int dft_mfma;            // MOT_DFT_MFMA=0: HBM-slab templates use the generic DFT instead of the MFMA products
     int dft_inplace;         // MOT_DFT_INPLACE=0: LDS-resident templates with the direct transforms keep the ping-pong buffer (region T)
-    int k80;                 // MOT_KCF_K80: which kernels of an 80 x 80 px pool run with the geometry folded in (bit 0 predict, 1 feature, 2 update; default 3, 0: none)
+    int k80;                 // MOT_KCF_K80: which kernels of an 80 x 80 px pool run with the geometry folded in (bit 0 predict, 1 feature, 2 update; default 7, 0: none)
     int mid_in_launch;       // MOT_MID_IN_LAUNCH=0: the chain event is recorded by a packet of its own behind the predict launch
     int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
@@ -55,7 +55,7 @@ inline const EnvSwitches& env()
         s.dft_mfma = off("MOT_DFT_MFMA") ? 0 : 1;
         s.kcf_r1_lds = off("MOT_KCF_R1LDS") ? 0 : 1;
         s.mid_in_launch = off("MOT_MID_IN_LAUNCH") ? 0 : 1;
-        s.k80 = geti("MOT_KCF_K80", 3);                                  // bit 0 predict, 1 feature, 2 update kernels (off by default, see launch_kcf_update)
+        s.k80 = geti("MOT_KCF_K80", 7);                                  // bit 0 predict, 1 feature, 2 update kernels
         s.dft_inplace = off("MOT_DFT_INPLACE") ? 0 : 1;
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
         s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
