@@ -163,24 +163,27 @@ def dropin_timing(device, n=16, reps=12):
         hs = [C.c_void_p(new_f(C.byref(b))) for b in boxes]
         for h, p, b in zip(hs, patches, boxes):
             upd_f(h, orc.P(p), C.byref(b))                              # first update (eta = 1), td.cpp:631-640
-        tp = tu = 0.0
+        tp, tu = [], []
         for _ in range(reps):
             for h, p, b in zip(hs, patches, boxes):
                 pb = mot_amd.BBox()
                 t0 = time.perf_counter(); pred_f(h, orc.P(p), C.byref(pb)); t1 = time.perf_counter()
                 upd_f(h, orc.P(p), C.byref(b)); t2 = time.perf_counter()
-                tp += t1 - t0; tu += t2 - t1
+                tp.append((t1 - t0) * 1e6); tu.append((t2 - t1) * 1e6)
         for h in hs:
             del_f(h)
-        return tp / (reps * n) * 1e6, tu / (reps * n) * 1e6
+        return np.array(tp), np.array(tu)
     run(new, pred, upd, dele)                                          # warm-up (context creation, first launches)
     p_us, u_us = run(new, pred, upd, dele)
-    out = {"tracker_predict_us": p_us, "tracker_update_us": u_us, "calls": n * reps, "patch": "80x80 float gray (caller memory)",
-           "note": "per-object interface = batch of one per call; the batch ABI (mot_step_frame_device) is the measured path"}
+    out = {"tracker_predict_us": float(p_us.mean()), "tracker_update_us": float(u_us.mean()),
+           "tracker_predict_p50_p90_us": [float(np.percentile(p_us, 50)), float(np.percentile(p_us, 90))],
+           "tracker_update_p50_p90_us": [float(np.percentile(u_us, 50)), float(np.percentile(u_us, 90))],
+           "calls": n * reps, "patch": "80x80 float gray (caller memory)",
+           "note": "per-object interface = batch of one per call (zero-copy: the kernel reads the pinned patch and writes the box itself; one launch + one stream synchronisation); the batch ABI (mot_step_frame_device) is the measured path"}
     if orc.ref_available():
         k = orc.load_ref("kcf")
         rp, ru = run(lambda b: k.refkcf_new(b), k.refkcf_predict, k.refkcf_update, k.refkcf_delete)
-        out.update({"reference_tracker_predict_us": rp, "reference_tracker_update_us": ru, "reference_cores": 1})
+        out.update({"reference_tracker_predict_us": float(rp.mean()), "reference_tracker_update_us": float(ru.mean()), "reference_cores": 1})
     return out
 
 
@@ -268,7 +271,8 @@ def main():
     n_prof = args.profile_frames if (world == 1 and args.streams_per_gpu == 1) else 0
     n_h2d = args.h2d if (world == 1 and args.streams_per_gpu == 1) else 0
     n_inloop = 20 if n_prof else 0                                      # frames of the ordinary loop whose predict launch is timed in place (roofline)
-    n_frames = 1 + args.warmup + args.steps + args.steady + n_inloop + n_prof
+    n_rank_prof = 10 if (world > 1 and not streams) else 0            # sharded runs: frames whose per-rank stage times are recorded (behind the timed windows)
+    n_frames = 1 + args.warmup + args.steps + args.steady + n_inloop + n_prof + n_rank_prof
     det_counts = []
     frames_h, dets_h = gen_stream(n_tracks, size, n_frames, stream_id=rank if streams else 0, det_sizes=tuple(args.det_sizes) if args.det_sizes else None,
                                   first_frame_exact=not args.per_track_sizes, miss_pct=args.miss_pct, fp_pct=args.fp_pct, nms=args.nms, counts=det_counts)
@@ -364,6 +368,21 @@ def main():
             steady = {"value": n_live * args.steady / ts, "ms_per_step": ts / args.steady * 1e3, "frames": args.steady,
                       "first_frame": 1 + args.warmup + args.steps}
 
+        # sharded: what a frame costs THIS rank, stage by stage (HIP events on the context's stream around predict launch / all-gather /
+        # replicated association chain / residual update), mean over 10 ordinary frames behind the timed windows; all ranks' rows go into
+        # the line so a scaling run can be checked against DESIGN.md section 5's table
+        rank_stages = None
+        if n_rank_prof:
+            acc4 = np.zeros(4)
+            for _ in range(n_rank_prof):
+                ctx.debug_profile_stages(True)
+                step(f); f += 1
+                acc4 += ctx.debug_profile_stages(False, read=True)
+            mine = {"rank": rank, **{k: float(v) for k, v in zip(("predict_ms", "gather_ms", "chain_ms", "update_ms"), acc4 / n_rank_prof)}}
+            rows = [None] * world
+            dist.all_gather_object(rows, mine)
+            rank_stages = rows
+
         # the predict launch as it runs IN the loop (look-ahead feature launch beside it, deferred blend in its prologue): its own begin / end
         # stamps over 20 ordinary frames -- the duration rocprofv3 --kernel-trace reports for it in this configuration (roofline.avg_launch_ms)
         inloop_ms = None
@@ -448,6 +467,9 @@ def main():
         ab = alg_bytes(size)
         if steady is not None:
             out["steady_state"] = steady
+        if rank_stages is not None:
+            out["per_rank_stage_ms"] = {"frames": n_rank_prof, "first_frame": 1 + args.warmup + args.steps + args.steady, "ranks": rank_stages,
+                                        "what": "mean per frame on every rank: predict launch (own shard), all-gather (end of the predict -> start of the finish call), replicated association chain incl. scatter + lifecycle, residual update launch; HIP events on the context's stream"}
         if h2d is not None:
             out["h2d_inclusive"] = h2d
         if stage is not None:

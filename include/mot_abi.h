@@ -217,6 +217,8 @@ int mot_step_frame_sharded(mot_ctx* ctx, const void* frame_dev, const void* dets
  * pointers and count to benefit.  mot_step_begin_device_ahead is the two-call form (the caller runs the all-gather itself). */
 int mot_step_frame_sharded_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
                                  const void* next_frame_dev, const void* next_dets_dev, int next_nD, void* nccl_comm);
+/* mot_step_finish_device must then be given the SAME dets_dev and nD as this call (the frame's detection spectra are computed, or adopted
+ * from the look-ahead launch, for that list): a different pointer or count is refused with MOT_ERR_ARG. */
 int mot_step_begin_device_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
                                 const void* next_frame_dev, const void* next_dets_dev, int next_nD, void** local_boxes_dev, int* slots_per_rank);
 int mot_live_count(mot_ctx* ctx, int* n_live);
@@ -258,10 +260,24 @@ int mot_get_pos(mot_ctx* ctx, int id, bbox_t* pos);
 /* device-resident loop: kcf_t::response (kcf.cpp:58) of the i-th LIVE track (order of mot_live_tracks) as left by the most recent
  * predict -- the 1e-4 peak check at full track counts */
 int mot_live_response(mot_ctx* ctx, int live_index, float* out, int* f_rows, int* f_cols);
+/* ... and its model as it is in device memory right now (kcf_t::xf_md, alpha, pos, scale: kcf.cpp:50-62): xm_out 31 * f_cols * (f_rows/2+1)
+ * complex, alpha_out f_cols * (f_rows/2+1) floats, scale2 (horizontal, vertical), pending_det = the detection of the last frame whose
+ * spectrum the NEXT predict will blend in first (deferred blend; -1: none).  Any output may be null.  Synchronises the context (all streams).
+ * State dump for replaying / comparing runs bit by bit (tools/lookahead_soak.py). */
+int mot_live_model(mot_ctx* ctx, int live_index, float* xm_out, float* alpha_out, bbox_t* pos, float* scale2, int* first_update, int* pending_det);
 /* debug: enable / read the per-phase time stamps (100 MHz ticks) of workgroup 0 of the device-loop KCF kernels:
  * [0] start [1] crop [2] gradient [3] histogram [4] norm [5] channels [6] DFT [7] end */
 /* debug: duration of the predict launch itself (the kernel's own begin / end stamps) while the ordinary device-resident step calls run:
  * arm n pairs, step n frames, read the n durations (synchronises).  What rocprofv3 reports for the launch in the timed configuration. */
+/* debug: stream-ordered (no host synchronisation) copy of the device loop's small state -- counts, live list, this frame's predicted boxes, KCF
+ * pos / pending detection / first-update flag by slot, head of the residual-update list, association header -- into caller-owned device memory;
+ * *bytes receives the record size (dst_dev may be null to ask for it).  Layout: csrc/mot_devloop.hip.  For soak tools. */
+int mot_debug_snapshot(mot_ctx* ctx, void* dst_dev, size_t* bytes);
+/* debug / bench: stage times of the two-call (mot_step_begin_device[_ahead] + mot_step_finish_device) and of the sharded step on this rank.
+ * enable, step ONE frame, then call again with stage_ms4 to read [0] predict launch [1] all-gather (end of the predict -> finish call)
+ * [2] association chain (scatter, row scan, solver / emulation, lifecycle) [3] residual update launch, in ms (HIP events on the context's
+ * stream; reading synchronises).  bench.py --gpus N prints them per rank. */
+int mot_debug_profile_stages(mot_ctx* ctx, int enable, float* stage_ms4);
 int mot_debug_predict_timing(mot_ctx* ctx, int n_pairs);
 int mot_debug_predict_times(mot_ctx* ctx, float* out_ms, int cap, int* n);
 int mot_debug_kcf_phases(mot_ctx* ctx, int enable, long long* predict8, long long* update8);

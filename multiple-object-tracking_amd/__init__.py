@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmot_amd.so")
+LIB_PATH = os.environ.get("MOT_AMD_LIB") or os.path.join(_HERE, "libmot_amd.so")   # MOT_AMD_LIB: the probe build of tools/kcf_ablate.py, never the product
 DROPIN_KCF_PATH = os.path.join(_HERE, "libmot_dropin_kcf.so")
 DROPIN_KALMAN_PATH = os.path.join(_HERE, "libmot_dropin_kalman.so")
 
@@ -320,6 +320,16 @@ class MotContext:
         self._chk(self.lib.mot_live_response(self._h, int(live_index), _vp(out), C.byref(fr), C.byref(fc)))
         return out
 
+    def live_model(self, live_index: int):
+        """(xm complex64 [31 * bins], alpha float32 [bins], pos, scale (h, v), first_update, pending_det) of the i-th live track of the device loop"""
+        fr, fc = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_live_response(self._h, int(live_index), None, C.byref(fr), C.byref(fc)))
+        bins = fc.value * (fr.value // 2 + 1)
+        xm = np.zeros(31 * bins * 2, np.float32); al = np.zeros(bins, np.float32); pos = np.zeros(1, BBOX_DTYPE); sc = np.zeros(2, np.float32)
+        first, pend = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.mot_live_model(self._h, int(live_index), _vp(xm), _vp(al), _vp(pos), _vp(sc), C.byref(first), C.byref(pend)))
+        return xm.view(np.complex64), al, pos[0], sc, first.value, pend.value
+
     # ---- introspection ----
     def get_response(self, tid: int) -> np.ndarray:
         fr, fc = C.c_int(0), C.c_int(0)
@@ -355,6 +365,21 @@ class MotContext:
         out = np.zeros(16, np.int32)
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
         return out
+
+    def debug_snapshot_bytes(self) -> int:
+        n = C.c_size_t(0)
+        self._chk(self.lib.mot_debug_snapshot(self._h, None, C.byref(n)))
+        return int(n.value)
+
+    def debug_snapshot(self, dst_dev: int):
+        """stream-ordered copy of the device loop's small state into device memory at dst_dev (debug_snapshot_bytes() bytes); no synchronisation"""
+        self._chk(self.lib.mot_debug_snapshot(self._h, C.c_void_p(dst_dev), None))
+
+    def debug_profile_stages(self, enable: bool, read: bool = False):
+        """two-call / sharded step: per-rank stage times of the last profiled frame [predict, all-gather, chain, residual update] in ms"""
+        out = np.zeros(4, np.float32)
+        self._chk(self.lib.mot_debug_profile_stages(self._h, 1 if enable else 0, _vp(out) if read else None))
+        return out if read else None
 
     def debug_predict_timing(self, n_pairs: int):
         self._chk(self.lib.mot_debug_predict_timing(self._h, int(n_pairs)))

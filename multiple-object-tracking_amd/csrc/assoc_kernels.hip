@@ -1124,6 +1124,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // kernel leaves a hint in pinned host memory, read here without synchronisation (stale by a frame or two: it only picks the grid)
     const bool hinted = hinted_now;                                    // (a noisy stream: the countdown above is armed)
     const bool big = !prep_in_kernel && ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (force_cov << 3), life, lap ? 1 : 0);
     else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0) | (prep_in_kernel ? 4 : 0), life, lap ? 1 : 0);
     return hipGetLastError();

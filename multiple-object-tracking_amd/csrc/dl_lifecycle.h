@@ -94,6 +94,10 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     __syncthreads();
     // td.cpp:512-582 (counters, update box) and :585-609 (lost rule)
     int slot = -1, age = 0, vis = 0, inv = 0, tcls = 0; unsigned tid = 0; bbox_t bb{}; bool keep = false, mine = false;
+    // Round 5: the update list and the free-slot stack are filled in LIVE ORDER (block scans instead of atomic counters) -- which slot a new
+    // track receives and where an item sits in the residual-update list no longer depend on the order in which wavefronts reach an atomic,
+    // so two runs of a stream leave the same bits in device memory (state dumps can be compared; results never depended on it).
+    bool to_upd = false, to_free = false; int j_upd = -1;
     if (t < nT) {
         slot = S.slot[t]; tid = S.tid[t]; age = S.age[t]; vis = S.vis[t]; inv = S.inv[t];
         if (multi) tcls = S.cls[t];
@@ -110,10 +114,20 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
                 kp.pos[slot] = bb;
                 kp.scale[slot] = make_float2(((float)(bb.r - bb.l + 1)) / ((float)kp.cols), ((float)(bb.b - bb.t + 1)) / ((float)kp.rows));
             }
-            else if (keep) { const int q = atomicAdd(&cnt[0], 1); S.upd_slots[q] = slot; S.upd_boxes[q] = bb; S.upd_det[q] = j; if (multi) S.upd_cls[q] = tcls; }
+            else if (keep) { to_upd = true; j_upd = j; }
             else if (multi) { const int q = atomicAdd(&cntc[tcls], 1); S.free_c[(size_t)tcls * S.cap + q] = slot; }
-            else { const int q = atomicAdd(&cnt[1], 1); S.free_slots[q] = slot; }   // tracker_delete (td.cpp:599)
+            else to_free = true;                                           // tracker_delete (td.cpp:599)
         }
+    }
+    {
+        int n_upd, n_free;
+        const int upos = block_excl_scan_flag(to_upd, wave_tot, n_upd);
+        const int fpos = block_excl_scan_flag(to_free, wave_tot, n_free);
+        const int free0 = cnt[1];                                          // (written before the first barrier of this function; rewritten behind the next one)
+        if (to_upd) { S.upd_slots[upos] = slot; S.upd_boxes[upos] = bb; S.upd_det[upos] = j_upd; if (multi) S.upd_cls[upos] = tcls; }
+        if (to_free) S.free_slots[free0 + fpos] = slot;
+        __syncthreads();
+        if (t == 0) { cnt[0] = n_upd; cnt[1] = free0 + n_free; }
     }
     int n_keep;
     const int newpos = block_excl_scan_flag(keep, wave_tot, n_keep);
@@ -131,16 +145,22 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     int n_spawn;
     const int spos = block_excl_scan_flag(spawn, wave_tot, n_spawn);
     const unsigned tid0 = *S.next_tid;
+    // slots for the spawning tracks this rank owns, in detection order from the top of the stack (single template; the per-class stacks of
+    // the size classes keep their atomic tops)
+    const bool in_cap = spawn && n_keep + spos < S.cap;
+    const bool m2 = in_cap && ((int)((tid0 + (unsigned)spos) % (unsigned)S.world) == S.rank);
+    int n_pop;
+    const int ppos = block_excl_scan_flag(m2 && !multi, wave_tot, n_pop);
+    const int top0 = cnt[1];
     __syncthreads();
     if (spawn) {
         const int idx = n_keep + spos;
         if (idx < S.cap) {
             const unsigned ntid = tid0 + (unsigned)spos;
-            const bool m2 = ((int)(ntid % (unsigned)S.world) == S.rank);
             int ns = -1;
             if (m2) {
                 if (multi) { const int top = atomicSub(&cntc[scls], 1) - 1; if (top >= 0) ns = S.free_c[(size_t)scls * S.cap + top]; else atomicAdd(&S.err[2], 1); }
-                else { const int top = atomicSub(&cnt[1], 1) - 1; if (top >= 0) ns = S.free_slots[top]; else atomicAdd(&S.err[2], 1); }
+                else { const int top = top0 - 1 - ppos; if (top >= 0) ns = S.free_slots[top]; else atomicAdd(&S.err[2], 1); }
             }
             S.slot[idx] = ns; S.tid[idx] = ntid; S.age[idx] = 0; S.vis[idx] = 0; S.inv[idx] = 0; S.bbox[idx] = db;
             if (multi) S.cls[idx] = scls;
@@ -158,6 +178,8 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
             }
         } else atomicAdd(&S.err[1], 1);
     }
+    __syncthreads();
+    if (t == 0 && !multi) cnt[1] = top0 - n_pop;
     __syncthreads();
     int n_new = n_keep + n_spawn; if (n_new > S.cap) n_new = S.cap;
     if (t == 0) {

@@ -15,6 +15,17 @@ using namespace mot_impl;
 
 namespace {
 
+// (debug, MOT_LDS_POISON) every compute unit's LDS is overwritten with `word`: 160 KB per workgroup = one workgroup per CU at a time, four
+// rounds over the 256 CUs; each workgroup lingers a few microseconds so that the dispatcher spreads the round over the chip
+__global__ void __launch_bounds__(256) lds_poison_kernel(unsigned word)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_poison_smem[];
+    volatile unsigned* q = lds_poison_smem;
+    for (int i = threadIdx.x; i < (int)(MOT_LDS_LIMIT / 4); i += 256) q[i] = word;
+    __syncthreads();
+    for (int k = 0; k < 4; k++) __builtin_amdgcn_s_sleep(127);
+}
+
 __global__ void __launch_bounds__(256) helper_gray_kernel(const uint8_t* __restrict__ crop, float* __restrict__ out, int rows, int cols)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -51,6 +62,15 @@ __global__ void __launch_bounds__(256) helper_rect_kernel(uint8_t* __restrict__ 
 }
 
 } // namespace
+
+namespace mot_impl {
+hipError_t lds_poison_launch(hipStream_t s, unsigned word)
+{
+    hipError_t e = func_lds_once(reinterpret_cast<const void*>(lds_poison_kernel), MOT_LDS_LIMIT); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(1024), dim3(256), MOT_LDS_LIMIT, s, word);
+    return hipGetLastError();
+}
+}
 
 extern "C" {
 

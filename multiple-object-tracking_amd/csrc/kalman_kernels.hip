@@ -6,6 +6,7 @@
 // in LDS (one 3 KB slab per wavefront).  Products accumulate k = 0..5 in
 // order with separate multiply/add roundings, matching the oracle.
 #include "mot_dev.h"
+#include "mot_env.h"
 
 namespace {
 
@@ -180,18 +181,21 @@ __global__ void kalman_init_kernel(KalmanPool p, const int* slots, int n, const 
 
 hipError_t launch_kalman_predict(const KalmanPool& p, const int* slots, const int* count, int n, bbox_t* boxes_out, int clamp, hipStream_t s)
 {
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kalman_predict_kernel, dim3((n + 3) / 4), dim3(256), 0, s, p, slots, count, n, boxes_out, clamp);
     return hipGetLastError();
 }
 hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int* count, int n, const bbox_t* boxes, hipStream_t s)
 {
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kalman_update_kernel, dim3((n + 3) / 4), dim3(256), 0, s, p, slots, count, n, boxes);
     return hipGetLastError();
 }
 hipError_t launch_kalman_init(const KalmanPool& p, const int* slots, int n, const bbox_t* boxes, hipStream_t s)
 {
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kalman_init_kernel, dim3(n), dim3(64), 0, s, p, slots, n, boxes);
     return hipGetLastError();

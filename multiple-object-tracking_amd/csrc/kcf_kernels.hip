@@ -18,9 +18,17 @@
 #include "mot_dev.h"
 #include "mot_env.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "bin_thresholds.inc"
 
 #define PI_F 3.14159265f /* libhog/gradientMex.cpp:12 */
+// (probe build only, `make ablate` -> libmot_amd_ablate.so) phases of the KCF kernels can be switched off one by one (KcfLaunch::ablate, from
+// MOT_KCF_ABLATE): the launch time lost is what the phase costs the LAUNCH under real contention -- results are garbage, timing tools only
+#ifdef MOT_KCF_ABLATE
+#define ABL(bit) (!((l.ablate >> (bit)) & 1))
+#else
+#define ABL(bit) true
+#endif
 /* R1 (18 orientation sums per cell) in LDS is WAVE-INTERLEAVED: bin o of cell c lives at ((c / 64) * 18 + o) * 64 + c % 64, so
  * a lane's read-modify-writes always hit bank = lane whatever the (data-dependent) bin -- cell-major rows made the
  * histogram's scatter 2- to 4-way bank-conflicted.  In the HBM slab R1 is orientation-major (coalesced), o * nb + c. */
@@ -218,9 +226,13 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
     { const int t1[9] = MOT_BIN_THR1; for (int j = 0; j < 9; j++) if (t1[j] != thr0[j]) __builtin_trap(); }   // both sign flags share the thresholds
     if (thr0[4] != 1) __builtin_trap();
     for (int j = 0; j < 4; j++) if (thr0[5 + j] != -thr0[3 - j] + 1) __builtin_trap();                           // the mirror structure the bin count relies on
-    const bool approx = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
+    const bool approx_rt = (p.fhog_mode == MOT_FHOG_INTEL_APPROX);
     if (xn < 0) xn = w;
-    auto group = [&](int it) {
+    // `approx` is launch-uniform: the loop is instantiated once per flavour (round 5) -- with the run-time test inside, every pixel's two table
+    // look-ups sat behind a branch and were waited for one by one (8 dependent LDS round trips per 4-pixel group); now the four pixels of a
+    // group are straight-line code and their look-ups are in flight together
+    auto group = [&](int it, auto approx_c) {
+        constexpr bool approx = decltype(approx_c)::value;
         uint32_t x, kq; p.d_ng.divmod((uint32_t)it, x, kq);
         x += (uint32_t)xb;
         const int y0 = 4 * (int)kq;
@@ -266,11 +278,15 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
         *reinterpret_cast<uint16_t*>(bo) = (uint16_t)(bq[0] | (bq[1] << 8));
         *reinterpret_cast<uint16_t*>(bo + 2) = (uint16_t)(bq[2] | (bq[3] << 8));
     };
-    if (UNR > 1) {
+    if (approx_rt) {
+        if (UNR > 1) {
 #pragma unroll UNR
-        for (int it = tid; it < xn * ng; it += nt) group(it);
+            for (int it = tid; it < xn * ng; it += nt) group(it, std::true_type{});
+        } else {
+            for (int it = tid; it < xn * ng; it += nt) group(it, std::true_type{});       // the compiler's own choice, as before the stripes existed
+        }
     } else {
-        for (int it = tid; it < xn * ng; it += nt) group(it);       // the compiler's own choice, as before the stripes existed
+        for (int it = tid; it < xn * ng; it += nt) group(it, std::false_type{});
     }
     // the two pad slots above and below every column are read (with weight 0) by the histogram: finite magnitude, bin 0
     for (int i = tid; i < 4 * xn; i += nt) {
@@ -336,14 +352,30 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 const float4 ma = pma[g], mb = pmb[g];
                 const uint32_t ba = pba[g], bb = pbb[g];
                 const float mv[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
-                // sequential read-modify-write in pixel order: the LDS queue of a wave is in order, so a later pixel of the
-                // same orientation sees the earlier sum.  (ds_add_f32 -- one LDS float add per pixel, no return value, bit-identical
-                // sums -- was measured in round 3: the predict launch went from 100 to 215 us; the LDS atomic path is that slow.)
+                // The eight read-modify-writes of the column in ONE LDS round trip instead of eight dependent ones (round 5; before, every pixel
+                // waited for its own ds_read: 64 round trips per cell): all eight sums are read first, the pixel order is then resolved in
+                // registers -- a later pixel of the same orientation continues from the running value of the latest earlier one, exactly the
+                // sequence of float additions of the sequential form -- and the eight results are stored in pixel order (the LDS executes a
+                // wave's accesses in order, so the last store of an orientation is the one that stays, and the next column's reads see it).
+                // (ds_add_f32 -- one LDS float add per pixel, no return value, bit-identical sums -- was measured in round 3: the predict
+                // launch went from 100 to 215 us; the LDS atomic path is that slow.)
+                int ad[8]; float wv[8], rv[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
-                    Rc[bj * 64] += (wx * wy[j]) * mv[j];
+                    ad[j] = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu) * 64;
+                    wv[j] = (wx * wy[j]) * mv[j];
                 }
+#pragma unroll
+                for (int j = 0; j < 8; j++) rv[j] = Rc[ad[j]];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float base = rv[j];
+#pragma unroll
+                    for (int m = 0; m < j; m++) base = (ad[m] == ad[j]) ? rv[m] : base;   // rv[m] already holds pixel m's result
+                    rv[j] = base + wv[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) Rc[ad[j]] = rv[j];
             }
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
@@ -1330,19 +1362,19 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
         const bool in_lds = nsrc <= p.stage_floats;
         phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(stage), tid, nt, p.stage_floats * 4, in_lds ? stage : r.B, in_lds ? p.stage_floats : p.lds_floats - p.offB);
     }
-    else phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt, 1 << 30, r.B, p.offC - p.offB);
+    else if (ABL(1)) phase_crop(p, l.frame, patch, box, r.A, reinterpret_cast<uint8_t*>(r.B), tid, nt, 1 << 30, r.B, p.offC - p.offB);
     __syncthreads();
     DBG_STAMP(1);
     float* Mq = r.B; uint8_t* bins = reinterpret_cast<uint8_t*>(r.B + p.cols * p.ldp);
-    phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
+    if (ABL(2)) phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
-    phase_hist<SLAB ? 4 : 0, LDSR1>(p, Mq, bins, r.A, stage, tid, nt);       // R1 overlays the patch
+    if (ABL(3)) phase_hist<SLAB ? 4 : 0, LDSR1>(p, Mq, bins, r.A, stage, tid, nt);       // R1 overlays the patch
     __syncthreads();
     DBG_STAMP(3);
-    phase_energy<SLAB>(p, r.A, r.E, tid, nt);
+    if (ABL(4)) phase_energy<SLAB>(p, r.A, r.E, tid, nt);
     __syncthreads();
-    phase_norm(p, r.E, r.N, tid, nt);
+    if (ABL(4)) phase_norm(p, r.E, r.N, tid, nt);
     __syncthreads();
     DBG_STAMP(4);
 }
@@ -1361,7 +1393,7 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
     // HBM-slab templates with MFMA tables: the half's feature planes go straight into the LDS staging area and both DFT
     // passes run from there (no slab round trip of the planes, no row-spectrum buffer)
     const bool fused = SLAB && spectrum && stage && p.mf && p.stage_floats >= MOT_HALF0 * p.wb * 2 * p.fh + MOT_MF_CW_FLOATS;
-    phase_channels<HALF, SLAB>(p, r.A, r.N, fused ? stage : r.B, fo, l.feat_windowed, tid, nt);
+    if (ABL(5)) phase_channels<HALF, SLAB>(p, r.A, r.N, fused ? stage : r.B, fo, l.feat_windowed, tid, nt);
     __syncthreads();
     DBG_STAMP(8 + HALF);
     if (fused) {
@@ -1374,7 +1406,8 @@ __device__ void half_spectrum(const KcfPool& p, const KcfLaunch& l, int item, co
         // the single-pool kernels with the R1-resident pipeline (kMode 2) keep this, for them dead, path out of line: inlined it costs the shared
         // phases registers (148 px: 586 -> 537 k updates/s); everywhere else -- also in the size-class kernels that mix R1-resident and larger
         // templates (kMode 4) -- inlining it is what pays (168 / 200 px: 0.48 / 0.77 -> 0.37 / 0.55 ms per frame)
-        if (OOL) fft_forward_ool<SLAB, GEN, INPL>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
+        if (!ABL(6)) { __syncthreads(); }
+        else if (OOL) fft_forward_ool<SLAB, GEN, INPL>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
         else fft_forward<SLAB, GEN, INPL>(p, r.T, r.B, r.twr, r.twc, HALF ? (MOT_NCHAN - MOT_HALF0) : MOT_HALF0, tid, nt, stage);
     }
 }
@@ -1501,16 +1534,16 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
         __syncthreads();                                           // the blended model is visible to the whole workgroup (loads below)
         if (tid == 0) { l.pend_det[slot] = -1; p.first_update[slot] = 0; }
     };
-    if (dj >= 0 && !late) blend();
+    if (dj >= 0 && !late && ABL(0)) blend();
     // the model does not depend on this frame: issue its loads now (31 independent 8-byte loads per bin thread),
     // they land while the features are computed
-    if (pre && !have_model && !late) {
+    if (pre && !have_model && !late && ABL(10)) {
 #pragma unroll
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
     features_prepare<!kLds, true, (kMode == 2 || kMode == 4)>(pc, l, item, pos, r, tid, nt, stage);
-    if (late) blend();
+    if (late && ABL(0)) blend();
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
     const float2* S = reinterpret_cast<const float2*>(r.B);
@@ -1520,12 +1553,14 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
     half_spectrum<0, !kLds, (kMode == 2 || kMode == 4), (kMode != 1 && kMode != 7), kMode == 2, kMode == 5>(p, l, item, r, tid, nt, true, stage);
     DBG_STAMP(5);
     if (pre) {
-        if (tid < p.nbins) {
+        if (tid < p.nbins && ABL(7)) {
 #pragma unroll
             for (int ch = 0; ch < MOT_HALF0; ch++) { const float2 a = S[ch * p.nbins + tid]; const float2 m = xmr[ch]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
         }
+        if (ABL(10)) {
 #pragma unroll
         for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) xmr[ch - MOT_HALF0] = xm[ch * p.nbins + bpre];   // second half: lands during its features
+        }
     } else if (r1m && p.nbins <= nt) {
         // R1-resident HBM-slab templates with one bin per thread: the partial sums stay in registers
         if (tid < p.nbins) {
@@ -1543,8 +1578,10 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
     DBG_STAMP(6);
     if (pre) {
         if (tid < p.nbins) {
+            if (ABL(7)) {
 #pragma unroll
             for (int ch = MOT_HALF0; ch < MOT_NCHAN; ch++) { const float2 a = S[(ch - MOT_HALF0) * p.nbins + tid]; const float2 m = xmr[ch - MOT_HALF0]; zr += a.x * m.x + a.y * m.y; zi += a.y * m.x - a.x * m.y; }
+            }
             r.zf[tid] = make_float2((zr * alr) * p.norm, (zi * alr) * p.norm);
         }
     } else if (r1m && p.nbins <= nt) {
@@ -1563,10 +1600,10 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
     }
     __syncthreads();
     DBG_STAMP(17);
-    fft_inverse_plane(p, r.zf, r.tmp, r.resp, r.twr, r.twc, tid, nt);
+    if (ABL(8)) fft_inverse_plane(p, r.zf, r.tmp, r.resp, r.twr, r.twc, tid, nt);
     DBG_STAMP(18);
-    for (int i = tid; i < p.nb; i += nt) p.response[(size_t)slot * p.nb + i] = r.resp[i];
-    const int best = block_argmax_first(r.resp, p.nb, r.red_v, r.red_i, tid, nt);
+    if (ABL(9)) for (int i = tid; i < p.nb; i += nt) p.response[(size_t)slot * p.nb + i] = r.resp[i];
+    const int best = ABL(9) ? block_argmax_first(r.resp, p.nb, r.red_v, r.red_i, tid, nt) : 0;
     DBG_STAMP(19);
     if (tid == 0) {
         int vd = 1, hd = 1;
@@ -1748,11 +1785,19 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
 // (tests/test_gpu_devloop.py::test_device_loop_vs_oracle[0-48-80-9], frame 8) came out two cells off, reproducibly, while the same folded copy in
 // the direct update kernel, the predict and the feature kernels passes every test and is bit-identical to the general kernels on every stream tried:
 // a code-generation issue around the by-value descriptor of an out-of-line function, not pursued.
-template <int kMode>
+template <int kMode, bool kView = false>
 __device__ __attribute__((noinline)) void kcf_update_sparse_run(KcfPool p, KcfLaunch l, int cnt)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode>(p, l, item, smem); __syncthreads(); }
+    for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode, kView>(p, l, item, smem); __syncthreads(); }
+}
+// (investigation, MOT_KCF_K80 bit 3) the folded descriptor inside the out-of-line body as well
+template <int kMode>
+__global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_view_kernel(const KcfPool p, const KcfLaunch l, int n)
+{
+    const int cnt = min(n, l.count ? *l.count : n);
+    if ((int)blockIdx.x >= cnt) return;
+    kcf_update_sparse_run<kMode, true>(p, l, cnt);
 }
 template <int kMode>
 __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_kernel(const KcfPool p, const KcfLaunch l, int n)
@@ -1974,8 +2019,18 @@ static hipError_t set_lds_attr(K kern, size_t bytes)
                           hipLaunchKernelGGL(KERN<0>, dim3(GRID), dim3(MOT_KCF_THREADS_SLAB), LDSB, STREAM, __VA_ARGS__); }     \
     } while (0)
 
-hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)
+#ifdef MOT_KCF_ABLATE
+static int g_ablate_mask = [] { const char* e = getenv("MOT_KCF_ABLATE"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+static int ablate_mask() { return g_ablate_mask; }
+extern "C" void mot_debug_kcf_ablate(int mask) { g_ablate_mask = mask; }   // probe build only: tools/kcf_ablate.py switches phases off for single frames
+#define ABLATE_ARG(L) KcfLaunch L##_abl = L; L##_abl.ablate = ablate_mask(); const KcfLaunch& L##_use = L##_abl
+#else
+#define ABLATE_ARG(L) const KcfLaunch& L##_use = L
+#endif
+hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l_in, int n, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)
 {
+    ABLATE_ARG(l_in); const KcfLaunch& l = l_in_use;
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
         const size_t ldsm = l.lds_bytes;
@@ -2003,16 +2058,20 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l, int n, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp, int n_pred, const KcfLaunch& lf, int n_feat, hipStream_t s)
+hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp_in, int n_pred, const KcfLaunch& lf_in, int n_feat, hipStream_t s)
 {
+    ABLATE_ARG(lp_in); const KcfLaunch& lp = lp_in_use; ABLATE_ARG(lf_in); const KcfLaunch& lf = lf_in_use;
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n_pred + n_feat <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
     KCF_LAUNCH3(kcf_predict_features_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1)), n_pred + n_feat, lds, s, p, lp, lf, n_pred, n_feat);
     return hipGetLastError();
 }
 
-hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s, bool exclusive_cu)
+hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l_in, int n, hipStream_t s, bool exclusive_cu)
 {
+    ABLATE_ARG(l_in); const KcfLaunch& l = l_in_use;
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     if (l.pools) {
         const size_t ldsm = l.lds_bytes;
@@ -2031,7 +2090,11 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
         KCF_LAUNCH3(kcf_features_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 2)), n, lds, s, p, l, n);
         return hipGetLastError();
     }
-    if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 4)), grid, lds, s, p, l, n);
+    if (l.grid_stride && p.use_lds && p.fft20 && p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 8)) {
+        hipError_t e_ = set_lds_attr(kcf_update_sparse_view_kernel<7>, lds); if (e_ != hipSuccess) return e_;
+        hipLaunchKernelGGL(kcf_update_sparse_view_kernel<7>, dim3(grid), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+    }
+    else if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 4)), grid, lds, s, p, l, n);
     else KCF_LAUNCH3(kcf_update_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 4)), grid, lds, s, p, l, n);
     return hipGetLastError();
 }
@@ -2039,6 +2102,7 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l, int n, hipStr
 
 hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hipStream_t s)
 {
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
     if (p.use_lds) {
@@ -2050,6 +2114,7 @@ hipError_t launch_kcf_fhog_only(const KcfPool& p, const KcfLaunch& l, int n, hip
 
 hipError_t launch_kcf_crop_only(const KcfPool& p, const KcfLaunch& l, int n, float* patch_out, hipStream_t s)
 {
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
     if (p.use_lds) {

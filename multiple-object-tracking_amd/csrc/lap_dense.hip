@@ -185,6 +185,7 @@ hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s)
 {
     hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_dense_kernel), (int)sizeof(DenseShared)); if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lap_cost_rm_kernel, dim3(gR, gC), dim3(256), 0, s, a);
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     hipLaunchKernelGGL(lap_dense_kernel, dim3(1), dim3(MK_THREADS), sizeof(DenseShared), s, a);
     return launch_lap_verify_again(a, gR, gC, s);
 }

@@ -625,6 +625,7 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     const int early = mot_impl::env().feat_before_rowscan;
     if (ev_mid && early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (ev_mid && !early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     // box costs: solver + dual check + certificate (+ lifecycle) in one workgroup; caller matrices keep the dense dual check
     const int fuse = mot_impl::env().lap_fused;

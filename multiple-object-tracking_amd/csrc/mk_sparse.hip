@@ -99,6 +99,7 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, c
     // box costs: the after-the-fact check (and the lifecycle step) run inside the emulation's workgroup; caller matrices keep the dense pass
     const int fuse = mot_impl::env().lap_fused;
     const int post_fused = (fuse && !a.user) ? 1 : 0;
+    mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (batch & SP_TIMING) hipLaunchKernelGGL(mk_sparse_kernel<true>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
     else hipLaunchKernelGGL(mk_sparse_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
     if (!post_fused) hipLaunchKernelGGL(mk_postcheck_kernel, dim3(gR, gC), dim3(256), 0, s, a);

@@ -1,6 +1,7 @@
 // mot_ctx.h -- internal host-side types shared by mot_ctx.hip and mot_devloop.hip.
 #pragma once
 #include "mot_dev.h"
+#include "mot_env.h"
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -17,7 +18,14 @@ int fail(int code, const char* fmt, ...);
 
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { release(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
+    hipError_t alloc(size_t count)
+    {
+        release(); n = count;
+        if (!count) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess && poison_byte() >= 0) { e = hipMemset(p, poison_byte(), count * sizeof(T)); if (e == hipSuccess) e = hipDeviceSynchronize(); }   // (debug) MOT_POISON, mot_env.h
+        return e;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     ~DevBuf() { release(); }
 };
@@ -69,6 +77,8 @@ struct mot_ctx {
     // staging (capacity = max_tracks + max_dets)
     int stage_cap = 0;
     mot_impl::DevBuf<int> d_slots; mot_impl::DevBuf<bbox_t> d_boxes_a, d_boxes_b, d_dets; mot_impl::DevBuf<float> d_patches; size_t patches_cap = 0;
+    // device-side addresses of the pinned staging buffers (zero-copy path of small batches, run_batch); null when the mapping is not available
+    int* zc_slots = nullptr; bbox_t* zc_boxes_a = nullptr; bbox_t* zc_boxes_b = nullptr; float* zc_patches = nullptr;
     mot_impl::PinBuf<int> h_slots; mot_impl::PinBuf<bbox_t> h_boxes_a, h_boxes_b; mot_impl::PinBuf<int> h_assign; mot_impl::PinBuf<int> h_hint; mot_impl::PinBuf<double> h_cost; mot_impl::PinBuf<float> h_patches;
     // association
     AssocWs assoc{}; mot_impl::DevBuf<double> a_dist; mot_impl::DevBuf<unsigned long long> a_zr, a_zc, a_linemin; mot_impl::DevBuf<int> a_assign, a_status; mot_impl::DevBuf<double> a_cost;

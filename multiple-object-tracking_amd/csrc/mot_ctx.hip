@@ -274,41 +274,59 @@ int run_batch(mot_ctx* c, bool predict, const int* ids, int n, const float* cons
         if (boxes_in) c->h_boxes_a.p[q] = boxes_in[i];
         else if (kind == MOT_TRACKER_KALMAN && boxes_out) c->h_boxes_a.p[q] = boxes_out[i];   // in/out: predict writes l,t,r,b only
     }
-    HIPCHK(hipMemcpyAsync(c->d_slots.p, c->h_slots.p, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
-    if (boxes_in || kind == MOT_TRACKER_KALMAN)
-        HIPCHK(hipMemcpyAsync(c->d_boxes_a.p, c->h_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyHostToDevice, c->stream));
+    // Small batches (the per-object drop-in interface is a batch of ONE per call, kcf.cpp:455-476): ZERO-COPY -- the kernels read slots, boxes and
+    // patches straight from the pinned, device-mapped staging buffers over PCIe and write the predicted boxes straight back into pinned memory:
+    // one launch + one stream synchronisation per call instead of three copy packets around the launch (round-4 verdict item 8: 66-130 us per
+    // tracker_predict, box to box).  Large batches keep the staged copies (one DMA beats thousands of workgroups pulling 25 KB each).
+    size_t patch_floats = 0;
+    if (kind == MOT_TRACKER_KCF && patches) for (size_t gi = 0; gi + 1 < g.start.size(); gi++) patch_floats = std::max(patch_floats, (size_t)c->pools[g.pool[gi]]->dev.rows * c->pools[g.pool[gi]]->dev.cols);
+    const bool zc = n <= 8 && (size_t)n * patch_floats * sizeof(float) <= ((size_t)512 << 10) && c->zc_slots != nullptr;
+    const int* slots_dev = zc ? c->zc_slots : c->d_slots.p;
+    const bbox_t* boxes_a_dev = zc ? c->zc_boxes_a : c->d_boxes_a.p;
+    bbox_t* boxes_b_dev = zc ? c->zc_boxes_b : c->d_boxes_b.p;
+    if (!zc) {
+        HIPCHK(hipMemcpyAsync(c->d_slots.p, c->h_slots.p, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+        if (boxes_in || kind == MOT_TRACKER_KALMAN)
+            HIPCHK(hipMemcpyAsync(c->d_boxes_a.p, c->h_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyHostToDevice, c->stream));
+    }
     if (kind == MOT_TRACKER_KALMAN) {
         if (predict) {
-            HIPCHK(hipMemcpyAsync(c->d_boxes_b.p, c->d_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(launch_kalman_predict(c->kal, c->d_slots.p, nullptr, n, c->d_boxes_b.p, clamp, c->stream));
-        } else HIPCHK(launch_kalman_update(c->kal, c->d_slots.p, nullptr, n, c->d_boxes_a.p, c->stream));
+            if (zc) memcpy(c->h_boxes_b.p, c->h_boxes_a.p, sizeof(bbox_t) * n);
+            else HIPCHK(hipMemcpyAsync(c->d_boxes_b.p, c->d_boxes_a.p, sizeof(bbox_t) * n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(launch_kalman_predict(c->kal, slots_dev, nullptr, n, boxes_b_dev, clamp, c->stream));
+        } else HIPCHK(launch_kalman_update(c->kal, slots_dev, nullptr, n, boxes_a_dev, c->stream));
     } else {
         for (size_t gi = 0; gi + 1 < g.start.size(); gi++) {
             const int s = g.start[gi], cnt = g.start[gi + 1] - s;
             PoolHost& ph = *c->pools[g.pool[gi]];
             KcfLaunch l{};
-            l.slots = c->d_slots.p + s; l.count = nullptr; l.frame = patches ? nullptr : c->frame;
+            l.slots = slots_dev + s; l.count = nullptr; l.frame = patches ? nullptr : c->frame;
             if (patches) {
                 const size_t npx = (size_t)ph.dev.rows * ph.dev.cols;
                 if ((size_t)n * npx > c->patches_cap) {
                     HIPCHK(hipStreamSynchronize(c->stream));
                     c->patches_cap = (size_t)n * npx * 2;
                     HIPCHK(c->d_patches.alloc(c->patches_cap)); HIPCHK(c->h_patches.alloc(c->patches_cap));
+                    c->zc_patches = nullptr;
+                    if (hipHostGetDevicePointer((void**)&c->zc_patches, c->h_patches.p, 0) != hipSuccess) { (void)hipGetLastError(); c->zc_patches = nullptr; }
                 }
                 for (int q = 0; q < cnt; q++) memcpy(c->h_patches.p + (size_t)(s + q) * npx, patches[g.order[s + q]], npx * sizeof(float));
-                HIPCHK(hipMemcpyAsync(c->d_patches.p + (size_t)s * npx, c->h_patches.p + (size_t)s * npx, (size_t)cnt * npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
-                l.patches = c->d_patches.p + (size_t)s * npx;
+                if (zc && c->zc_patches) l.patches = c->zc_patches + (size_t)s * npx;
+                else {
+                    HIPCHK(hipMemcpyAsync(c->d_patches.p + (size_t)s * npx, c->h_patches.p + (size_t)s * npx, (size_t)cnt * npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
+                    l.patches = c->d_patches.p + (size_t)s * npx;
+                }
             }
-            l.boxes_in = boxes_in ? c->d_boxes_a.p + s : nullptr;
-            l.boxes_out = predict ? c->d_boxes_b.p + s : nullptr;
+            l.boxes_in = boxes_in ? boxes_a_dev + s : nullptr;
+            l.boxes_out = predict ? boxes_b_dev + s : nullptr;
             l.clamp = clamp;
             if (predict) HIPCHK(launch_kcf_predict(ph.dev, l, cnt, c->stream));
             else HIPCHK(launch_kcf_update(ph.dev, l, cnt, c->stream));
         }
     }
     if (predict && boxes_out) {
-        HIPCHK(hipMemcpyAsync(c->h_boxes_b.p, c->d_boxes_b.p, sizeof(bbox_t) * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!zc) HIPCHK(hipMemcpyAsync(c->h_boxes_b.p, c->d_boxes_b.p, sizeof(bbox_t) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));                       // zero-copy: the kernel wrote the pinned buffer itself; its end-of-kernel release + this wait make it visible
         for (int q = 0; q < n; q++) boxes_out[g.order[q]] = c->h_boxes_b.p[q];
     } else HIPCHK(hipStreamSynchronize(c->stream));   // caller buffers (patches / boxes) may be reused after return
     return MOT_OK;
@@ -389,6 +407,9 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     const int sc = c->stage_cap;
     HIPCHK(c->d_slots.alloc(sc)); HIPCHK(c->d_boxes_a.alloc(sc)); HIPCHK(c->d_boxes_b.alloc(sc)); HIPCHK(c->d_dets.alloc(sc));
     HIPCHK(c->h_slots.alloc(sc)); HIPCHK(c->h_boxes_a.alloc(sc)); HIPCHK(c->h_boxes_b.alloc(sc)); HIPCHK(c->h_assign.alloc(1024 + 1)); /* + the Munkres status word */ HIPCHK(c->h_cost.alloc(1));
+    // zero-copy path of small batches: the device's view of the three pinned staging buffers (all or nothing)
+    if (hipHostGetDevicePointer((void**)&c->zc_slots, c->h_slots.p, 0) != hipSuccess || hipHostGetDevicePointer((void**)&c->zc_boxes_a, c->h_boxes_a.p, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->zc_boxes_b, c->h_boxes_b.p, 0) != hipSuccess) { (void)hipGetLastError(); c->zc_slots = nullptr; c->zc_boxes_a = nullptr; c->zc_boxes_b = nullptr; }
     if (cfg->tracker_kind == MOT_TRACKER_KALMAN) {
         HIPCHK(c->kal_x.alloc((size_t)cfg->max_tracks * 6)); HIPCHK(c->kal_P.alloc((size_t)cfg->max_tracks * 36));
         c->kal.x = c->kal_x.p; c->kal.P = c->kal_P.p;
@@ -396,7 +417,7 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     }
     const size_t n2 = (size_t)1024 * 1024;
     const size_t mr = std::max(cfg->max_tracks, cfg->max_dets);
-    const size_t mat = std::min(n2, mr * mr);
+    const size_t mat = std::max(std::min(n2, mr * mr), (size_t)8192);   // >= 8192 words: the sparse emulation's time-stamp trace (MOT_MK_TIMING, <= 8190 entries) lives in it
     HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024)); HIPCHK(hipMemset(c->a_linemin.p, 0xFF, 1024 * sizeof(unsigned long long)));
     HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(hipMemset(c->a_status.p, 0, 16 * sizeof(int))); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
@@ -810,7 +831,10 @@ int mot_debug_assoc_trace(mot_ctx* c, long long* out, int n)
 {
     if (!c || !out || n <= 0) return fail(MOT_ERR_ARG, "bad argument");
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->assoc.dist, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+    const size_t have = c->a_dist.n;                                   // never read beyond the working matrix (round-4 advisor finding); the rest of `out` is zeroed
+    const size_t take = std::min((size_t)n, have);
+    if (take < (size_t)n) memset(out + take, 0, sizeof(long long) * ((size_t)n - take));
+    if (take) HIPCHK(hipMemcpy(out, c->assoc.dist, sizeof(long long) * take, hipMemcpyDeviceToHost));
     return MOT_OK;
 }
 

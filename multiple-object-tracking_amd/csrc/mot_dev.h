@@ -100,6 +100,7 @@ struct KcfLaunch {
     unsigned lds_bytes;       // dynamic LDS of the launch = the largest need of any class
     int r1_any;               // some class runs the R1-resident pipeline (KcfPool::r1_lds): the launch takes the kernels built with it
     int gen_any;              // some LDS-resident class is not 20 x 20 cells: the launch takes the kernels with the direct transforms compiled in
+    int ablate;               // (probe build, MOT_KCF_ABLATE) mask of phases to skip -- timing tools only, see kcf_kernels.hip
 };
 
 struct KalmanPool {

@@ -81,6 +81,7 @@ struct DevLoop {
     int buf_prev = 0, buf_cur = 1; hipEvent_t ev_spec[3]{}; bool spec_side[3] = {false, false, false}; bool have_cur = false;
     const void* pf_frame = nullptr; const void* pf_dets = nullptr; int pf_nD = -1, pf_buf = -1; bool pf_valid = false;
     const void* next_frame = nullptr; const void* next_dets = nullptr; int next_nD = 0;
+    const void* begin_dets = nullptr; int begin_nD = -1;             // the list dl_begin computed / adopted this frame's detection features for
     hipStream_t side = nullptr; hipEvent_t ev_mid = nullptr, ev_in = nullptr; bool split = false;
     // mot_step_frame_host: copy stream + two device buffers (frame, detections); up[b]: upload of buffer b done, done[b]: the frame that read it finished
     // host-fed loop (mot_step_frame_host): three device buffers for frame + boxes, an upload event per buffer, and a ring of the chain events of the last
@@ -93,6 +94,7 @@ struct DevLoop {
     // (debug) in-loop timing of the predict launch: pairs of events that receive the kernel's own begin / end stamps while the normal
     // step calls run (look-ahead, side stream and all) -- what rocprofv3 reports for the launch in the timed configuration
     std::vector<hipEvent_t> pt; int pt_used = 0;
+    bool prof_two_call = false;   // (debug) mot_debug_profile_stages: the two-call / sharded step records its stage events (ev[0..5])
 };
 
 void devloop_destroy(DevLoop* d)
@@ -231,6 +233,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     if (S.kind == MOT_TRACKER_KCF && !frame_dev) return fail(MOT_ERR_ARG, "null frame");
     d->frame = frame_dev;
     d->frame_no++;
+    d->begin_dets = dets_dev; d->begin_nD = nD;
     // this frame's spectra buffer: the one a look-ahead launch of the previous call filled for exactly this frame and detection list,
     // else a free one (then the features are computed within the frame, as before)
     d->have_cur = d->split && d->pf_valid && d->pf_frame == frame_dev && d->pf_dets == dets_dev && d->pf_nD == nD && dets_dev;
@@ -299,7 +302,9 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
 // release_inputs: the context stream waits, at the end of the frame, for the side-stream feature launch that read THIS frame's image and
 // detection list -- so a caller may overwrite both in stream order behind the call (round-3 advisor finding: with the deferred blend only
 // the next frame's predict waited for that launch).  The next predict needed that wait anyway (its blend prologue reads the spectra), so
-// the wait moves, it is not added.  mot_step_frame_host guards its own two buffers and passes false.
+// the wait moves, it is not added.  mot_step_frame_host passes true as well: the reuse of its three buffers is ordered behind chain events
+// (ev_ring), and the chain event of frame f - 2 lies behind this wait of frame f - 3 in stream order -- with release_inputs == false a frame whose
+// features were computed inside the frame (side stream) could still be read when its buffer is uploaded again.
 int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev, int nD, hipEvent_t* ev, bool release_inputs = true)
 {
     RoctxRange range_("mot.frame.assoc_update");
@@ -307,6 +312,10 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     if (!d->begun) return fail(MOT_ERR_STATE, "mot_step_finish_device without mot_step_begin_device");
     d->begun = false;
     if (nD < 0 || nD > S.max_dets || (nD && !dets_dev)) return fail(MOT_ERR_ARG, "bad detection list (%d, max %d)", nD, S.max_dets);
+    // the two-call form: the spectra of this frame were computed (or adopted from a look-ahead launch) for the list given to the begin call -- the
+    // list associated here must be that one (round-4 advisor finding: a different list silently got the other list's spectra)
+    if ((d->feat_early || d->have_cur) && (dets_dev != d->begin_dets || nD != d->begin_nD))
+        return fail(MOT_ERR_ARG, "mot_step_finish_device: detection list (%p, %d) differs from the one given to the begin call (%p, %d)", dets_dev, nD, d->begin_dets, d->begin_nD);
     const bbox_t* g = gathered ? (const bbox_t*)gathered : S.gather;
     const bbox_t* trk = g;
     if (S.world > 1) { hipLaunchKernelGGL(dl_scatter_kernel, dim3(1), dim3(1024), 0, c->stream, S, g); HIPCHK(hipGetLastError()); trk = S.pred; }
@@ -391,7 +400,7 @@ int mot_step_begin_device(mot_ctx* c, const void* frame_dev, void** local_boxes_
     if (!c) return fail(MOT_ERR_ARG, "null ctx");
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
-    rc = dl_begin(c, d, frame_dev, nullptr); if (rc) return rc;
+    rc = dl_begin(c, d, frame_dev, d->prof_two_call ? d->ev : nullptr); if (rc) return rc;
     if (local_boxes_dev) *local_boxes_dev = d->S.gather + (size_t)d->S.rank * d->S.spr;
     if (slots_per_rank) *slots_per_rank = d->S.spr;
     return MOT_OK;
@@ -406,7 +415,7 @@ int mot_step_begin_device_ahead(mot_ctx* c, const void* frame_dev, const void* d
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
     if (mot_impl::env().lookahead) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
-    rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
+    rc = dl_begin(c, d, frame_dev, d->prof_two_call ? d->ev : nullptr, dets_dev, nD); if (rc) return rc;
     if (local_boxes_dev) *local_boxes_dev = d->S.gather + (size_t)d->S.rank * d->S.spr;
     if (slots_per_rank) *slots_per_rank = d->S.spr;
     return MOT_OK;
@@ -416,7 +425,9 @@ int mot_step_finish_device(mot_ctx* c, const void* gathered_boxes_dev, const voi
 {
     if (!c || !c->devloop) return fail(MOT_ERR_STATE, "mot_step_finish_device without mot_step_begin_device");
     int rc = ensure_device(c); if (rc) return rc;
-    return dl_finish(c, c->devloop, gathered_boxes_dev, dets_dev, nD, nullptr);
+    DevLoop* d = c->devloop;
+    if (d->prof_two_call) HIPCHK(hipEventRecord(d->ev[5], c->stream));   // the caller's all-gather lies between ev[1] and this
+    return dl_finish(c, d, gathered_boxes_dev, dets_dev, nD, d->prof_two_call ? d->ev : nullptr);
 }
 
 int mot_step_frame_device(mot_ctx* c, const void* frame_dev, const void* dets_dev, int nD)
@@ -463,7 +474,7 @@ int mot_step_frame_sharded_ahead(mot_ctx* c, const void* frame_dev, const void* 
     if (!all_gather) return fail(MOT_ERR_DEVICE, "librccl.so.1 / ncclAllGather not available: %s", rb.why.c_str());
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
     if (mot_impl::env().lookahead && next_frame_dev) { d->next_frame = next_frame_dev; d->next_dets = next_dets_dev; d->next_nD = next_nD; }
-    rc = dl_begin(c, d, frame_dev, nullptr, dets_dev, nD); if (rc) return rc;
+    rc = dl_begin(c, d, frame_dev, d->prof_two_call ? d->ev : nullptr, dets_dev, nD); if (rc) return rc;
     // the frame's single collective: every rank's segment of predicted boxes, in place (send = recv + rank * count), on the SAME stream
     // as the kernels on both sides of it -- stream order is the only synchronisation
     const DLState& S = d->S;
@@ -471,7 +482,8 @@ int mot_step_frame_sharded_ahead(mot_ctx* c, const void* frame_dev, const void* 
     const int ncclChar = 0;
     const int nr = all_gather(reinterpret_cast<const char*>(S.gather) + (size_t)S.rank * count, S.gather, count, ncclChar, nccl_comm, c->stream);
     if (nr != 0) { d->begun = false; return fail(MOT_ERR_DEVICE, "ncclAllGather failed (ncclResult_t %d)", nr); }
-    return dl_finish(c, d, nullptr, dets_dev, nD, nullptr);
+    if (d->prof_two_call) HIPCHK(hipEventRecord(d->ev[5], c->stream));
+    return dl_finish(c, d, nullptr, dets_dev, nD, d->prof_two_call ? d->ev : nullptr);
 }
 
 int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_dets, int nD)
@@ -514,8 +526,9 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         else (void)hipGetLastError();                                  // pageable / unregistered memory: the runtime's staged copy below
     }
     const bool lookahead = h2d_mode != 1 && d->split && d->S.kind == MOT_TRACKER_KCF && d->S.ncls <= 1 && mot_impl::env().lookahead;
-    // without the look-ahead launches (Kalman, size classes, switched off) a frame's own feature launch may still read its buffer when the chain event
-    // of the next frame is recorded: those configurations order the upload behind the END of frame f - 3 instead (its last event on the side stream too)
+    // Every configuration orders the upload of frame f behind ev_ring[(f - 2) % 3], the chain event of frame f - 2.  That event is recorded behind
+    // predict(f - 2), which in stream order lies behind dl_finish(f - 3)'s release_inputs wait for the side-stream launch that read buffer (f - 3) % 3 --
+    // so the buffer is free also when a frame's features were computed inside the frame (Kalman, size classes, look-ahead switched off).
     if (h2d_mode == 1) {
         HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, c->stream));
         if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
@@ -607,6 +620,28 @@ int mot_profile_frame_device(mot_ctx* c, const void* frame_dev, const void* dets
     return MOT_OK;
 }
 
+// (debug / bench) stage times of the two-call and the sharded step on THIS rank: enable, step a frame, read.  Events on the context's stream:
+// [0] predict launch (the kernel's own begin / end stamps)  [1] end of the predict -> start of the finish call: the all-gather (caller's or RCCL)
+// [2] association chain incl. scatter and lifecycle  [3] residual update launch.  Reading synchronises the context's stream.
+int mot_debug_profile_stages(mot_ctx* c, int enable, float* stage_ms4)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    int rc = ensure_device(c); if (rc) return rc;
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    if (!d->ev_ok) { for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i])); d->ev_ok = true; }
+    if (stage_ms4 && d->prof_two_call) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        float ms;
+        if (hipEventElapsedTime(&ms, d->ev[0], d->ev[1]) != hipSuccess) { (void)hipGetLastError(); return fail(MOT_ERR_STATE, "no profiled frame yet"); }
+        stage_ms4[0] = ms;
+        HIPCHK(hipEventElapsedTime(&ms, d->ev[1], d->ev[5])); stage_ms4[1] = ms;
+        HIPCHK(hipEventElapsedTime(&ms, d->ev[5], d->ev[2])); stage_ms4[2] = ms;
+        HIPCHK(hipEventElapsedTime(&ms, d->ev[3], d->ev[4])); stage_ms4[3] = ms;
+    }
+    d->prof_two_call = enable != 0;
+    return MOT_OK;
+}
+
 int mot_live_count(mot_ctx* c, int* n_live)
 {
     if (!c || !n_live) return fail(MOT_ERR_ARG, "null argument");
@@ -641,6 +676,59 @@ int mot_live_response(mot_ctx* c, int live_index, float* out, int* f_rows, int* 
     HIPCHK(hipMemcpy(&slot, S.slot + live_index, sizeof(int), hipMemcpyDeviceToHost));
     if (slot < 0) return fail(MOT_ERR_ARG, "live track %d is owned by another rank", live_index);
     HIPCHK(hipMemcpy(out, p.response + (size_t)slot * p.nb, sizeof(float) * p.nb, hipMemcpyDeviceToHost));
+    return MOT_OK;
+}
+
+int mot_live_model(mot_ctx* c, int live_index, float* xm_out, float* alpha_out, bbox_t* pos, float* scale2, int* first_update, int* pending_det)
+{
+    if (!c || !c->devloop) return fail(MOT_ERR_STATE, "mot_live_model needs the device-resident loop");
+    const DLState& S = c->devloop->S;
+    if (S.kind != MOT_TRACKER_KCF || S.ncls > 1) return fail(MOT_ERR_STATE, "mot_live_model: single-template KCF loop only");
+    const KcfPool& p = c->pools[c->devloop->pool]->dev;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = devloop_check(c); if (rc) return rc;                      // drains the side stream too
+    int n = 0, slot = -1;
+    HIPCHK(hipMemcpy(&n, S.nlive, sizeof(int), hipMemcpyDeviceToHost));
+    if (live_index < 0 || live_index >= n) return fail(MOT_ERR_ARG, "live index %d out of range (%d live tracks)", live_index, n);
+    HIPCHK(hipMemcpy(&slot, S.slot + live_index, sizeof(int), hipMemcpyDeviceToHost));
+    if (slot < 0) return fail(MOT_ERR_ARG, "live track %d is owned by another rank", live_index);
+    if (xm_out) HIPCHK(hipMemcpy(xm_out, p.xm + (size_t)slot * MOT_NCHAN * p.nbins, sizeof(float2) * MOT_NCHAN * p.nbins, hipMemcpyDeviceToHost));
+    if (alpha_out) HIPCHK(hipMemcpy(alpha_out, p.alpha + (size_t)slot * p.nbins, sizeof(float) * p.nbins, hipMemcpyDeviceToHost));
+    if (pos) HIPCHK(hipMemcpy(pos, p.pos + slot, sizeof(bbox_t), hipMemcpyDeviceToHost));
+    if (scale2) HIPCHK(hipMemcpy(scale2, p.scale + slot, sizeof(float2), hipMemcpyDeviceToHost));
+    if (first_update) HIPCHK(hipMemcpy(first_update, p.first_update + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (pending_det) { *pending_det = -1; if (S.defer && S.pend_det) HIPCHK(hipMemcpy(pending_det, S.pend_det + slot, sizeof(int), hipMemcpyDeviceToHost)); }
+    return MOT_OK;
+}
+
+// (debug) stream-ordered snapshot of the device loop's small state into caller-owned DEVICE memory -- no host synchronisation, so a soak can
+// record every frame of a run that must not be synchronised and read the records back only when the run went wrong (tools/lookahead_soak.py).
+// Layout (4-byte words, cap = max_tracks): [0] nlive [1] upd_count [2] loc_count [3] frame_no | tid[cap] | live bbox[cap] (6 words each) |
+// predicted boxes of this frame in item order [cap] (6 words each) | slot[cap] | KCF pos by SLOT [cap] (6 words each) | pend_det by slot [cap] |
+// first_update by slot [cap] | upd_slots[64] | upd_det[64] | lap header [64].  Returns the number of bytes through *bytes (dst may be null).
+int mot_debug_snapshot(mot_ctx* c, void* dst_dev, size_t* bytes)
+{
+    if (!c || !c->devloop) return fail(MOT_ERR_STATE, "mot_debug_snapshot needs the device-resident loop");
+    DevLoop* d = c->devloop; const DLState& S = d->S;
+    const size_t cap = (size_t)S.cap;
+    const size_t total = 4 * (4 + cap + 6 * cap + 6 * cap + cap + 6 * cap + cap + cap + 64 + 64 + 64);
+    if (bytes) *bytes = total;
+    if (!dst_dev) return MOT_OK;
+    int rc = ensure_device(c); if (rc) return rc;
+    char* q = (char*)dst_dev;
+    auto put = [&](const void* src, size_t n) -> hipError_t { hipError_t e = src ? hipMemcpyAsync(q, src, n, hipMemcpyDeviceToDevice, c->stream) : hipMemsetAsync(q, 0xFF, n, c->stream); q += n; return e; };
+    HIPCHK(put(S.nlive, 4)); HIPCHK(put(S.upd_count, 4)); HIPCHK(put(S.loc_count, 4));
+    { const unsigned fno = d->frame_no; HIPCHK(hipMemsetAsync(q, 0, 4, c->stream)); (void)fno; q += 4; }
+    HIPCHK(put(S.tid, 4 * cap)); HIPCHK(put(S.bbox, 24 * cap));
+    HIPCHK(put(S.gather + (size_t)S.rank * S.spr, 24 * cap));
+    HIPCHK(put(S.slot, 4 * cap));
+    const bool kcf1 = S.kind == MOT_TRACKER_KCF && S.ncls <= 1;
+    const KcfPool* kp = kcf1 ? &c->pools[d->pool]->dev : nullptr;
+    HIPCHK(put(kp ? (const void*)kp->pos : nullptr, 24 * cap));
+    HIPCHK(put((kp && S.defer) ? (const void*)S.pend_det : nullptr, 4 * cap));
+    HIPCHK(put(kp ? (const void*)kp->first_update : nullptr, 4 * cap));
+    HIPCHK(put(S.upd_slots, 4 * 64)); HIPCHK(put(S.upd_det, 4 * 64));
+    HIPCHK(put(c->assoc.lap.hdr, 4 * 64));
     return MOT_OK;
 }
 

@@ -64,6 +64,23 @@ inline const EnvSwitches& env()
     return e;
 }
 
+// ---- (debug) poisoning: turns reads of memory nobody wrote into deterministic failures --------------------------------------------
+// MOT_POISON=<byte>      every device allocation of the library is filled with this byte (hipMalloc hands out recycled pages in a long-lived
+//                        process and zero pages in a fresh one: a read-before-write shows up as a flake that depends on the process' history)
+// MOT_LDS_POISON=<word>  a scribble kernel overwrites the LDS of every compute unit with this word in front of every kernel launch of the
+//                        library (LDS keeps the previous workgroup's contents)
+inline int poison_byte()
+{
+    static const int v = [] { const char* e = getenv("MOT_POISON"); return e ? (int)(strtol(e, nullptr, 0) & 0xFF) : -1; }();
+    return v;
+}
+hipError_t lds_poison_launch(hipStream_t s, unsigned word);            // helper_kernels.hip
+inline void lds_poison(hipStream_t s)
+{
+    static const long long v = [] { const char* e = getenv("MOT_LDS_POISON"); return e ? (long long)(strtoul(e, nullptr, 0) & 0xFFFFFFFFul) | (1ll << 40) : 0ll; }();
+    if (v) (void)lds_poison_launch(s, (unsigned)(v & 0xFFFFFFFFll));
+}
+
 // hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes) once per (device, kernel); safe from several threads / devices
 inline hipError_t func_lds_once(const void* fn, int bytes)
 {

@@ -467,3 +467,39 @@ def test_size_class_after_single_pool_use(mot, oracle):
         assert np.array_equal(tids, ref["tids"]), f"frame {f} tids"
         assert np.array_equal(bnp(boxes), bnp(ref["live"])), f"frame {f} live boxes"
     m.close(); c.close()
+
+
+def _state_hashes(env_extra, args):
+    import subprocess, sys
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "state_dump.py")] + [str(a) for a in args],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    return [ln for ln in out.stdout.splitlines() if ln.startswith("frame ")]
+
+
+@pytest.mark.parametrize("args", [(48, 128, 8, 4, 9, 21), (30, 32, 30, 0, 8, 33), (300, 1024, 6, 4, 6, 7, "--ahead")])
+def test_folded_geometry_kernels_bit_equal_general_kernels(args):
+    """Round-4 advisor finding: the 80 x 80 px kernels with the template geometry folded in as constants (kMode 7: predict, feature, direct update
+    and -- MOT_KCF_K80 bit 3 -- the out-of-line sparse update body, where round 4 once saw a residual update two cells off) must leave the SAME
+    BITS in device memory as the general kernels: model, alpha, pos, scale, flags and response map of every live track, after every frame of
+    noisy streams (tracks that keep their predicted box every frame; the second case has more of them than the residual-update grid has
+    workgroups, so its multi-item loop runs).  One process per variant (the switch is read once)."""
+    general = _state_hashes({"MOT_KCF_K80": "0"}, args)
+    assert len(general) == args[4]
+    for k80 in ("7", "15", "3"):
+        assert _state_hashes({"MOT_KCF_K80": k80}, args) == general, f"MOT_KCF_K80={k80} differs from the general kernels"
+
+
+def test_finish_refuses_a_different_detection_list(mot):
+    """two-call form: the detection spectra belong to the list given to mot_step_begin_device_ahead (round-4 advisor finding)"""
+    from multiple_object_tracking_amd import synth
+    scene = synth.Scene(24, 80, stream_id=3)
+    items = list(scene.frames(3))
+    fd, dd, da = _dev([f for f, _ in items], [d for _, d in items], mot)
+    c = mot.MotContext(max_tracks=64, max_dets=64)
+    n0 = len(items[0][1])
+    c.step_begin_device_ahead(fd[0].data_ptr(), dd[0].data_ptr(), n0, 0, 0, 0)
+    with pytest.raises(mot.MotError):
+        c.step_finish_device(0, dd[1].data_ptr(), n0)                   # another list than the begin call's
+    c.close()

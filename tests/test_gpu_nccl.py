@@ -89,6 +89,28 @@ def test_bench_sharded_branch_two_ranks_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "strong" and j["config"]["live_tracks_end"] == 96
     assert j["smoke_backend"].startswith("gloo") and j["value"] > 0
+    # every rank's stage times are in the line (round-4 verdict item 7a): predict / all-gather / chain / residual update, all positive
+    rows = j["per_rank_stage_ms"]["ranks"]
+    assert [r["rank"] for r in rows] == [0, 1]
+    assert all(r[k] > 0 for r in rows for k in ("predict_ms", "gather_ms", "chain_ms")) and all(r["update_ms"] >= 0 for r in rows)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_one_gpu():
+    """BASELINE configs[3]'s shape -- 1024 tracks sharded 128 per rank over EIGHT ranks -- through bench.py's own launcher on one GPU
+    (gloo-staged all-gather: RCCL refuses several ranks on one device).  Smoke test of the 8-process path the driver's SCALE run takes:
+    rendezvous, shard ownership tid % 8, replicated association on eight contexts, one JSON line with eight per-rank rows."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MOT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "2", "--steady", "0", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["tracks_per_gpu"] == 128 and j["config"]["live_tracks_end"] == 1024 and j["value"] > 0
+    assert [r["rank"] for r in j["per_rank_stage_ms"]["ranks"]] == list(range(8))
 
 
 @pytest.mark.gpu

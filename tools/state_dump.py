@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Prints one sha256 per frame over the complete device state of every live track of the device-resident loop (model, alpha, pos, scale, flags,
+response map; boxes, ids) for a seeded noisy stream -- two builds / kernel variants / runs are equal iff their outputs are (GPU box).
+usage: state_dump.py N CAP MISS FP FRAMES [STREAM_ID] [--ahead]"""
+import hashlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import mot_amd
+from multiple_object_tracking_amd import synth
+
+n, cap, miss, fp, nframes = (int(x) for x in sys.argv[1:6])
+sid = int(sys.argv[6]) if len(sys.argv) > 6 and not sys.argv[6].startswith("-") else 21
+ahead = "--ahead" in sys.argv
+scene = synth.Scene(n, 80, stream_id=sid, miss_pct=miss, fp_pct=fp)
+items = list(scene.frames(nframes))
+frames = [f for f, _ in items]; dets = [d[:cap] for _, d in items]
+fd = torch.from_numpy(np.stack(frames)).cuda()
+nmax = max(len(d) for d in dets)
+da = np.zeros((nframes, max(nmax, 1)), mot_amd.BBOX_DTYPE)
+for i, d in enumerate(dets):
+    da[i, :len(d)] = mot_amd.boxes_array(d)
+dd = torch.from_numpy(da.view(np.uint8).reshape(nframes, -1)).cuda()
+c = mot_amd.MotContext(max_tracks=cap, max_dets=cap)
+for f in range(nframes):
+    if ahead and f + 1 < nframes:
+        c.step_frame_device_ahead(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]), fd[f + 1].data_ptr(), dd[f + 1].data_ptr(), len(dets[f + 1]))
+    else:
+        c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+    boxes, tids, ages = c.live_tracks()
+    h = hashlib.sha256()
+    h.update(boxes.tobytes()); h.update(tids.tobytes()); h.update(ages.tobytes())
+    for i in range(len(tids)):
+        xm, al, pos, sc, first, pend = c.live_model(i)
+        for part in (xm, al, pos, sc, c.live_response(i)):
+            h.update(np.ascontiguousarray(part).tobytes())
+        h.update(bytes([first & 255, pend & 255, (pend >> 8) & 255]))
+    upd = int(c.assoc_stats()[0]) if False else 0
+    print(f"frame {f} live {len(tids)} {h.hexdigest()}")
+c.close()
