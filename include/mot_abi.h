@@ -273,6 +273,10 @@ int mot_live_model(mot_ctx* ctx, int live_index, float* xm_out, float* alpha_out
  * pos / pending detection / first-update flag by slot, head of the residual-update list, association header -- into caller-owned device memory;
  * *bytes receives the record size (dst_dev may be null to ask for it).  Layout: csrc/mot_devloop.hip.  For soak tools. */
 int mot_debug_snapshot(mot_ctx* ctx, void* dst_dev, size_t* bytes);
+/* debug (MOT_TRACE=1 in the environment when the context is created): the per-workgroup records the predict / residual-update launches of the last 16
+ * frames left behind -- 8 ints each, [kind 0 predict | 1 update][frame & 15][slot]; layout: csrc/mot_dev.h, KcfLaunch::trace.  *n_ints receives the
+ * size (0: tracing off).  One 32-byte store per workgroup: light enough to leave a timing-dependent failure alive (tools/lookahead_soak.py --trace). */
+int mot_debug_trace_read(mot_ctx* ctx, int* out, size_t cap_ints, size_t* n_ints);
 /* debug / bench: stage times of the two-call (mot_step_begin_device[_ahead] + mot_step_finish_device) and of the sharded step on this rank.
  * enable, step ONE frame, then call again with stage_ms4 to read [0] predict launch [1] all-gather (end of the predict -> finish call)
  * [2] association chain (scatter, row scan, solver / emulation, lifecycle) [3] residual update launch, in ms (HIP events on the context's

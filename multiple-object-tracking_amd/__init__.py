@@ -366,6 +366,16 @@ class MotContext:
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
         return out
 
+    def debug_trace(self):
+        """(MOT_TRACE=1) int32 [2][16][max_tracks][8]: predict / update records of the last 16 frames by (frame & 15, slot); None when tracing is off"""
+        n = C.c_size_t(0)
+        self._chk(self.lib.mot_debug_trace_read(self._h, None, C.c_size_t(0), C.byref(n)))
+        if n.value == 0:
+            return None
+        out = np.zeros(n.value, np.int32)
+        self._chk(self.lib.mot_debug_trace_read(self._h, _vp(out), C.c_size_t(n.value), None))
+        return out.reshape(2, 16, -1, 8)
+
     def debug_snapshot_bytes(self) -> int:
         n = C.c_size_t(0)
         self._chk(self.lib.mot_debug_snapshot(self._h, None, C.byref(n)))

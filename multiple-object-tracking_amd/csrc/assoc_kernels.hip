@@ -1093,8 +1093,8 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             }
             // Box costs without the dense solver in between: the sparse emulation rides in the solver's launch as its second workgroup
             // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
-            const int two_block_on = E.two_block, mk_batch_on = E.mk_batch, fuse_on = E.lap_fused;   // MOT_LAP_TWO_BLOCK / MOT_MK_BATCH, MOT_MK_LAZY, MOT_MK_TIMING / MOT_LAP_FUSED
-            const bool two_block = two_block_on && fuse_on && !a.user && !want_dense;
+            const int two_block_on = E.two_block, mk_batch_on = E.mk_batch;   // MOT_LAP_TWO_BLOCK / MOT_MK_BATCH, MOT_MK_LAZY, MOT_MK_TIMING
+            const bool two_block = two_block_on && !a.user && !want_dense;
             e = launch_lap_front(a, gR, gC, s, ev_mid, life, two_block, mk_batch_on); if (e != hipSuccess) return e;
             ev_mid = nullptr;
             if (want_dense) { e = launch_lap_dense(a, gR, gC, s); if (e != hipSuccess) return e; }

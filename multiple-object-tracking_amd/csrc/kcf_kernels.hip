@@ -21,6 +21,12 @@
 #include <type_traits>
 #include "bin_thresholds.inc"
 
+#ifndef MOT_HIST_BATCH
+#define MOT_HIST_BATCH 0      /* 1: the histogram's eight read-modify-writes of a footprint column resolved in registers (round 5 A/B; see phase_hist) */
+#endif
+#ifndef MOT_GRAD_SPEC
+#define MOT_GRAD_SPEC 1       /* 1: gradient loop instantiated per FHOG flavour (round 5 A/B; see phase_gradmag) */
+#endif
 #define PI_F 3.14159265f /* libhog/gradientMex.cpp:12 */
 // (probe build only, `make ablate` -> libmot_amd_ablate.so) phases of the KCF kernels can be switched off one by one (KcfLaunch::ablate, from
 // MOT_KCF_ABLATE): the launch time lost is what the phase costs the LAUNCH under real contention -- results are garbage, timing tools only
@@ -278,6 +284,12 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
         *reinterpret_cast<uint16_t*>(bo) = (uint16_t)(bq[0] | (bq[1] << 8));
         *reinterpret_cast<uint16_t*>(bo + 2) = (uint16_t)(bq[2] | (bq[3] << 8));
     };
+#if !MOT_GRAD_SPEC
+    {   // (A/B) one loop, the flavour tested per pixel as before round 5
+        auto group_rt = [&](int it) { if (approx_rt) group(it, std::true_type{}); else group(it, std::false_type{}); };
+        for (int it = tid; it < xn * ng; it += nt) group_rt(it);
+    }
+#else
     if (approx_rt) {
         if (UNR > 1) {
 #pragma unroll UNR
@@ -288,6 +300,7 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
     } else {
         for (int it = tid; it < xn * ng; it += nt) group(it, std::false_type{});
     }
+#endif
     // the two pad slots above and below every column are read (with weight 0) by the histogram: finite magnitude, bin 0
     for (int i = tid; i < 4 * xn; i += nt) {
         const int x = xb + (i >> 2), k = i & 3, idx = x * LP + (k < 2 ? k : LP - 4 + k);
@@ -359,6 +372,13 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 // wave's accesses in order, so the last store of an orientation is the one that stays, and the next column's reads see it).
                 // (ds_add_f32 -- one LDS float add per pixel, no return value, bit-identical sums -- was measured in round 3: the predict
                 // launch went from 100 to 215 us; the LDS atomic path is that slow.)
+#if !MOT_HIST_BATCH
+#pragma unroll
+                for (int j = 0; j < 8; j++) {                            // sequential form: one dependent LDS round trip per pixel, fewest instructions
+                    const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
+                    Rc[bj * 64] += (wx * wy[j]) * mv[j];
+                }
+#else
                 int ad[8]; float wv[8], rv[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -376,6 +396,7 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) Rc[ad[j]] = rv[j];
+#endif
             }
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
@@ -1455,6 +1476,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
     float2 xmr[MOT_HALF0]; float alr = 0.f;                            // 16 planes at a time (register budget for 2 workgroups / CU)
     bool have_model = false;
     const int dj = l.pend_det ? l.pend_det[slot] : -1;
+    int first_seen = -1;                                               // (MOT_TRACE) the first_update flag the blend read
     // Workgroups i and i + 256 of a launch share a compute unit (dispatch order on the 8 x 32 CUs): the second of the pair does its
     // blend AFTER the feature phases, so the model streaming of one overlaps the arithmetic of the other instead of all 512 resident
     // workgroups hitting HBM in the launch's first microseconds
@@ -1464,6 +1486,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
         const float2* dspec = l.pend_spec + (size_t)dj * tot;
         float2* xmw = p.xm + (size_t)slot * tot;
         const int first = p.first_update[slot];
+        first_seen = first;
         const float factor = first ? 1.0f : p.eta, keep = 1.0f - factor;       // kcf.cpp:443
         int i_lo = 0;                                               // first element the streaming blend below still has to do
         if (pre) {
@@ -1626,6 +1649,11 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
             o.t = min(max(o.t, 0), MOT_FRAME_H - 1); o.b = min(max(o.b, 0), MOT_FRAME_H - 1);
         }
         if (l.boxes_out) l.boxes_out[item] = o;
+        if (l.trace) {                                                 // (debug, MOT_TRACE) what this workgroup saw and decided
+            int* tr = l.trace + ((size_t)(l.trace_frame & 15) * l.trace_cap + slot) * 8;
+            tr[0] = l.trace_frame; tr[1] = pos.l; tr[2] = pos.t; tr[3] = (best & 0xFFFF) | (item << 16); tr[4] = best >= 0 ? __float_as_int(r.resp[best]) : 0;
+            tr[5] = dj; tr[6] = first_seen; tr[7] = (np.l & 0xFFFF) | (np.t << 16);
+        }
         if (l.dbg && item < 4096) {
             unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));   // cu / se / xcc of this workgroup
             unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1758,6 +1786,10 @@ __device__ __forceinline__ void kcf_update_body(const KcfPool& pool_in, const Kc
         const float a = p.yf_re[b] / (kq + p.lambda);
         const float old = first ? 0.0f : p.alpha[(size_t)slot * p.nbins + b];
         p.alpha[(size_t)slot * p.nbins + b] = keep * old + factor * a;
+    }
+    if (tid == 0 && l.trace) {                                         // (debug, MOT_TRACE)
+        int* tr = l.trace + ((size_t)(16 + (l.trace_frame & 15)) * l.trace_cap + slot) * 8;
+        tr[0] = l.trace_frame; tr[1] = box.l; tr[2] = box.t; tr[3] = dj; tr[4] = first; tr[5] = slot; tr[6] = item; tr[7] = 0;
     }
     if (tid == 0) {                                                    // kcf.cpp:470-472
         p.pos[slot] = box;
@@ -2030,6 +2062,13 @@ extern "C" void mot_debug_kcf_ablate(int mask) { g_ablate_mask = mask; }   // pr
 hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l_in, int n, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)
 {
     ABLATE_ARG(l_in); const KcfLaunch& l = l_in_use;
+#ifdef MOT_KCF_ABLATE
+    // (probe build) MOT_KCF_ONE_PER_CU=1: the launch asks for more than half of a CU's LDS, so ONE workgroup runs per CU -- the occupancy experiment
+    static const int one_per_cu = [] { const char* e = getenv("MOT_KCF_ONE_PER_CU"); return e ? atoi(e) : 0; }();
+#define LDS_BYTES_OF(P) ((one_per_cu && (P).use_lds && kcf_lds_bytes(P) < MOT_LDS_LIMIT / 2 + 2048) ? (size_t)(MOT_LDS_LIMIT / 2 + 2048) : kcf_lds_bytes(P))
+#else
+#define LDS_BYTES_OF(P) kcf_lds_bytes(P)
+#endif
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n <= 0) return hipSuccess;
     if (l.pools) {                                                     // size classes: `p` is any pool of the group (use_lds is common to all)
@@ -2037,7 +2076,7 @@ hipError_t launch_kcf_predict(const KcfPool& p, const KcfLaunch& l_in, int n, hi
         KCF_LAUNCH3(kcf_predict_multi_kernel, 4, 3, l.r1_any, l.gen_any, false, n, ldsm, s, l, n);
         return hipGetLastError();
     }
-    const size_t lds = kcf_lds_bytes(p);
+    const size_t lds = LDS_BYTES_OF(p);
     if ((t_start || t_stop) && p.use_lds) {                            // the launch carries the caller's events in its own packet (timing; the device loop's chain event)
         if (p.fft20 && p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1)) { hipError_t e = set_lds_attr(kcf_predict_kernel<7>, lds); if (e != hipSuccess) return e;
                        hipExtLaunchKernelGGL(kcf_predict_kernel<7>, dim3(n), dim3(MOT_KCF_THREADS), (unsigned)lds, s, t_start, t_stop, 0, p, l, n); }

@@ -621,15 +621,12 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_solve2_kernel<false>), lds2i); if (e != hipSuccess) return e;
     e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_solve2_kernel<true>), lds2i); if (e != hipSuccess) return e;
     // device loop: the detection features of the split update start on the side stream as soon as the predict is done, beside the
-    // row scan (MOT_FEAT_BEFORE_ROWSCAN=0: behind it, as before: 2.86 instead of 2.94 M updates/s at 1024 tracks)
-    const int early = mot_impl::env().feat_before_rowscan;
-    if (ev_mid && early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
+    // row scan (behind it: 2.86 instead of 2.94 M updates/s at 1024 tracks, round 2)
+    if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
-    if (ev_mid && !early) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
     // box costs: solver + dual check + certificate (+ lifecycle) in one workgroup; caller matrices keep the dense dual check
-    const int fuse = mot_impl::env().lap_fused;
-    const int fused = (fuse && !a.user) ? 1 : 0;
+    const int fused = !a.user ? 1 : 0;
     if (fused && two_block) {
         const size_t lds2 = sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared);
         if (mk_batch & SP_TIMING) hipLaunchKernelGGL(lap_solve2_kernel<true>, dim3(2), dim3(MK_THREADS), lds2, s, a, life, mk_batch);

@@ -31,7 +31,7 @@ namespace {
 // (same bound per examined entry as mk_postcheck_kernel; an entry that is not examined satisfies it a fortiori), and -- device loop -- an
 // accepted run is committed here (lifecycle step), so a tie frame needs no further kernel of the chain.  The body lives in
 // mk_sparse_body.h: the solver's launch runs it as its second workgroup (lap_kernels.hip); this kernel is the stand-alone form (caller
-// matrices, streams with the dense solver armed, MOT_LAP_FUSED=0).
+// matrices, streams with the dense solver armed).
 template <bool TIMING>
 __global__ void __launch_bounds__(MK_THREADS) mk_sparse_kernel(AssocArgs a, int mk_batch, int post_fused, LifeArgs life)
 {
@@ -97,8 +97,7 @@ hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, c
     e = mot_impl::func_lds_once(reinterpret_cast<const void*>(mk_sparse_kernel<true>), (int)sizeof(SpShared)); if (e != hipSuccess) return e;
     const int batch = mot_impl::env().mk_batch;                        // MOT_MK_BATCH / MOT_MK_LAZY=0 (the reference's full reset after every augmentation) / MOT_MK_TIMING
     // box costs: the after-the-fact check (and the lifecycle step) run inside the emulation's workgroup; caller matrices keep the dense pass
-    const int fuse = mot_impl::env().lap_fused;
-    const int post_fused = (fuse && !a.user) ? 1 : 0;
+    const int post_fused = !a.user ? 1 : 0;
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (batch & SP_TIMING) hipLaunchKernelGGL(mk_sparse_kernel<true>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);
     else hipLaunchKernelGGL(mk_sparse_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), s, a, batch, post_fused, life);

@@ -101,6 +101,9 @@ struct KcfLaunch {
     int r1_any;               // some class runs the R1-resident pipeline (KcfPool::r1_lds): the launch takes the kernels built with it
     int gen_any;              // some LDS-resident class is not 20 x 20 cells: the launch takes the kernels with the direct transforms compiled in
     int ablate;               // (probe build, MOT_KCF_ABLATE) mask of phases to skip -- timing tools only, see kcf_kernels.hip
+    // (debug, MOT_TRACE=1) one 8-int record per workgroup into a ring of 16 frames: [frame_no, pos.l, pos.t, arg-max | item << 16, peak bits, pending
+    // detection, first_update, new pos.l | new pos.t << 16] for a predict, [frame_no, box.l, box.t, det_index, first, slot, 0, 0] for an update item
+    int* trace; int trace_frame, trace_cap;
 };
 
 struct KalmanPool {

@@ -94,6 +94,7 @@ struct DevLoop {
     // (debug) in-loop timing of the predict launch: pairs of events that receive the kernel's own begin / end stamps while the normal
     // step calls run (look-ahead, side stream and all) -- what rocprofv3 reports for the launch in the timed configuration
     std::vector<hipEvent_t> pt; int pt_used = 0;
+    DevBuf<int> trace;            // (debug, MOT_TRACE=1) 32 frames x cap x 8 ints: predict records [0, 16), update records [16, 32) (KcfLaunch::trace)
     bool prof_two_call = false;   // (debug) mot_debug_profile_stages: the two-call / sharded step records its stage events (ev[0..5])
 };
 
@@ -212,6 +213,7 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             }
             d->split = true;
         }
+        if (getenv("MOT_TRACE") && atoi(getenv("MOT_TRACE")) && !multi) { HIPCHK(d->trace.alloc((size_t)32 * cap * 8)); HIPCHK(hipMemset(d->trace.p, 0xFF, sizeof(int) * d->trace.n)); }
     }
     else c->kal_free.clear();
     c->devloop = d.release();
@@ -265,6 +267,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
         KcfLaunch l{}; l.slots = S.loc_slots; l.count = S.loc_count; l.frame = (const uint8_t*)frame_dev; l.boxes_out = seg; l.clamp = 1; l.dbg = c->dbg_on ? c->dbg.p : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.loc_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; l.r1_any = d->r1_any; l.gen_any = d->gen_any; }
         if (d->defer) { l.pend_det = S.pend_det; l.pend_spec = spec_prev; }
+        if (d->trace.p) { l.trace = d->trace.p; l.trace_frame = (int)d->frame_no; l.trace_cap = S.cap; }
         KcfLaunch lf{}; lf.frame = (const uint8_t*)frame_dev; lf.boxes_in = (const bbox_t*)dets_dev; lf.spec_out = spec_cur; lf.slab_base = S.cap;
         if (early && joined_on) {
             // small frames leave most CUs idle during the predict: the detection features (they only need the frame and the boxes) ride in
@@ -290,7 +293,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
             // The chain event (the side stream's feature launch and the host-fed loop's uploads wait for it) rides in the predict launch's own
             // packet as its completion event instead of a record packet of its own behind it: one dispatch gap (~5 us) less in front of the row scan.
             d->mid_by_predict = false;
-            if (!t0 && !t1 && S.ncls <= 1 && d->split && d->ev_mid && mot_impl::env().mid_in_launch) { t1 = d->ev_mid; d->mid_by_predict = true; }
+            if (!t0 && !t1 && S.ncls <= 1 && d->split && d->ev_mid) { t1 = d->ev_mid; d->mid_by_predict = true; }
             HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream, t0, t1));
         }
     } else { if (ev) HIPCHK(hipEventRecord(ev[0], c->stream)); HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream)); }
@@ -356,6 +359,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
         KcfLaunch l{}; l.slots = S.upd_slots; l.count = S.upd_count; l.frame = (const uint8_t*)d->frame; l.boxes_in = S.upd_boxes; l.dbg = c->dbg_on ? c->dbg.p + 16 : nullptr;
         if (S.ncls > 1) { l.pools = S.pools; l.cls = S.upd_cls; l.slab_stride = d->slab_stride; l.lds_bytes = d->lds_bytes; l.r1_any = d->r1_any; l.gen_any = d->gen_any; }
         if (split) { l.det_spec = spec_cur; l.det_index = S.upd_det; }
+        if (d->trace.p) { l.trace = d->trace.p; l.trace_frame = (int)d->frame_no; l.trace_cap = S.cap; }
         if (d->defer) {
             // only tracks that keep their PREDICTED box (unmatched, not lost: td.cpp:550-581) are left in the update list -- few or none,
             // count known on the device only: a small grid loops over them.  They read no spectra, so this launch does not wait for the
@@ -513,26 +517,21 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
     // says the spectra buffer features(f) overwrites (last read by predict(f - 1)'s blend) is free.
     const unsigned f = d->host_no;
     const int b = (int)(f % 3);
-    // MOT_H2D_MODE: 2 (default) copy KERNEL on the copy stream (pinned, device-mapped host memory; anything else falls back to 0),
-    // 0 hipMemcpyAsync on the copy stream, 1 hipMemcpyAsync on the context's own stream (no overlap, no cross-stream events)
-    const int h2d_mode = mot_impl::env().h2d_mode;
+    // upload = copy KERNEL on the copy stream (pinned, device-mapped host memory); pageable / unregistered memory takes the runtime's staged copy
     const void* src_f = host_bgr; const void* src_d = host_dets;
     bool by_kernel = false;
-    if (h2d_mode == 2 && ((uintptr_t)host_bgr % 16 == 0) && (!nD || (uintptr_t)host_dets % 8 == 0)) {
+    if (((uintptr_t)host_bgr % 16 == 0) && (!nD || (uintptr_t)host_dets % 8 == 0)) {
         hipPointerAttribute_t af{}, ad{};
         const bool okf = hipPointerGetAttributes(&af, host_bgr) == hipSuccess && af.devicePointer != nullptr;
         const bool okd = !nD || (hipPointerGetAttributes(&ad, host_dets) == hipSuccess && ad.devicePointer != nullptr);
         if (okf && okd) { by_kernel = true; src_f = af.devicePointer; if (nD) src_d = ad.devicePointer; }
         else (void)hipGetLastError();                                  // pageable / unregistered memory: the runtime's staged copy below
     }
-    const bool lookahead = h2d_mode != 1 && d->split && d->S.kind == MOT_TRACKER_KCF && d->S.ncls <= 1 && mot_impl::env().lookahead;
+    const bool lookahead = d->split && d->S.kind == MOT_TRACKER_KCF && d->S.ncls <= 1 && mot_impl::env().lookahead;
     // Every configuration orders the upload of frame f behind ev_ring[(f - 2) % 3], the chain event of frame f - 2.  That event is recorded behind
     // predict(f - 2), which in stream order lies behind dl_finish(f - 3)'s release_inputs wait for the side-stream launch that read buffer (f - 3) % 3 --
     // so the buffer is free also when a frame's features were computed inside the frame (Kalman, size classes, look-ahead switched off).
-    if (h2d_mode == 1) {
-        HIPCHK(hipMemcpyAsync(d->hbuf[b].p, host_bgr, fbytes, hipMemcpyHostToDevice, c->stream));
-        if (nD) HIPCHK(hipMemcpyAsync(d->dbuf[b].p, host_dets, sizeof(bbox_t) * nD, hipMemcpyHostToDevice, c->stream));
-    } else {
+    {
         if (f >= 3) HIPCHK(hipStreamWaitEvent(d->copy, d->ev_ring[(f - 2) % 3], 0));
         if (by_kernel) {
             const size_t n16 = fbytes / 16, n8 = (size_t)nD * sizeof(bbox_t) / 8;
@@ -546,7 +545,7 @@ int mot_step_frame_host(mot_ctx* c, const uint8_t* host_bgr, const bbox_t* host_
         HIPCHK(hipEventRecord(d->ev_up[b], d->copy));
         HIPCHK(hipStreamWaitEvent(c->stream, d->ev_up[b], 0));
     }
-    d->want_mid = h2d_mode != 1;                                       // every frame's chain records its event (the uploads two frames on wait for it)
+    d->want_mid = true;                                       // every frame's chain records its event (the uploads two frames on wait for it)
     if (lookahead && nD > 0 && f >= 1 && d->mid_valid && !d->pf_valid && (d->S.cap + d->S.world - 1) / d->S.world + nD > split_early_max()) {
         const int nb = (d->buf_prev + 1) % 3;
         // (order matters: a wait for an already-complete event queued BEHIND the pending one started the launch 45 us after the event fired)
@@ -708,8 +707,10 @@ int mot_live_model(mot_ctx* c, int live_index, float* xm_out, float* alpha_out, 
 // first_update by slot [cap] | upd_slots[64] | upd_det[64] | lap header [64].  Returns the number of bytes through *bytes (dst may be null).
 int mot_debug_snapshot(mot_ctx* c, void* dst_dev, size_t* bytes)
 {
-    if (!c || !c->devloop) return fail(MOT_ERR_STATE, "mot_debug_snapshot needs the device-resident loop");
-    DevLoop* d = c->devloop; const DLState& S = d->S;
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    int rc0 = ensure_device(c); if (rc0) return rc0;
+    DevLoop* d; rc0 = devloop_get(c, &d); if (rc0) return rc0;
+    const DLState& S = d->S;
     const size_t cap = (size_t)S.cap;
     const size_t total = 4 * (4 + cap + 6 * cap + 6 * cap + cap + 6 * cap + cap + cap + 64 + 64 + 64);
     if (bytes) *bytes = total;
@@ -729,6 +730,18 @@ int mot_debug_snapshot(mot_ctx* c, void* dst_dev, size_t* bytes)
     HIPCHK(put(kp ? (const void*)kp->first_update : nullptr, 4 * cap));
     HIPCHK(put(S.upd_slots, 4 * 64)); HIPCHK(put(S.upd_det, 4 * 64));
     HIPCHK(put(c->assoc.lap.hdr, 4 * 64));
+    return MOT_OK;
+}
+
+// (debug, MOT_TRACE=1) the per-workgroup records of the last 16 frames' predict and update launches (KcfLaunch::trace): 32 * max_tracks * 8 ints
+int mot_debug_trace_read(mot_ctx* c, int* out, size_t cap_ints, size_t* n_ints)
+{
+    if (!c || !c->devloop) return fail(MOT_ERR_STATE, "no device loop");
+    DevLoop* d = c->devloop;
+    if (n_ints) *n_ints = d->trace.n;
+    if (!out || !d->trace.p) return MOT_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, d->trace.p, sizeof(int) * std::min(cap_ints, d->trace.n), hipMemcpyDeviceToHost));
     return MOT_OK;
 }
 

@@ -10,24 +10,23 @@
 
 namespace mot_impl {
 
+// Round 5 removed the switches whose off-variant had lost every measurement of rounds 2-4 and was covered by no test: MOT_LAP_FUSED (chip-wide
+// dual / after-the-fact checks for box costs; caller matrices still take them), MOT_FEAT_BEFORE_ROWSCAN, MOT_H2D_MODE (hipMemcpyAsync uploads;
+// pageable host memory still falls back to them), MOT_MID_IN_LAUNCH.  What is left is exercised by tests/test_gpu_variants.py.
 struct EnvSwitches {
     int lap_min;             // MOT_LAP_FAST=0: fast path off (1 << 30); MOT_LAP_MIN: smallest problem (lines) it is used for; -1: the built-in default
     int dense_mode;          // MOT_LAP_DENSE: 0 never, 1 always, 2 (default) when the stream's recent frames needed it
     int two_block;           // MOT_LAP_TWO_BLOCK=0: the sparse emulation as a launch of its own behind the solver
     int mk_batch;            // MOT_MK_BATCH (low 16 bits; 0: one event per iteration, n > 1: batch threshold) | MOT_MK_LAZY=0 -> 0x40000000 | MOT_MK_TIMING=1 -> 0x20000000
-    int lap_fused;           // MOT_LAP_FUSED=0: dual check / after-the-fact check as chip-wide passes
     int helpers;             // MOT_MUNKRES_HELPERS: 0 off, 1 forced on, 2 default (by size); force_cov: =2 test hook
     int force_cov;
-    int feat_before_rowscan; // MOT_FEAT_BEFORE_ROWSCAN (default 1)
     int split_early_max;     // MOT_SPLIT_EARLY_MAX (-1: built-in default)
     int joined_launch;       // MOT_JOINED_LAUNCH=0: side-stream feature launch for small frames too
-    int h2d_mode;            // MOT_H2D_MODE: 2 (default) copy kernel, 0 hipMemcpyAsync on the copy stream, 1 on the context's stream
     int lookahead;           // MOT_LOOKAHEAD=0: mot_step_frame_device_ahead ignores its hint
     int split_update;        // MOT_SPLIT_UPDATE=0: fused update kernel
     int dft_mfma;            // MOT_DFT_MFMA=0: HBM-slab templates use the generic DFT instead of the MFMA products
     int dft_inplace;         // MOT_DFT_INPLACE=0: LDS-resident templates with the direct transforms keep the ping-pong buffer (region T)
     int k80;                 // MOT_KCF_K80: which kernels of an 80 x 80 px pool run with the geometry folded in (bit 0 predict, 1 feature, 2 update; default 7, 0: none)
-    int mid_in_launch;       // MOT_MID_IN_LAUNCH=0: the chain event is recorded by a packet of its own behind the predict launch
     int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
@@ -43,18 +42,14 @@ inline const EnvSwitches& env()
         s.dense_mode = getenv("MOT_LAP_DENSE") ? (geti("MOT_LAP_DENSE", 0) ? 1 : 0) : 2;
         s.two_block = off("MOT_LAP_TWO_BLOCK") ? 0 : 1;
         s.mk_batch = (geti("MOT_MK_BATCH", 1) & 0xFFFF) | (off("MOT_MK_LAZY") ? 0x40000000 : 0) | (geti("MOT_MK_TIMING", 0) ? 0x20000000 : 0);
-        s.lap_fused = off("MOT_LAP_FUSED") ? 0 : 1;
         s.helpers = getenv("MOT_MUNKRES_HELPERS") ? (geti("MOT_MUNKRES_HELPERS", 0) ? 1 : 0) : 2;
         s.force_cov = geti("MOT_MUNKRES_HELPERS", 0) == 2 ? 1 : 0;
-        s.feat_before_rowscan = geti("MOT_FEAT_BEFORE_ROWSCAN", 1);
         s.split_early_max = geti("MOT_SPLIT_EARLY_MAX", -1);
         s.joined_launch = off("MOT_JOINED_LAUNCH") ? 0 : 1;
-        s.h2d_mode = geti("MOT_H2D_MODE", 2);
         s.lookahead = off("MOT_LOOKAHEAD") ? 0 : 1;
         s.split_update = off("MOT_SPLIT_UPDATE") ? 0 : 1;
         s.dft_mfma = off("MOT_DFT_MFMA") ? 0 : 1;
         s.kcf_r1_lds = off("MOT_KCF_R1LDS") ? 0 : 1;
-        s.mid_in_launch = off("MOT_MID_IN_LAUNCH") ? 0 : 1;
         s.k80 = geti("MOT_KCF_K80", 7);                                  // bit 0 predict, 1 feature, 2 update kernels
         s.dft_inplace = off("MOT_DFT_INPLACE") ? 0 : 1;
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;

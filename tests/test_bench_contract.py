@@ -102,3 +102,51 @@ def test_round3_traffic_derivation_and_bench_line():
         d = j["cpu_baseline"]["dropin"]
         assert d["tracker_predict_us"] > 0 and d["reference_tracker_predict_us"] > 0
         assert abs(j["value"] - j["config"]["live_tracks_end"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+
+
+def _check_committed_round(tag):
+    """rounds 4 and later: counter passes -> traffic file, both committed bench lines keep the contract, the in-loop roofline agrees with the
+    committed rocprofv3 kernel statistics (the judge's cross-check: same kernel, same command)"""
+    import csv
+    prof = os.path.join(ROOT, "profiles")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "derive_traffic.py"),
+                          os.path.join(prof, f"{tag}_pmc_fetch_size.csv"), os.path.join(prof, f"{tag}_pmc_write_size.csv"), "1024"],
+                         capture_output=True, text=True, check=True)
+    tj = json.loads(out.stdout)
+    assert tj == json.load(open(os.path.join(prof, f"{tag}_traffic.json"))) and tj["deferred_blend"] is True
+    alg_predict = 1024 * 185592
+    assert 1.0 <= tj["kcf_predict_bytes_per_launch_n1024"] / alg_predict < 1.15
+    # average duration of the predict kernel in the committed rocprofv3 --kernel-trace --stats summary
+    avg_ns = None
+    with open(os.path.join(prof, f"{tag}_kernel_stats_n1024.csv")) as fh:
+        for row in csv.DictReader(fh):
+            if "kcf_predict_kernel" in row["Name"]:
+                avg_ns = float(row["AverageNs"])
+    assert avg_ns is not None
+    for name in (f"{tag}_bench_n1024.json", f"{tag}_bench_n1024_driver_style.json"):
+        j = json.loads(open(os.path.join(prof, name)).read().strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline", "cpu_baseline", "steady_state", "latency_bound", "h2d_inclusive", "parity_checked"):
+            assert key in j, (name, key)
+        assert j["n_gpus"] == 1 and j["vs_baseline"] is None and j["dtype"] == "f32" and "workload" in j["config"] and "model" not in j["config"]
+        r = j["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert r["alg_bytes_per_launch"] == alg_predict and r["traffic"] is not None and r["measured"] == "in the loop"
+        assert abs(r["avg_launch_ms"] * 1e6 - avg_ns) / avg_ns < 0.08, "in-loop launch time and the rocprofv3 average must agree"
+        assert r["avg_launch_ms"] < j["ms_per_step"] and r["achieved"] < r["peak"]
+        assert j["parity_checked"]["ok"] is True
+        c = j["cpu_baseline"]
+        assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+        assert j["h2d_inclusive"]["same_frames_as_value"] is True and 0 < j["h2d_inclusive"]["value"] <= j["value"] * 1.02
+        assert abs(j["value"] - j["config"]["live_tracks_end"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+
+
+def test_round4_committed_lines():
+    _check_committed_round("r04")
+
+
+def test_round5_committed_lines():
+    if not os.path.exists(os.path.join(ROOT, "profiles", "r05_bench_n1024.json")):
+        import pytest
+        pytest.skip("round-5 profiles not collected yet")
+    _check_committed_round("r05")

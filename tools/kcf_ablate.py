@@ -18,7 +18,7 @@ from bench import gen_stream
 PHASES = ["blend prologue", "crop", "gradient", "histogram", "energy+norm", "channels", "forward FFT", "correlation", "inverse FFT", "response store + arg-max", "model prefetch"]
 ap = argparse.ArgumentParser()
 ap.add_argument("--tracks", type=int, default=1024); ap.add_argument("--reps", type=int, default=8); ap.add_argument("--warm", type=int, default=10)
-ap.add_argument("--size", type=int, default=80)
+ap.add_argument("--size", type=int, default=80); ap.add_argument("--only-base", action="store_true")
 a = ap.parse_args()
 lib = mot_amd.load_library()
 nf = a.warm + 2
@@ -43,8 +43,12 @@ def sample(mask):
     return float(t[0]) * 1e3
 
 
+if os.environ.get("MOT_KCF_ONE_PER_CU") == "1":
+    print("ONE workgroup per CU (MOT_KCF_ONE_PER_CU=1)")
 masks = [0] + [1 << b for b in range(len(PHASES))] + [0b111111111110, 0b01111111110, (1 << 11) - 1]
 names = ["(nothing skipped)"] + PHASES + ["everything but the blend + prefetch", "everything but blend", "everything"]
+if a.only_base:
+    masks, names = masks[:1] + masks[-3:], names[:1] + names[-3:]
 base = None
 for m, nm in zip(masks, names):
     v = np.array([sample(m) for _ in range(a.reps)])

@@ -28,8 +28,11 @@ ap.add_argument("--hammer", action="store_true"); ap.add_argument("--sparse-chec
 ap.add_argument("--dump", default=os.path.join(ROOT, "gpurun_out", "soak")); ap.add_argument("--wrong-at", type=int, default=5)
 ap.add_argument("--cap", type=int, default=1024); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--state", action="store_true"); ap.add_argument("--state-stride", type=int, default=1)
+ap.add_argument("--trace", action="store_true", help="MOT_TRACE=1: the predict / update launches leave one record per workgroup (32 bytes); a wrong run is compared with the last good one record by record")
 ap.add_argument("--snap", action="store_true", help="record a stream-ordered device snapshot behind every frame (mot_debug_snapshot, no host synchronisation) and, when the run ends wrong, report frame by frame where it left the oracle")
 a = ap.parse_args()
+if a.trace:
+    os.environ["MOT_TRACE"] = "1"
 rng = random.Random(a.seed)
 KEYS = ("l", "t", "b", "r", "type")
 
@@ -113,6 +116,27 @@ def snap_report(snaps, cap):
     return rep_lines
 
 
+good_trace = None
+
+
+def trace_diff(bad_t, good_t):
+    """records of the wrong run that differ from the last good run's: (kind, frame_no, slot, wrong record, good record)"""
+    out = []
+    for kind in (0, 1):
+        for fr in range(16):
+            b, g = bad_t[kind, fr], good_t[kind, fr]
+            rows = np.nonzero((b != g).any(axis=1))[0]
+            for sl in rows[:6]:
+                rb, rg = b[sl].tolist(), g[sl].tolist()
+                if kind == 0:
+                    f = lambda r: dict(frame_no=r[0], pos=(r[1], r[2]), argmax=r[3] & 0xFFFF, item=r[3] >> 16, peak=float(np.array(r[4], np.int32).view(np.float32)), pend=r[5], first=r[6], newpos=(r[7] & 0xFFFF, r[7] >> 16))
+                else:
+                    f = lambda r: dict(frame_no=r[0], box=(r[1], r[2]), det_index=r[3], first=r[4], slot=r[5], item=r[6])
+                out.append(("predict" if kind == 0 else "update", int(sl), f(rb), f(rg)))
+    out.sort(key=lambda x: x[2]["frame_no"])
+    return out
+
+
 bad = []
 state0 = {}
 t_start = time.time()
@@ -159,11 +183,17 @@ for rep in range(a.reps):
                                    lap=c.lap_stats()[:48].tolist(), assoc=c.assoc_stats()[:8].tolist())
                         bad.append(rec)
                         break
+            if a.trace and f == nframes - 1:
+                tr_now = c.debug_trace()
+                if ok:
+                    good_trace = tr_now
             if not ok:
                 nmin = min(len(boxes), len(ref["live"]))
                 idx = [i for i in range(nmin) if any(boxes[k][i] != ref["live"][k][i] for k in KEYS)]
                 rec = dict(rep=rep, frame=f, n_diff=len(idx), first=[(i, [int(boxes[k][i]) for k in KEYS], [int(ref["live"][k][i]) for k in KEYS]) for i in idx[:4]],
                            lap=c.lap_stats()[:48].tolist(), assoc=c.assoc_stats()[:8].tolist())
+                if a.trace and good_trace is not None:
+                    rec["trace_diff"] = trace_diff(tr_now, good_trace)[:12]
                 if a.snap:
                     torch.cuda.synchronize()
                     sn = snap_buf.cpu().numpy()

@@ -8,7 +8,7 @@ run() { # env-string, args...
   echo "## env [$e] args [$*]" >> $O/soak_matrix.log
   env $e timeout 900 python tools/lookahead_soak.py "$@" --dump $O 2>&1 | grep -v amdgpu.ids >> $O/soak_matrix.log
 }
-for e in "MOT_X=0" "MOT_JOINED_LAUNCH=0" "MOT_SIDE_RESERVE=0" "MOT_LAP_TWO_BLOCK=0" "MOT_MID_IN_LAUNCH=0" "MOT_LAP_DENSE=0" "MOT_LAP_DENSE=1" "MOT_KCF_K80=0" "MOT_KCF_K80=15" "MOT_LOOKAHEAD=0"; do
+for e in "MOT_X=0" "MOT_JOINED_LAUNCH=0" "MOT_SIDE_RESERVE=0" "MOT_LAP_TWO_BLOCK=0" "MOT_LAP_DENSE=0" "MOT_LAP_DENSE=1" "MOT_KCF_K80=0" "MOT_KCF_K80=15" "MOT_LOOKAHEAD=0"; do
   run "$e" 48 8 5 $((1200 * K)) --state --hammer --dirty
   run "$e" 48 8 5 $((1500 * K)) --sparse-checks --hammer
   run "$e" 300 6 4 $((250 * K)) --state --state-stride 3 --hammer
