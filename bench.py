@@ -10,7 +10,7 @@ rank, then every track runs tracker_update; track lifecycle (delete / spawn)
 included (top/td.cpp:344-644).  One tracker-update = one track x one frame.
 
 Workload (BASELINE.json configs[2] at N=1, configs[3] at N=8): 1024 concurrent
-80x80 KCF tracks on a synthetic 1280x720 BGR stream, sharded tid % N across the
+80x80 KCF tracks on a synthetic 1280x720 BGR stream, sharded across the
 GPUs of one node => "scaling": "strong".  Frames and detections are resident in
 HBM before the timed region.  `--tracks 64` gives configs[1].
 
@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--fp-pct", type=int, default=0, help="detector noise: number of false-positive boxes per frame, percent of --tracks")
     ap.add_argument("--nms", action="store_true", help="no two detections of a frame share a centroid (what a detector's NMS guarantees)")
     ap.add_argument("--mode", choices=["sharded", "streams"], default="sharded",
-                    help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded tid %% N, one all-gather per frame (BASELINE configs[3], strong scaling); "
+                    help="N > 1: sharded = ONE stream of --tracks tracks, tracks sharded over the N ranks (least-loaded rank per spawn), one all-gather per frame (BASELINE configs[3], strong scaling); "
                          "streams = N independent camera streams of --tracks tracks each, one per GPU, no collective (BASELINE configs[4], weak scaling)")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="single GPU only: K independent camera streams of --tracks tracks each run concurrently (K contexts, K HIP streams); "
@@ -449,13 +449,13 @@ def main():
         out = {
             "metric": "tracker-updates/sec (KCF, 80x80 patch)", "value": value, "unit": "tracker-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            **({"rccl_ranks": world, "collective": "1 x all_gather_into_tensor(bbox_t[max_tracks]) per frame" if not streams else "none"} if world > 1 and backend != "gloo" else {}),
+            **({"rccl_ranks": world, "collective": "1 x all_gather_into_tensor(bbox_t[ceil(max_tracks / world)] per rank) per frame" if not streams else "none"} if world > 1 and backend != "gloo" else {}),
             **({"smoke_backend": "gloo (not a measurement)"} if backend == "gloo" and world > 1 else {}),
             "higher_is_better": True, "scaling": "weak" if streams else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{world} independent camera streams (one per GPU, no collective), each {n_tracks} concurrent {size}x{size} KCF tracks, "
                                     f"1280x720 BGR synthetic stream, Munkres {n_tracks}x{n_tracks}; BASELINE configs[4]") if streams else
                                    (f"{n_tracks} concurrent {size}x{size} KCF tracks (31-ch FHOG, cell 4), 1280x720 BGR synthetic stream, "
-                                    f"{n_tracks} detections/frame, Munkres {n_tracks}x{n_tracks}, tracks sharded tid % {world}; "
+                                    f"{n_tracks} detections/frame, Munkres {n_tracks}x{n_tracks}, tracks sharded over {world} rank(s); "
                                     f"BASELINE configs[{2 if n_tracks == 1024 else 1}]" + ("/[3]" if world > 1 else "")),
                        **({"streams_per_gpu": args.streams_per_gpu, "note": "K independent contexts on K HIP streams of one GPU; value = all streams"} if extra else {}),
                        "tracks_total": n_tracks * (world if streams else 1) * (1 + len(extra)), "tracks_per_gpu": n_tracks if streams else n_tracks // world,
@@ -497,7 +497,7 @@ def main():
             launch_ms = inloop_ms if (inloop_ms is not None and dom.startswith("kcf_predict")) else isolated_ms
             achieved = per_launch / (launch_ms * 1e-3) / 1e9
             traffic = None; tj = {}; traffic_src = None
-            for cand_file in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            for cand_file in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", cand_file)
                 if os.path.exists(tpath):
                     try:

@@ -96,7 +96,9 @@ typedef struct mot_config {
     int fft_mode;      /* MOT_FFT_* */
     int max_tracks;    /* capacity of the live-track list (reference: 256, td.cpp:12) */
     int max_dets;      /* capacity of a detection list (reference: 128, cnntype.h:46) */
-    int rank, world;   /* track sharding: this context owns KCF/Kalman state of tracks with tid % world == rank */
+    int rank, world;   /* track sharding: this context holds the KCF/Kalman state of the tracks rank `rank` owns.  Device-resident loop: a spawning track goes to the
+                        * rank with the fewest live tracks (lowest rank on a tie; replicated, deterministic), so a rank never owns more than
+                        * ceil(max_tracks / world) tracks; host-orchestrated mot_step_begin / mot_step_finish: tid % world */
     void* stream;      /* hipStream_t to launch on, or NULL to create a private stream */
     int dev_rows, dev_cols; /* template size of the device-resident loop (mot_step_frame_device); 0 = 80 */
     int dev_size_lo, dev_size_hi; /* device-resident loop with per-track template sizes (the reference freezes rows / cols at tracker_new

@@ -4,12 +4,19 @@
 #include "mot_dev.h"
 
 #define DL_MAX_CLASSES 128
-#define DL_LIFE_SCRATCH_INTS (2048 + 16 + 4 + DL_MAX_CLASSES)
+#define DL_MAX_WORLD 64           /* ranks a sharded context can address (one lane of a wavefront each in the spawn assignment) */
+#define DL_LIFE_SCRATCH_INTS (2048 + 16 + 4 + DL_MAX_CLASSES + DL_MAX_WORLD)
 
 struct DLState {
     int* nlive; unsigned* next_tid; int* nfree; int* free_slots;
     int* slot; unsigned* tid; int* age; int* vis; int* inv; bbox_t* bbox;   // [cap] live list, td.cpp order
     int* rankpos;                 // [cap] index inside the owner's all-gather segment
+    // Sharding (round 5): the rank that owns a live track is part of the replicated live list.  A spawning track goes to the rank that owns the
+    // FEWEST live tracks at that moment (lowest rank on a tie; detection order) -- round-robin by creation id while nothing dies, and no rank
+    // ever owns more than ceil(cap / world) tracks, so a segment of the all-gather holds exactly that many boxes (3 KB at 1024 tracks on 8
+    // GPUs) and the predict / update grids of a rank are shard-sized.  (Rounds 1-4: owner = tid % world, which drifts under track
+    // churn -- every segment had to hold max_tracks boxes.)
+    int* owner;                   // [cap] owning rank of every live track (all zero when world == 1)
     int* loc_slots; int* loc_count;
     int* upd_slots; bbox_t* upd_boxes; int* upd_count;
     int* upd_det;                 // [cap + max_dets] detection whose box an update item adopts (-1: the predicted box, td.cpp:540-560)
@@ -49,15 +56,14 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* wave_tot, in
 __device__ inline void dl_build_lists(const DLState& S, int n, int* wave_tot)
 {
     const int t = threadIdx.x;
-    const unsigned mytid = (t < n) ? S.tid[t] : 0u;
-    const int r = (t < n) ? (int)(mytid % (unsigned)S.world) : -1;
+    const int r = (t < n) ? (S.world > 1 ? S.owner[t] : 0) : -1;
     int mine_total = 0;
     for (int rk = 0; rk < S.world; rk++) {
         int total;
         const int pos = block_excl_scan_flag(r == rk, wave_tot, total);
         if (r == rk) {
             S.rankpos[t] = pos;
-            if (pos >= S.spr) atomicAdd(&S.err[3], 1);                 // cannot happen: a segment holds cap boxes (mot_ctx.hip)
+            if (pos >= S.spr) atomicAdd(&S.err[3], 1);                 // cannot happen: no rank ever owns more than ceil(cap / world) = spr tracks (DLState::owner)
             else if (rk == S.rank) {
                 S.loc_slots[pos] = S.slot[t];
                 if (S.ncls > 1) S.loc_cls[pos] = S.cls[t];
@@ -79,11 +85,14 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     int* wave_tot = scratch + 2048;
     int* cnt = scratch + 2048 + 16;   // [0] update list, [1] free stack top
     int* cntc = scratch + 2048 + 16 + 4;  // size classes: per-class free stack tops
+    int* load = scratch + 2048 + 16 + 4 + DL_MAX_CLASSES;   // sharding: live tracks per rank (spawn assignment)
+    const bool sharded = S.world > 1;
     const int t = threadIdx.x;
     const int nT = *S.nlive;
     const bool multi = S.kind == MOT_TRACKER_KCF && S.ncls > 1;
     if (t == 0) { cnt[0] = 0; cnt[1] = *S.nfree; }
     if (multi && t < S.ncls) cntc[t] = S.nfree_c[t];
+    if (t < DL_MAX_WORLD) load[t] = 0;
     at[t] = -1; ad[t] = -1;
     __syncthreads();
     // td.cpp:472-502 -- scatter of the assignment vector (rows = the smaller side, td.cpp:462-469)
@@ -97,9 +106,10 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     // Round 5: the update list and the free-slot stack are filled in LIVE ORDER (block scans instead of atomic counters) -- which slot a new
     // track receives and where an item sits in the residual-update list no longer depend on the order in which wavefronts reach an atomic,
     // so two runs of a stream leave the same bits in device memory (state dumps can be compared; results never depended on it).
-    bool to_upd = false, to_free = false; int j_upd = -1;
+    bool to_upd = false, to_free = false; int j_upd = -1; int own = 0;
     if (t < nT) {
         slot = S.slot[t]; tid = S.tid[t]; age = S.age[t]; vis = S.vis[t]; inv = S.inv[t];
+        if (sharded) own = S.owner[t];
         if (multi) tcls = S.cls[t];
         bb = trk_pred[t];
         const int j = at[t];
@@ -107,7 +117,8 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
         else { age++; inv++; }
         const bool lost = ((age < 10) && (vis * 5 < 3 * age)) || (inv >= 20);
         keep = !lost;
-        mine = ((int)(tid % (unsigned)S.world) == S.rank);
+        mine = own == S.rank;
+        if (sharded && keep) atomicAdd(&load[own], 1);
         if (mine) {
             if (keep && S.defer && j >= 0) {                               // tracker_update's bookkeeping now, its model blend in the next predict
                 S.pend_det[slot] = j;
@@ -132,7 +143,7 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     int n_keep;
     const int newpos = block_excl_scan_flag(keep, wave_tot, n_keep);
     __syncthreads();
-    if (keep) { S.slot[newpos] = slot; S.tid[newpos] = tid; S.age[newpos] = age; S.vis[newpos] = vis; S.inv[newpos] = inv; S.bbox[newpos] = bb; if (multi) S.cls[newpos] = tcls; }
+    if (keep) { S.slot[newpos] = slot; S.tid[newpos] = tid; S.age[newpos] = age; S.vis[newpos] = vis; S.inv[newpos] = inv; S.bbox[newpos] = bb; if (multi) S.cls[newpos] = tcls; if (sharded) S.owner[newpos] = own; }
     // td.cpp:612-644 -- spawn a tracker per unassigned detection, in detection order
     bool spawn = false; bbox_t db{}; int scls = 0;
     if (t < nD && ad[t] < 0) {
@@ -148,7 +159,27 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
     // slots for the spawning tracks this rank owns, in detection order from the top of the stack (single template; the per-class stacks of
     // the size classes keep their atomic tops)
     const bool in_cap = spawn && n_keep + spos < S.cap;
-    const bool m2 = in_cap && ((int)((tid0 + (unsigned)spos) % (unsigned)S.world) == S.rank);
+    // owners of the spawning tracks, in detection order: each goes to the rank with the fewest live tracks so far (lowest rank on a tie).
+    // Wavefront 0, lane = rank: one wave-wide arg-min per spawn (frame 0 spawns everything: ~0.1 ms once; a steady frame spawns a handful).
+    int* sp_owner = at;                                                // the assignment scatter is spent (read above, behind a barrier)
+    if (sharded) {
+        __syncthreads();                                               // load[] complete, at[] dead
+        if (t < 64) {
+            const int n_sp = min(n_spawn, S.cap - n_keep);
+            unsigned ld = (t < S.world) ? (unsigned)load[t] : 0xFFFFFFu;
+            for (int q = 0; q < n_sp; q++) {
+                unsigned key = (ld << 8) | (unsigned)t;                    // (load, rank): the smallest wins
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)key, off); key = o < key ? o : key; }
+                const int win = (int)(key & 0xFFu);
+                if (t == win) ld++;
+                if (t == 0) sp_owner[q] = win;
+            }
+        }
+        __syncthreads();
+    }
+    const int own_new = (sharded && in_cap) ? sp_owner[spos] : 0;
+    const bool m2 = in_cap && own_new == S.rank;
     int n_pop;
     const int ppos = block_excl_scan_flag(m2 && !multi, wave_tot, n_pop);
     const int top0 = cnt[1];
@@ -164,6 +195,7 @@ __device__ inline void dl_lifecycle_body(const DLState& S, const KcfPool& kp, co
             }
             S.slot[idx] = ns; S.tid[idx] = ntid; S.age[idx] = 0; S.vis[idx] = 0; S.inv[idx] = 0; S.bbox[idx] = db;
             if (multi) S.cls[idx] = scls;
+            if (sharded) S.owner[idx] = own_new;
             if (ns >= 0) {
                 if (S.kind == MOT_TRACKER_KCF) {
                     const KcfPool& sp = multi ? S.pools[scls] : kp;

@@ -316,7 +316,11 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // ---------------------------------------------------------------------------
 // NPRE (HBM-slab templates): the footprint columns are loaded four at a time, all in flight at once, because there every
 // load is an L2 round trip; the LDS-resident kernels load column by column.
-template <int NPRE, bool LDSACC = true>   // LDSACC: the accumulators live in LDS (false only for the FHOG-only test kernel of templates beyond the LDS)
+// BATCH: the eight read-modify-writes of a footprint column resolved in registers -- 8 instead of 64 dependent LDS round trips per cell, at the price of
+// 56 more instructions per column.  Round 5 measured both ways: a launch that FILLS the chip (1024 tracks, two workgroups per CU) is bound by what it
+// issues, not by one workgroup's latency, and gets slower (isolated predict launch 88 -> 92 us); a small joined launch (one workgroup per CU) waits
+// for exactly this chain.  So only the small-frame kernel takes it.
+template <int NPRE, bool LDSACC = true, bool BATCH = (MOT_HIST_BATCH != 0)>   // LDSACC: the accumulators live in LDS (false only for the FHOG-only test kernel of templates beyond the LDS)
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
                            float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt, int cell_lo = 0, int cell_hi = -1)
 {
@@ -372,13 +376,13 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 // wave's accesses in order, so the last store of an orientation is the one that stays, and the next column's reads see it).
                 // (ds_add_f32 -- one LDS float add per pixel, no return value, bit-identical sums -- was measured in round 3: the predict
                 // launch went from 100 to 215 us; the LDS atomic path is that slow.)
-#if !MOT_HIST_BATCH
+                if constexpr (!BATCH) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {                            // sequential form: one dependent LDS round trip per pixel, fewest instructions
                     const int bj = (int)(((j < 4 ? ba : bb) >> (8 * (j & 3))) & 0xffu);
                     Rc[bj * 64] += (wx * wy[j]) * mv[j];
                 }
-#else
+                } else {
                 int ad[8]; float wv[8], rv[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -396,7 +400,7 @@ __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) Rc[ad[j]] = rv[j];
-#endif
+                }
             }
         }
         int nmul = ((int)cx == 0) + ((int)cy == 0) + ((int)cx == wb - 1) + ((int)cy == hb - 1);
@@ -1327,7 +1331,7 @@ __device__ __forceinline__ Regions carve(const KcfPool& p, float* base, float* c
 }
 
 // Everything up to R1 (region A) and the norm matrix: shared by predict / update.
-template <bool SLAB, bool LDSR1 = true, bool R1 = false>
+template <bool SLAB, bool LDSR1 = true, bool R1 = false, bool HB = (MOT_HIST_BATCH != 0)>   // HB: phase_hist's BATCH
 __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item, bbox_t box, const Regions& r, int tid, int nt, float* stage = nullptr)
 {
 #define DBG_STAMP(i) do { if (l.dbg && blockIdx.x == 0 && tid == 0) l.dbg[i] = wall_clock64(); } while (0)
@@ -1390,7 +1394,7 @@ __device__ void features_prepare(const KcfPool& p, const KcfLaunch& l, int item,
     if (ABL(2)) phase_gradmag(p, r.A, Mq, bins, r.tab, tid, nt);
     __syncthreads();
     DBG_STAMP(2);
-    if (ABL(3)) phase_hist<SLAB ? 4 : 0, LDSR1>(p, Mq, bins, r.A, stage, tid, nt);       // R1 overlays the patch
+    if (ABL(3)) phase_hist<SLAB ? 4 : 0, LDSR1, HB>(p, Mq, bins, r.A, stage, tid, nt);       // R1 overlays the patch
     __syncthreads();
     DBG_STAMP(3);
     if (ABL(4)) phase_energy<SLAB>(p, r.A, r.E, tid, nt);
@@ -1450,7 +1454,7 @@ __device__ __forceinline__ KcfPool pool_view(const KcfPool& in)
     return q;
 }
 
-template <int kMode, bool kStagger = false>   // kMode 0: HBM slab, 1: LDS with the 20 x 20 register FFT only (80 px: the headline kernels), 2: HBM slab with the R1-resident pipeline compiled in,
+template <int kMode, bool kStagger = false, bool kHB = (MOT_HIST_BATCH != 0)>   // kMode 0: HBM slab, 1: LDS with the 20 x 20 register FFT only (80 px: the headline kernels), 2: HBM slab with the R1-resident pipeline compiled in,
                                              // 3: LDS with the direct transforms compiled in as well (size-class launches), 5: as 3 plus their in-place form (single pool), 4: as 2 for size-class launches,
                                              // 7: as 1 for the pool of exactly 80 x 80 px, geometry folded into the code (pool_view) (the staged transforms inline: larger classes run them)
                                              // (kernels of their own: the other modes keep their code and registers)
@@ -1565,7 +1569,7 @@ __device__ __forceinline__ void kcf_predict_body(const KcfPool& pool_in, const K
         for (int ch = 0; ch < MOT_HALF0; ch++) xmr[ch] = xm[ch * p.nbins + bpre];
         alr = p.alpha[(size_t)slot * p.nbins + bpre];
     }
-    features_prepare<!kLds, true, (kMode == 2 || kMode == 4)>(pc, l, item, pos, r, tid, nt, stage);
+    features_prepare<!kLds, true, (kMode == 2 || kMode == 4), kHB>(pc, l, item, pos, r, tid, nt, stage);
     if (late && ABL(0)) blend();
     // kcf_linear_correlation_zf (kcf.cpp:306-362): zf = sum_c xf_c * conj(xm_c), then * alpha * norm; accumulated over the
     // two channel halves in registers (one thread per bin)
@@ -1852,7 +1856,7 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
 // Feature-only launch of the split update (device loop): crop -> FHOG -> 31 spectra of every DETECTION box, written to l.spec_out.
 // A kernel of its own: inside kcf_update_kernel the model prefetch and the blend paths it never takes cost it 300 spilled VGPRs
 // (1 KB of scratch per lane) -- and this launch is the one that shares the chip with the association chain every frame.
-template <int kMode>
+template <int kMode, bool kHB = (MOT_HIST_BATCH != 0)>
 __device__ __forceinline__ void kcf_features_body(const KcfPool& pool_in, const KcfLaunch& l, const int item, float* smem)
 {
     constexpr bool kLds = (kMode & 1) != 0;
@@ -1864,7 +1868,7 @@ __device__ __forceinline__ void kcf_features_body(const KcfPool& pool_in, const 
     const Regions r = carve(p, base, r1m ? smem + MOT_NORI * 64 * ((p.nb + 63) >> 6) : ((!kLds && p.szC > 0) ? smem : nullptr), r1m);
     const int tid = threadIdx.x, nt = blockDim.x;
     const bbox_t box = l.boxes_in[item];
-    features_prepare<!kLds, true, (kMode == 2 || kMode == 4)>(pc, l, item, box, r, tid, nt, stage);
+    features_prepare<!kLds, true, (kMode == 2 || kMode == 4), kHB>(pc, l, item, box, r, tid, nt, stage);
     const float2* S = reinterpret_cast<const float2*>(r.B);
     float2* so = l.spec_out + (size_t)item * MOT_NCHAN * p.nbins;
     if (r1m) {                                                         // the transforms store straight into the launch's spectrum buffer
@@ -1893,18 +1897,18 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
 // Small frames (predict + feature workgroups fit the chip together): ONE launch carries both -- workgroups [0, n_pred) predict the
 // tracks, workgroups [n_pred, n_pred + n_feat) compute the detection spectra of the split update.  No side stream, no event pair, no
 // cross-stream wait: at 64 tracks those cost more than the kernels' own work.
-template <int kMode>
+template <int kMode, bool kHB = (MOT_HIST_BATCH != 0)>   // kHB: the launch leaves every workgroup alone on its CU (<= 256 workgroups): latency-bound, see phase_hist
 __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < n_pred) {
         const int item = blockIdx.x;
         if (lp.count && item >= *lp.count) return;
-        kcf_predict_body<kMode>(p, lp, item, smem);
+        kcf_predict_body<kMode, false, kHB>(p, lp, item, smem);
     } else {
         const int item = (int)blockIdx.x - n_pred;
         if (item >= n_feat) return;
-        kcf_features_body<kMode>(p, lf, item, smem);
+        kcf_features_body<kMode, kHB>(p, lf, item, smem);
     }
 }
 
@@ -2103,6 +2107,13 @@ hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp_in,
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n_pred + n_feat <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
+    // small frames (every workgroup alone on its CU) with the 80 x 80 px template: the instantiation with the batched histogram (phase_hist);
+    // MOT_KCF_K80 bit 4 (16) switches it off
+    if (p.use_lds && p.fft20 && p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1) && !(mot_impl::env().k80 & 16) && n_pred + n_feat <= 256) {
+        hipError_t e_ = set_lds_attr(kcf_predict_features_kernel<7, true>, lds); if (e_ != hipSuccess) return e_;
+        hipLaunchKernelGGL((kcf_predict_features_kernel<7, true>), dim3(n_pred + n_feat), dim3(MOT_KCF_THREADS), lds, s, p, lp, lf, n_pred, n_feat);
+        return hipGetLastError();
+    }
     KCF_LAUNCH3(kcf_predict_features_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1)), n_pred + n_feat, lds, s, p, lp, lf, n_pred, n_feat);
     return hipGetLastError();
 }

@@ -181,6 +181,7 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
     if (!p.use_lds && !shared_scratch) { HIPCHK(ph->gscratch.alloc((size_t)(cap + c->cfg.max_dets) * p.lds_floats)); }
     p.xm = ph->xm.p; p.alpha = ph->alpha.p; p.pos = ph->pos.p; p.scale = ph->scale.p; p.first_update = ph->first.p; p.response = ph->response.p;
     p.cos_win = ph->cos_win.p; p.yf_re = ph->yf_re.p; p.tw_r = ph->tw_r.p; p.tw_c = ph->tw_c.p; p.sse_tab = c->sse_tab.p; p.gscratch = ph->gscratch.p;
+    HIPCHK(hipDeviceSynchronize());                                    // pool creation is rare: its fills and table uploads are complete before anything uses the pool (see mot_ctx_create)
     c->pools.push_back(std::move(ph));
     *out_idx = (int)c->pools.size() - 1;
     return MOT_OK;
@@ -418,19 +419,19 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     const size_t n2 = (size_t)1024 * 1024;
     const size_t mr = std::max(cfg->max_tracks, cfg->max_dets);
     const size_t mat = std::max(std::min(n2, mr * mr), (size_t)8192);   // >= 8192 words: the sparse emulation's time-stamp trace (MOT_MK_TIMING, <= 8190 entries) lives in it
-    HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024)); HIPCHK(hipMemset(c->a_linemin.p, 0xFF, 1024 * sizeof(unsigned long long)));
-    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(hipMemset(c->a_status.p, 0, 16 * sizeof(int))); HIPCHK(c->a_cost.alloc(1));
+    HIPCHK(c->a_dist.alloc(mat)); HIPCHK(c->a_zr.alloc(mr * 16)); HIPCHK(c->a_zc.alloc(mr * 16)); HIPCHK(c->a_linemin.alloc(1024)); HIPCHK(hipMemsetAsync(c->a_linemin.p, 0xFF, 1024 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c->a_assign.alloc(1024)); HIPCHK(c->a_status.alloc(16)); HIPCHK(hipMemsetAsync(c->a_status.p, 0, 16 * sizeof(int), c->stream)); HIPCHK(c->a_cost.alloc(1));
     c->assoc.dist = c->a_dist.p; c->assoc.zr = c->a_zr.p; c->assoc.zc = c->a_zc.p; c->assoc.linemin = c->a_linemin.p;
     c->assoc.assignment = c->a_assign.p; c->assoc.status = c->a_status.p; c->assoc.cost = c->a_cost.p;
     HIPCHK(c->h_hint.alloc(16)); for (int i = 0; i < 16; i++) c->h_hint.p[i] = 0; c->assoc.dense_hint = c->h_hint.p;
-    HIPCHK(c->a_ctl.alloc(MOT_ASSOC_CTL_WORDS)); HIPCHK(hipMemset(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n)); c->assoc.ctl = c->a_ctl.p;
+    HIPCHK(c->a_ctl.alloc(MOT_ASSOC_CTL_WORDS)); HIPCHK(hipMemsetAsync(c->a_ctl.p, 0, sizeof(unsigned long long) * c->a_ctl.n, c->stream)); c->assoc.ctl = c->a_ctl.p;
     {   // assignment fast path workspace (lap_kernels.hip): one block, carved here
         size_t off = 0; auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_cost = carve(sizeof(double) * 1024 * LAP_K), o_col = carve(sizeof(unsigned short) * 1024 * LAP_K), o_v = carve(sizeof(double) * 1024),
                      o_u = carve(sizeof(double) * 1024), o_cr = carve(sizeof(short) * 1024), o_rc = carve(sizeof(short) * 1024),
                      o_e = carve(sizeof(unsigned) * LAP_EDGES), o_h = carve(sizeof(int) * 64), o_d = carve(sizeof(double) * 8), o_k = carve(8),
                      o_sa = carve(sizeof(short) * 1024), o_ss = carve(sizeof(double) * 1024);
-        HIPCHK(c->a_lap.alloc(off)); HIPCHK(hipMemset(c->a_lap.p, 0, off));
+        HIPCHK(c->a_lap.alloc(off)); HIPCHK(hipMemsetAsync(c->a_lap.p, 0, off, c->stream));
         unsigned char* b = c->a_lap.p; LapWs& L = c->assoc.lap;
         L.ccost = (double*)(b + o_cost); L.ccol = (unsigned short*)(b + o_col); L.v = (double*)(b + o_v); L.u = (double*)(b + o_u);
         L.colOfRow = (short*)(b + o_cr); L.rowOfCol = (short*)(b + o_rc); L.edges = (unsigned*)(b + o_e); L.hdr = (int*)(b + o_h);
@@ -441,7 +442,12 @@ int mot_ctx_create(const mot_config* cfg, mot_ctx** out)
     // still a latency-bound message); the predict / update grids are bounded by device-side counts, not by the segment size.
     c->slots_per_rank = cfg->max_tracks;
     HIPCHK(c->d_gather.alloc((size_t)c->slots_per_rank * cfg->world));
-    HIPCHK(hipMemset(c->d_gather.p, 0, sizeof(bbox_t) * c->d_gather.n));
+    HIPCHK(hipMemsetAsync(c->d_gather.p, 0, sizeof(bbox_t) * c->d_gather.n, c->stream));
+    // Every fill above is ordered on the context's OWN stream and the set-up ends with a device-wide wait.  Round 5's root cause of the
+    // "look-ahead flake": hipMemset() of device memory is asynchronous to the host and runs on the NULL stream, with which a non-blocking stream
+    // does not synchronise -- under load the 0xFF fill of the pending-detection array (mot_devloop.hip) executed AFTER the first frame's lifecycle
+    // step had written it, every first model update slipped by one frame, and about one run in 10^4 left the oracle.
+    HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipDeviceSynchronize());
     *out = c.release();
     return MOT_OK;
 }
@@ -795,7 +801,7 @@ int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long*
 {   // workgroup-0 phase stamps (100 MHz ticks) of the most recent device-loop predict / update launches
     if (!c) return fail(MOT_ERR_ARG, "null ctx");
     // [0..15] predict, [16..31] update phase stamps of workgroup 0; [32 + 3i ..] start, end, hardware id of predict workgroup i (MOT_DBG_WG=1)
-    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32 + 3 * 4096)); HIPCHK(hipMemset(c->dbg.p, 0, (32 + 3 * 4096) * sizeof(long long))); }
+    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32 + 3 * 4096)); HIPCHK(hipMemsetAsync(c->dbg.p, 0, (32 + 3 * 4096) * sizeof(long long), c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     c->dbg_on = enable != 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));

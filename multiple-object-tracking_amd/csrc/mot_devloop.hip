@@ -22,7 +22,9 @@
 // device.  (Timeline: the gap in front of the predict launch went from 10.5 to 5.9 us; the bench moved within its noise.  The two
 // sync packets of a frame -- this wait and the record in front of the row scan -- still cost ~13 us together: the fused-update
 // variant, which has neither, shows no gap at all between its kernels.)
-#define MOT_EVENT_FLAGS (hipEventDisableTiming | hipEventReleaseToDevice)
+// (investigation, MOT_EVENT_SYSTEM=1: the default system-scope release instead -- round 5's hunt for a stale cross-stream read)
+static unsigned mot_event_flags() { static const unsigned f = (getenv("MOT_EVENT_SYSTEM") && atoi(getenv("MOT_EVENT_SYSTEM"))) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice); return f; }
+#define MOT_EVENT_FLAGS (mot_event_flags())
 
 using namespace mot_impl;
 
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(1024) dl_scatter_kernel(DLState S, const bbox_
 {   // gathered segments -> live order (world > 1)
     const int n = *S.nlive, t = threadIdx.x;
     if (t < n) {
-        const int r = (int)(S.tid[t] % (unsigned)S.world);
+        const int r = S.owner[t];
         S.pred[t] = gathered[(size_t)r * S.spr + S.rankpos[t]];
     }
 }
@@ -125,7 +127,10 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     std::unique_ptr<DevLoop> d(new DevLoop);
     DLState& S = d->S;
     const int cap = c->cfg.max_tracks, md = c->cfg.max_dets;
-    S.cap = cap; S.max_dets = md; S.rank = c->cfg.rank; S.world = c->cfg.world; S.spr = c->slots_per_rank; S.kind = c->cfg.tracker_kind;
+    S.cap = cap; S.max_dets = md; S.rank = c->cfg.rank; S.world = c->cfg.world; S.kind = c->cfg.tracker_kind;
+    // a rank never owns more than ceil(cap / world) tracks (balanced spawn assignment, DLState::owner): that is a segment of the all-gather
+    S.spr = S.world > 1 ? (cap + S.world - 1) / S.world : c->slots_per_rank;
+    if (S.world > DL_MAX_WORLD) return fail(MOT_ERR_ARG, "world %d exceeds %d ranks", S.world, DL_MAX_WORLD);
     S.rows = c->cfg.dev_rows > 0 ? c->cfg.dev_rows : 80; S.cols = c->cfg.dev_cols > 0 ? c->cfg.dev_cols : 80;
     S.ncls = 1; S.cls_lo = S.rows;
     if (S.kind == MOT_TRACKER_KCF && c->cfg.dev_size_lo > 0) {
@@ -148,14 +153,14 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     } else if (S.kind == MOT_TRACKER_KCF) { int rc = get_pool(c, S.rows, S.cols, &d->pool); if (rc) return rc; }
     const bool multi = S.ncls > 1;
     // one int arena: nlive, next_tid(as tids), nfree, loc_count, upd_count, err[4], then arrays
-    const size_t nints = 16 + (size_t)cap * 8 + 2 * (size_t)(cap + md) + 64 + (multi ? (size_t)cap * 2 + (cap + md) + S.ncls + (size_t)S.ncls * cap : 0);
+    const size_t nints = 16 + (size_t)cap * 9 + 2 * (size_t)(cap + md) + 64 + (multi ? (size_t)cap * 2 + (cap + md) + S.ncls + (size_t)S.ncls * cap : 0);
     HIPCHK(d->ints.alloc(nints)); HIPCHK(hipMemsetAsync(d->ints.p, 0, nints * sizeof(int), c->stream));
     HIPCHK(d->tids.alloc((size_t)cap + 4)); HIPCHK(hipMemsetAsync(d->tids.p, 0, (cap + 4) * sizeof(unsigned), c->stream));
     HIPCHK(d->boxes.alloc((size_t)cap * 2 + cap + md + 8)); HIPCHK(hipMemsetAsync(d->boxes.p, 0, d->boxes.n * sizeof(bbox_t), c->stream));
     int* ip = d->ints.p;
     S.nlive = ip; S.nfree = ip + 1; S.loc_count = ip + 2; S.upd_count = ip + 3; S.err = ip + 4; ip += 16;
     S.free_slots = ip; ip += cap; S.slot = ip; ip += cap; S.age = ip; ip += cap; S.vis = ip; ip += cap; S.inv = ip; ip += cap;
-    S.rankpos = ip; ip += cap; S.loc_slots = ip; ip += cap; S.upd_slots = ip; ip += cap + md; S.upd_det = ip; ip += cap + md;
+    S.rankpos = ip; ip += cap; S.owner = ip; ip += cap; S.loc_slots = ip; ip += cap; S.upd_slots = ip; ip += cap + md; S.upd_det = ip; ip += cap + md;
     if (multi) { S.cls = ip; ip += cap; S.loc_cls = ip; ip += cap; S.upd_cls = ip; ip += cap + md; S.nfree_c = ip; ip += S.ncls; S.free_c = ip; ip += (size_t)S.ncls * cap; }
     S.next_tid = d->tids.p; S.tid = d->tids.p + 4;
     S.bbox = d->boxes.p; S.pred = S.bbox + cap; S.upd_boxes = S.pred + cap;
@@ -208,14 +213,15 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             HIPCHK(d->det_spec.alloc(d->spec_stride * 3));
             for (int b = 0; b < 3; b++) HIPCHK(hipEventCreateWithFlags(&d->ev_spec[b], MOT_EVENT_FLAGS));
             if (d->defer) {
-                HIPCHK(d->pend.alloc((size_t)cap)); HIPCHK(hipMemset(d->pend.p, 0xFF, sizeof(int) * cap));
+                HIPCHK(d->pend.alloc((size_t)cap)); HIPCHK(hipMemsetAsync(d->pend.p, 0xFF, sizeof(int) * cap, c->stream));   // on the context's stream: see mot_ctx_create
                 S.defer = 1; S.pend_det = d->pend.p;
             }
             d->split = true;
         }
-        if (getenv("MOT_TRACE") && atoi(getenv("MOT_TRACE")) && !multi) { HIPCHK(d->trace.alloc((size_t)32 * cap * 8)); HIPCHK(hipMemset(d->trace.p, 0xFF, sizeof(int) * d->trace.n)); }
+        if (getenv("MOT_TRACE") && atoi(getenv("MOT_TRACE")) && !multi) { HIPCHK(d->trace.alloc((size_t)32 * cap * 8)); HIPCHK(hipMemsetAsync(d->trace.p, 0xFF, sizeof(int) * d->trace.n, c->stream)); }
     }
     else c->kal_free.clear();
+    HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipDeviceSynchronize());   // nothing of the set-up (fills, table uploads) is still in flight when the first frame is enqueued
     c->devloop = d.release();
     *out = c->devloop;
     return MOT_OK;

@@ -1,12 +1,13 @@
-"""Multi-GPU glue: one process per GPU, tracks sharded round-robin by creation id
-(``gpu = tid % world``), ONE all-gather of predicted ``bbox_t`` per frame, then
-replicated association + lifecycle on every rank.
+"""Multi-GPU glue: one process per GPU, tracks sharded round-robin (a spawning track goes
+to the rank that owns the fewest live tracks, lowest rank on a tie: round-robin by
+creation id while nothing dies, balanced under churn), ONE all-gather of predicted
+``bbox_t`` per frame, then replicated association + lifecycle on every rank.
 
 The collective is a plain ``torch.distributed.all_gather_into_tensor`` (backend
 "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).  The message is
-24 B x max_tracks per rank (ownership tid % world drifts under track churn, so a
-segment must hold up to max_tracks boxes) -- 24 KB at 1024 tracks, latency-bound, so
-there is exactly one collective per frame and nothing else on the data path.
+24 B x ceil(max_tracks / world) per rank -- 3 KB at 1024 tracks on 8 GPUs --
+latency-bound, so there is exactly one collective per frame and nothing else on the
+data path.
 """
 from __future__ import annotations
 
@@ -16,31 +17,42 @@ BBOX_BYTES = 24
 
 
 def slots_per_rank(max_tracks: int, world: int) -> int:
-    return max_tracks
+    """boxes in one rank's segment of the all-gather: no rank ever owns more than ceil(max_tracks / world) tracks (assign_owners)"""
+    return max_tracks if world <= 1 else (max_tracks + world - 1) // world
 
 
-def owner_of(tid: int, world: int) -> int:
-    return int(tid) % world
+def assign_owners(owners_kept, n_spawn: int, world: int):
+    """The replicated ownership rule of the device loop (csrc/dl_lifecycle.h, DLState::owner): every spawning track, in detection order, goes to
+    the rank that owns the fewest live tracks at that moment, lowest rank on a tie.  Returns the owners of the n_spawn new tracks."""
+    load = [0] * world
+    for o in owners_kept:
+        load[o] += 1
+    out = []
+    for _ in range(n_spawn):
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += 1
+        out.append(r)
+    return out
 
 
-def local_segment(live_tids, live_boxes: np.ndarray, rank: int, world: int, spr: int) -> np.ndarray:
+def local_segment(owners, live_boxes: np.ndarray, rank: int, world: int, spr: int) -> np.ndarray:
     """What rank `rank` contributes to the all-gather: its own tracks' boxes, in live-list order, padded to spr."""
     seg = np.zeros(spr, live_boxes.dtype)
     j = 0
-    for i, tid in enumerate(live_tids):
-        if owner_of(tid, world) == rank:
+    for i, o in enumerate(owners):
+        if o == rank:
             seg[j] = live_boxes[i]
             j += 1
+    assert j <= spr
     return seg
 
 
-def gathered_to_live_order(gathered: np.ndarray, live_tids, world: int, spr: int) -> np.ndarray:
-    """Inverse mapping executed on device by dl_scatter_kernel (csrc/mot_devloop.hip): live index i reads
-    segment (tid_i % world) at the position i has among that rank's tracks."""
-    out = np.zeros(len(live_tids), gathered.dtype)
+def gathered_to_live_order(gathered: np.ndarray, owners, world: int, spr: int) -> np.ndarray:
+    """Inverse mapping executed on device by dl_scatter_kernel (csrc/mot_devloop.hip): live index i reads the segment of its owner at the
+    position i has among that rank's tracks."""
+    out = np.zeros(len(owners), gathered.dtype)
     cursor = [0] * world
-    for i, tid in enumerate(live_tids):
-        r = owner_of(tid, world)
+    for i, r in enumerate(owners):
         out[i] = gathered[r * spr + cursor[r]]
         cursor[r] += 1
     return out

@@ -119,13 +119,15 @@ def test_device_loop_per_track_template_sizes(mot, oracle, n, lo, hi, miss, fp):
 
 
 def test_device_loop_eight_ranks_on_one_gpu(mot, oracle):
-    """BASELINE configs[3] shape: 1024 tracks sharded tid % 8 over eight contexts (here on one GPU, the all-gather emulated
-    with device copies) must equal the unsharded oracle"""
+    """BASELINE configs[3] shape: 1024 tracks sharded over eight contexts (here on one GPU, the all-gather emulated with device copies) must
+    equal the unsharded oracle.  Round 5: a spawning track goes to the least loaded rank, so a segment holds ceil(1024 / 8) = 128 boxes
+    (3 KB) -- with tracks dying and spawning every frame (2 % misses, 1 % false positives) no rank may overflow it (a sticky device
+    error of live_tracks() otherwise)"""
     from multiple_object_tracking_amd import synth
     hip = C.CDLL("libamdhip64.so")
     W, n = 8, 1024
     scene = synth.Scene(n, 80, stream_id=6, miss_pct=2, fp_pct=1)
-    items = list(scene.frames(4))
+    items = list(scene.frames(6))
     frames = [f for f, _ in items]; dets = [d[:1024] for _, d in items]
     fd, dd, da = _dev(frames, dets, mot)
     ranks = [mot.MotContext(max_tracks=1024, max_dets=1024, rank=r, world=W) for r in range(W)]
@@ -133,6 +135,7 @@ def test_device_loop_eight_ranks_on_one_gpu(mot, oracle):
     for f in range(len(frames)):
         segs = [c.step_begin_device(fd[f].data_ptr()) for c in ranks]
         spr = segs[0][1]
+        assert spr == 128
         for c in ranks:
             c.sync()
         bases = [segs[r][0] - r * spr * 24 for r in range(W)]
@@ -154,7 +157,7 @@ def test_device_loop_eight_ranks_on_one_gpu(mot, oracle):
 
 @pytest.mark.parametrize("n,ahead", [(30, False), (30, True), (700, True)])
 def test_device_loop_sharded_two_ranks(mot, oracle, n, ahead):
-    """two ranks (tid % 2) on one GPU, the all-gather emulated by copies: both reproduce the unsharded oracle.  ahead: the two-call form with
+    """two ranks on one GPU, the all-gather emulated by copies: both reproduce the unsharded oracle.  ahead: the two-call form with
     the detection list and the NEXT frame announced (mot_step_begin_device_ahead) -- at 700 tracks the next frame's detection features are
     then computed one frame early on the side stream of every rank"""
     from multiple_object_tracking_amd import synth
@@ -253,7 +256,7 @@ def test_device_loop_empty_and_bursty_frames(mot, oracle, kind):
 
 
 def test_device_loop_per_track_sizes_two_ranks_on_one_gpu(mot, oracle):
-    """per-track template sizes AND the tid % world shard together: two contexts of one GPU (the all-gather emulated with device
+    """per-track template sizes AND the shard over two ranks together: two contexts of one GPU (the all-gather emulated with device
     copies), 150 tracks of sizes 74..86 with misses and false positives, must equal the unsharded oracle"""
     from multiple_object_tracking_amd import synth
     hip = C.CDLL("libamdhip64.so")
@@ -481,14 +484,18 @@ def _state_hashes(env_extra, args):
 @pytest.mark.parametrize("args", [(48, 128, 8, 4, 9, 21), (30, 32, 30, 0, 8, 33), (300, 1024, 6, 4, 6, 7, "--ahead")])
 def test_folded_geometry_kernels_bit_equal_general_kernels(args):
     """Round-4 advisor finding: the 80 x 80 px kernels with the template geometry folded in as constants (kMode 7: predict, feature, direct update
-    and -- MOT_KCF_K80 bit 3 -- the out-of-line sparse update body, where round 4 once saw a residual update two cells off) must leave the SAME
-    BITS in device memory as the general kernels: model, alpha, pos, scale, flags and response map of every live track, after every frame of
+    kernels) must leave the SAME BITS in device memory as the general kernels: model, alpha, pos, scale, flags and response map of every live track, after every frame of
     noisy streams (tracks that keep their predicted box every frame; the second case has more of them than the residual-update grid has
     workgroups, so its multi-item loop runs).  One process per variant (the switch is read once)."""
     general = _state_hashes({"MOT_KCF_K80": "0"}, args)
     assert len(general) == args[4]
-    for k80 in ("7", "15", "3"):
+    for k80 in ("7", "3"):
         assert _state_hashes({"MOT_KCF_K80": k80}, args) == general, f"MOT_KCF_K80={k80} differs from the general kernels"
+    # bit 3 (the folded copy inside the out-of-line body of the sparse update kernel) is NOT part of the product: that instantiation writes a wrong
+    # model (whole planes; which ones changes with -mllvm -amdgpu-spill-sgpr-to-vgpr, while every shipped kernel is insensitive to that flag:
+    # profiles/README.md, round 5) -- if a compiler release ever fixes it this reminder fails and the variant can be reconsidered
+    if len(args) == 6 and args[0] == 48:
+        assert _state_hashes({"MOT_KCF_K80": "15"}, args) != general, "the folded sparse-update body now equals the general kernels: re-evaluate MOT_KCF_K80 bit 3"
 
 
 def test_finish_refuses_a_different_detection_list(mot):
@@ -503,3 +510,40 @@ def test_finish_refuses_a_different_detection_list(mot):
     with pytest.raises(mot.MotError):
         c.step_finish_device(0, dd[1].data_ptr(), n0)                   # another list than the begin call's
     c.close()
+
+
+def test_setup_fills_are_ordered_before_the_first_frame(mot, oracle):
+    """Round 5's root cause of the "look-ahead flake" (rounds 4-5: about one run in 10^4 of the device loop left the oracle, only when nothing was
+    synchronised between frames and the chip was busy): the set-up filled the pending-detection array with hipMemset(), which for device memory is
+    asynchronous to the host and runs on the NULL stream -- and the context's non-blocking stream does not synchronise with the null stream.  When the
+    fill executed late it wiped what the first frame's lifecycle step had just written, every track's FIRST model update slipped from the second
+    frame's predict to the third's, and near-twin tracks swapped detections (tools/memset_order_probe.hip shows the mechanism in isolation: 20 of 20).
+    Here the null stream is made busy on purpose (a queue of 1 GB fills) before the context exists: with the set-up's fill on the null stream it
+    lands ~100 ms late and this test fails on every run; with every set-up fill on the context's own stream and a device-wide wait at the end of the
+    set-up it passes."""
+    from multiple_object_tracking_amd import synth
+    n = 64
+    scene = synth.Scene(n, 80, stream_id=13)
+    items = list(scene.frames(3))
+    frames = [f for f, _ in items]; dets = [d for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(400):                                                # ~0.1 s of fills queued on the NULL stream (what tools/memset_order_probe.hip does with a spin kernel)
+        assert hip.hipMemsetAsync(C.c_void_p(big.data_ptr()), 0, C.c_size_t(1 << 30), None) == 0
+    c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    c.step_frame_device(fd[0].data_ptr(), dd[0].data_ptr(), len(dets[0]))      # spawns the tracks: pend_det[slot] = detection, first_update = 1
+    torch.cuda.synchronize()                                            # the null stream has drained: a fill that was queued on it has landed by now -- behind frame 0
+    c.step_frame_device(fd[1].data_ptr(), dd[1].data_ptr(), len(dets[1]))      # its predict must run the first update
+    boxes, tids, _ = c.live_tracks()
+    m = orc.OracleMot(oracle, 0, 0, 1024)
+    m.step(frames[0], dets[0]); ref = m.step(frames[1], dets[1])
+    assert np.array_equal(tids, ref["tids"]) and np.array_equal(bnp(boxes), bnp(ref["live"]))
+    for i in range(0, len(tids), 7):
+        xm, al, pos, sc, first, pend = c.live_model(i)
+        assert first == 0, f"track {i}: the first model update did not run in the second frame's predict (pending detection {pend})"
+        assert np.abs(xm).max() > 0 and np.abs(al).max() > 0
+    del big
+    m.close(); c.close()

@@ -99,7 +99,7 @@ def test_bench_sharded_branch_two_ranks_one_gpu():
 def test_bench_eight_ranks_one_gpu():
     """BASELINE configs[3]'s shape -- 1024 tracks sharded 128 per rank over EIGHT ranks -- through bench.py's own launcher on one GPU
     (gloo-staged all-gather: RCCL refuses several ranks on one device).  Smoke test of the 8-process path the driver's SCALE run takes:
-    rendezvous, shard ownership tid % 8, replicated association on eight contexts, one JSON line with eight per-rank rows."""
+    rendezvous, shard ownership over eight ranks, replicated association on eight contexts, one JSON line with eight per-rank rows."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}

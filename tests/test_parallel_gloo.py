@@ -27,24 +27,28 @@ def _worker(rank, world, port, q):
     max_tracks = 37
     spr = par.slots_per_rank(max_tracks, world)
     ok = True
-    tids = []
+    tids = []; owners = []
     next_tid = 0
-    for frame in range(12):
-        # replicated lifecycle: drop some tracks, spawn some (tids keep growing, order is stable)
-        tids = [t for t in tids if rng.integers(0, 10) > 1]
-        for _ in range(int(rng.integers(0, 6))):
-            if len(tids) < max_tracks:
-                tids.append(next_tid); next_tid += 1
+    for frame in range(40):
+        # replicated lifecycle: drop some tracks, spawn some (tids keep growing, order is stable); the owner of a track is part of the
+        # replicated list, a spawning track goes to the least loaded rank (par.assign_owners = the rule of csrc/dl_lifecycle.h)
+        keep = [rng.integers(0, 10) > 1 for _ in tids]
+        tids = [t for t, k in zip(tids, keep) if k]; owners = [o for o, k in zip(owners, keep) if k]
+        n_sp = min(int(rng.integers(0, 9)), max_tracks - len(tids))
+        owners += par.assign_owners(owners, n_sp, world)
+        for _ in range(n_sp):
+            tids.append(next_tid); next_tid += 1
+        ok &= max([owners.count(r) for r in range(world)] + [0]) <= spr   # no rank ever owns more than a segment holds
         boxes = np.zeros(len(tids), dt)
         for i, t in enumerate(tids):                       # the box every rank WOULD predict for tid t this frame
             boxes[i] = (t * 3 + frame, t + frame, t + frame + 79, t * 3 + frame + 79, t % 3, 0.9)
         # each rank only knows its own shard's predictions
-        seg = par.local_segment(tids, boxes, rank, world, spr)
+        seg = par.local_segment(owners, boxes, rank, world, spr)
         local = torch.from_numpy(seg.view(np.uint8).copy())
         gathered = par.all_gather_boxes(local).numpy().view(dt)
-        full = par.gathered_to_live_order(gathered, tids, world, spr)
+        full = par.gathered_to_live_order(gathered, owners, world, spr)
         ok &= bool(np.array_equal(full, boxes))
-        ok &= all(par.owner_of(t, world) == t % world for t in tids)
+        ok &= spr == (max_tracks + world - 1) // world
     dist.barrier()
     q.put((rank, ok))
     dist.destroy_process_group()

@@ -1,8 +1,9 @@
-# round-4 evidence run (GPU box): bench lines, rocprofv3 kernel statistics, PMC passes, association probes.
-# usage: bash tools/collect_profiles.sh     (writes gpurun_out/r04/final/; tools/install_profiles.sh copies the summaries into profiles/)
+# evidence run of a round (GPU box; ROUND=r05 by default): bench lines, rocprofv3 kernel statistics, PMC passes, association probes.
+# usage: [ROUND=r05] bash tools/collect_profiles.sh     (writes gpurun_out/$ROUND/final/; tools/install_profiles.sh copies the summaries into profiles/)
 # Every rocprofv3 run gets a directory of its own, so each holds exactly one result set (no "newest file" guessing).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04/final; rm -rf $O; mkdir -p $O
+ROUND=${ROUND:-r05}
+O=gpurun_out/$ROUND/final; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_n1024.json 2> $O/bench_n1024.err
 python bench.py --steps 20 --warmup 5 > $O/bench_n1024_driver.json 2>/dev/null
 python bench.py --tracks 64 --no-cpu-baseline > $O/bench_n64.json 2>/dev/null
@@ -23,6 +24,11 @@ python tools/assoc_probe.py 1024 30 > $O/assoc_probe_n1024.log 2>&1
 python tools/assoc_trace.py 1024 23 8 > $O/assoc_trace_n1024_frame23.log 2>&1
 python tools/assoc_trace.py 1024 7 8 > $O/assoc_trace_n1024_frame7.log 2>&1
 ./tools/ubench_latency > $O/ubench_latency.log 2>&1
+# round 5: what each phase costs the predict LAUNCH (probe build), two workgroups per CU against one; small-frame histogram A/B; event-scope probe
+python tools/kcf_ablate.py --reps 8 > $O/kcf_ablate_n1024.log 2>&1
+MOT_KCF_ONE_PER_CU=1 python tools/kcf_ablate.py --reps 6 --only-base > $O/kcf_ablate_n1024_one_per_cu.log 2>&1
+MOT_KCF_K80=23 python bench.py --tracks 64 --no-cpu-baseline --h2d 0 > $O/bench_n64_sequential_histogram.json 2>/dev/null
+./tools/event_scope_probe 50000 56 1 > $O/event_scope_probe.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_default -- python3 bench.py --no-cpu-baseline --h2d 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_driver -- python3 bench.py --steps 20 --warmup 5 --steady 0 --h2d 0 --profile-frames 0 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_s148 -- python3 bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline --h2d 0 > /dev/null 2>&1

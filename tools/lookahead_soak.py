@@ -28,6 +28,7 @@ ap.add_argument("--hammer", action="store_true"); ap.add_argument("--sparse-chec
 ap.add_argument("--dump", default=os.path.join(ROOT, "gpurun_out", "soak")); ap.add_argument("--wrong-at", type=int, default=5)
 ap.add_argument("--cap", type=int, default=1024); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--state", action="store_true"); ap.add_argument("--state-stride", type=int, default=1)
+ap.add_argument("--frames", type=int, default=9, help="frames per repetition (default 9; with --sparse-checks --state a short run compares the complete device state at its end)")
 ap.add_argument("--trace", action="store_true", help="MOT_TRACE=1: the predict / update launches leave one record per workgroup (32 bytes); a wrong run is compared with the last good one record by record")
 ap.add_argument("--snap", action="store_true", help="record a stream-ordered device snapshot behind every frame (mot_debug_snapshot, no host synchronisation) and, when the run ends wrong, report frame by frame where it left the oracle")
 a = ap.parse_args()
@@ -53,7 +54,7 @@ def spin(us):
 
 
 oracle = orc.load_oracle()
-nframes = 9
+nframes = a.frames
 scene = synth.Scene(a.n, 80, stream_id=7, miss_pct=a.miss, fp_pct=a.fp)
 items = list(scene.frames(nframes))
 frames = [f for f, _ in items]; dets = [d[:a.cap] for _, d in items]
@@ -170,6 +171,7 @@ for rep in range(a.reps):
             ok = np.array_equal(tids, ref["tids"]) and all(np.array_equal(boxes[k], ref["live"][k]) for k in KEYS)
             if ok and a.state:
                 st = state_of(c, len(tids))
+                n_state_checks = globals().get("n_state_checks", 0) + 1
                 if rep == 0:
                     state0[f] = st
                 else:

@@ -22,7 +22,7 @@ int run_rank(int rank, int world, ncclComm_t comm, const void* const* frames_dev
 {
     mot_config cfg; mot_config_default(&cfg);
     cfg.device = rank; cfg.tracker_kind = MOT_TRACKER_KCF; cfg.max_tracks = 1024; cfg.max_dets = 1024;
-    cfg.rank = rank; cfg.world = world;                                 // tracks sharded tid % world
+    cfg.rank = rank; cfg.world = world;                                 // tracks sharded round-robin / least-loaded rank
     mot_ctx* ctx = nullptr;
     if (mot_ctx_create(&cfg, &ctx) != MOT_OK) { std::fprintf(stderr, "rank %d: %s\n", rank, mot_last_error()); return 1; }
     for (int f = 0; f < n_frames; f++)                                  // predict -> ncclAllGather(bbox_t) -> association -> update, enqueued only
