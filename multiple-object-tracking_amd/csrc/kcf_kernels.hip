@@ -316,10 +316,11 @@ __device__ void phase_gradmag(const KcfPool& p, const float* __restrict__ P, flo
 // ---------------------------------------------------------------------------
 // NPRE (HBM-slab templates): the footprint columns are loaded four at a time, all in flight at once, because there every
 // load is an L2 round trip; the LDS-resident kernels load column by column.
-// BATCH: the eight read-modify-writes of a footprint column resolved in registers -- 8 instead of 64 dependent LDS round trips per cell, at the price of
-// 56 more instructions per column.  Round 5 measured both ways: a launch that FILLS the chip (1024 tracks, two workgroups per CU) is bound by what it
-// issues, not by one workgroup's latency, and gets slower (isolated predict launch 88 -> 92 us); a small joined launch (one workgroup per CU) waits
-// for exactly this chain.  So only the small-frame kernel takes it.
+// BATCH (compile-time A/B, -DMOT_HIST_BATCH=1; off): the eight read-modify-writes of a footprint column resolved in registers -- 8 instead of 64
+// dependent LDS round trips per cell, at the price of 56 more instructions per column.  Round 5 measured it both ways and it loses both: a launch that
+// FILLS the chip (1024 tracks, two workgroups per CU) is bound by what it issues, not by one workgroup's latency (isolated predict launch 88 -> 92 us,
+// profiles/r05_kernel_ab_hist_grad.log), and a small joined launch (64 tracks, one workgroup per CU) does not gain either (36.5 against 36.1 us,
+// profiles/r05_bench_n64*.json).
 template <int NPRE, bool LDSACC = true, bool BATCH = (MOT_HIST_BATCH != 0)>   // LDSACC: the accumulators live in LDS (false only for the FHOG-only test kernel of templates beyond the LDS)
 __device__ void phase_hist(const KcfPool& p, const float* __restrict__ Mq, const uint8_t* __restrict__ bins,
                            float* __restrict__ R1, float* __restrict__ scratch, int tid, int nt, int cell_lo = 0, int cell_hi = -1)
@@ -1897,7 +1898,7 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
 // Small frames (predict + feature workgroups fit the chip together): ONE launch carries both -- workgroups [0, n_pred) predict the
 // tracks, workgroups [n_pred, n_pred + n_feat) compute the detection spectra of the split update.  No side stream, no event pair, no
 // cross-stream wait: at 64 tracks those cost more than the kernels' own work.
-template <int kMode, bool kHB = (MOT_HIST_BATCH != 0)>   // kHB: the launch leaves every workgroup alone on its CU (<= 256 workgroups): latency-bound, see phase_hist
+template <int kMode, bool kHB = (MOT_HIST_BATCH != 0)>   // kHB: phase_hist's BATCH (compile-time A/B)
 __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_predict_features_kernel(const KcfPool p, const KcfLaunch lp, const KcfLaunch lf, int n_pred, int n_feat)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2107,13 +2108,6 @@ hipError_t launch_kcf_predict_features(const KcfPool& p, const KcfLaunch& lp_in,
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     if (n_pred + n_feat <= 0) return hipSuccess;
     const size_t lds = kcf_lds_bytes(p);
-    // small frames (every workgroup alone on its CU) with the 80 x 80 px template: the instantiation with the batched histogram (phase_hist);
-    // MOT_KCF_K80 bit 4 (16) switches it off
-    if (p.use_lds && p.fft20 && p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1) && !(mot_impl::env().k80 & 16) && n_pred + n_feat <= 256) {
-        hipError_t e_ = set_lds_attr(kcf_predict_features_kernel<7, true>, lds); if (e_ != hipSuccess) return e_;
-        hipLaunchKernelGGL((kcf_predict_features_kernel<7, true>), dim3(n_pred + n_feat), dim3(MOT_KCF_THREADS), lds, s, p, lp, lf, n_pred, n_feat);
-        return hipGetLastError();
-    }
     KCF_LAUNCH3(kcf_predict_features_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 1)), n_pred + n_feat, lds, s, p, lp, lf, n_pred, n_feat);
     return hipGetLastError();
 }

@@ -491,6 +491,10 @@ def test_folded_geometry_kernels_bit_equal_general_kernels(args):
     assert len(general) == args[4]
     for k80 in ("7", "3"):
         assert _state_hashes({"MOT_KCF_K80": k80}, args) == general, f"MOT_KCF_K80={k80} differs from the general kernels"
+    # the DIRECT update kernel (every update of a frame when the blend is not deferred): its <7> instantiation holds the folded copy inlined
+    if len(args) == 6:
+        assert _state_hashes({"MOT_KCF_K80": "7", "MOT_DEFER_BLEND": "0"}, args) == _state_hashes({"MOT_KCF_K80": "0", "MOT_DEFER_BLEND": "0"}, args), \
+            "direct update kernel: folded <7> differs from the general <1>"
     # bit 3 (the folded copy inside the out-of-line body of the sparse update kernel) is NOT part of the product: that instantiation writes a wrong
     # model (whole planes; which ones changes with -mllvm -amdgpu-spill-sgpr-to-vgpr, while every shipped kernel is insensitive to that flag:
     # profiles/README.md, round 5) -- if a compiler release ever fixes it this reminder fails and the variant can be reconsidered
@@ -515,12 +519,13 @@ def test_finish_refuses_a_different_detection_list(mot):
 def test_setup_fills_are_ordered_before_the_first_frame(mot, oracle):
     """Round 5's root cause of the "look-ahead flake" (rounds 4-5: about one run in 10^4 of the device loop left the oracle, only when nothing was
     synchronised between frames and the chip was busy): the set-up filled the pending-detection array with hipMemset(), which for device memory is
-    asynchronous to the host and runs on the NULL stream -- and the context's non-blocking stream does not synchronise with the null stream.  When the
-    fill executed late it wiped what the first frame's lifecycle step had just written, every track's FIRST model update slipped from the second
-    frame's predict to the third's, and near-twin tracks swapped detections (tools/memset_order_probe.hip shows the mechanism in isolation: 20 of 20).
-    Here the null stream is made busy on purpose (a queue of 1 GB fills) before the context exists: with the set-up's fill on the null stream it
-    lands ~100 ms late and this test fails on every run; with every set-up fill on the context's own stream and a device-wide wait at the end of the
-    set-up it passes."""
+    asynchronous to the host and runs on the NULL stream -- and the context's non-blocking stream does not synchronise with the null stream
+    (tools/memset_order_probe.hip shows the mechanism in isolation: 20 of 20).  When the fill executed late it wiped what the first frame's lifecycle
+    step had just written, every track's FIRST model update slipped from the second frame's predict to the third's, and near-twin tracks swapped
+    detections (tests/test_flake_replay.py reproduces two failing runs box for box on the CPU).  This test keeps the null stream busy in front of the
+    first step call and requires the first update to have run in the second frame's predict.  (It is a sanity check, not a discriminator: in a library
+    built before the fix the pool set-up's synchronous table uploads happen to drain the null stream just before the critical fill, so the late fill
+    needs a busy CHIP, which only the soak provides -- profiles/r05_hunt_soak.log.  tests/test_abi_symbols.py keeps hipMemset( out of the product.)"""
     from multiple_object_tracking_amd import synth
     n = 64
     scene = synth.Scene(n, 80, stream_id=13)
@@ -531,9 +536,9 @@ def test_setup_fills_are_ordered_before_the_first_frame(mot, oracle):
     hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
     big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    for _ in range(400):                                                # ~0.1 s of fills queued on the NULL stream (what tools/memset_order_probe.hip does with a spin kernel)
-        assert hip.hipMemsetAsync(C.c_void_p(big.data_ptr()), 0, C.c_size_t(1 << 30), None) == 0
     c = mot.MotContext(max_tracks=1024, max_dets=1024)
+    for _ in range(600):                                                # ~0.15 s of fills queued on the NULL stream (what tools/memset_order_probe.hip does with a spin kernel),
+        assert hip.hipMemsetAsync(C.c_void_p(big.data_ptr()), 0, C.c_size_t(1 << 30), None) == 0   # right in front of the first step: the device loop's set-up runs inside it
     c.step_frame_device(fd[0].data_ptr(), dd[0].data_ptr(), len(dets[0]))      # spawns the tracks: pend_det[slot] = detection, first_update = 1
     torch.cuda.synchronize()                                            # the null stream has drained: a fill that was queued on it has landed by now -- behind frame 0
     c.step_frame_device(fd[1].data_ptr(), dd[1].data_ptr(), len(dets[1]))      # its predict must run the first update

@@ -27,7 +27,6 @@ python tools/assoc_trace.py 1024 7 8 > $O/assoc_trace_n1024_frame7.log 2>&1
 # round 5: what each phase costs the predict LAUNCH (probe build), two workgroups per CU against one; small-frame histogram A/B; event-scope probe
 python tools/kcf_ablate.py --reps 8 > $O/kcf_ablate_n1024.log 2>&1
 MOT_KCF_ONE_PER_CU=1 python tools/kcf_ablate.py --reps 6 --only-base > $O/kcf_ablate_n1024_one_per_cu.log 2>&1
-MOT_KCF_K80=23 python bench.py --tracks 64 --no-cpu-baseline --h2d 0 > $O/bench_n64_sequential_histogram.json 2>/dev/null
 ./tools/event_scope_probe 50000 56 1 > $O/event_scope_probe.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_default -- python3 bench.py --no-cpu-baseline --h2d 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_driver -- python3 bench.py --steps 20 --warmup 5 --steady 0 --h2d 0 --profile-frames 0 --no-cpu-baseline > /dev/null 2>&1

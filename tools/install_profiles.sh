@@ -27,4 +27,4 @@ cp $(one "$R/pmc_write_s148/*/*_counter_collection.csv") profiles/${ROUND}_pmc_w
 python tools/derive_traffic.py profiles/${ROUND}_pmc_fetch_size_s148.csv profiles/${ROUND}_pmc_write_size_s148.csv 256 > profiles/${ROUND}_traffic_s148.json
 python tools/derive_sq.py $(one "$R/pmc_sq_s148/*/*_counter_collection.csv") > profiles/${ROUND}_sq_counters_s148.json
 cp $R/kcf_ablate_n1024.log profiles/${ROUND}_kcf_ablate_n1024.log; cp $R/kcf_ablate_n1024_one_per_cu.log profiles/${ROUND}_kcf_ablate_n1024_one_per_cu.log
-cp $R/bench_n64_sequential_histogram.json profiles/${ROUND}_bench_n64_sequential_histogram.json; cp $R/event_scope_probe.log profiles/${ROUND}_event_scope_probe.log
+cp $R/event_scope_probe.log profiles/${ROUND}_event_scope_probe.log
