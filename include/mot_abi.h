@@ -223,6 +223,13 @@ int mot_step_frame_sharded_ahead(mot_ctx* ctx, const void* frame_dev, const void
  * from the look-ahead launch, for that list): a different pointer or count is refused with MOT_ERR_ARG. */
 int mot_step_begin_device_ahead(mot_ctx* ctx, const void* frame_dev, const void* dets_dev, int nD,
                                 const void* next_frame_dev, const void* next_dets_dev, int next_nD, void** local_boxes_dev, int* slots_per_rank);
+/* Checkpoint / resume of the device-resident loop (single template size): mot_state_save writes one flat host record -- live list and counters,
+ * per-slot tracker state (KCF: model, alpha, pos, scale, flags, response maps, pending detections and the spectra they refer to; Kalman: x, P) --
+ * and reports its size through *bytes (host_buf may be null to ask for it); mot_state_load puts it into a FRESH context of the same
+ * configuration (tracker kind, capacities, template size, rank / world, frame structure switches), after which the loop continues bit for bit as
+ * the saved one would have.  Both synchronise the context (all its streams). */
+int mot_state_save(mot_ctx* ctx, void* host_buf, size_t cap_bytes, size_t* bytes);
+int mot_state_load(mot_ctx* ctx, const void* host_buf, size_t bytes);
 int mot_live_count(mot_ctx* ctx, int* n_live);
 int mot_live_tracks(mot_ctx* ctx, bbox_t* boxes, unsigned* tids, int* ages, int* n_live);
 

@@ -366,6 +366,19 @@ class MotContext:
         self._chk(self.lib.mot_get_assoc_stats(self._h, _vp(out)))
         return out
 
+    def state_save(self) -> np.ndarray:
+        """checkpoint of the device-resident loop as one uint8 record (mot_state_save)"""
+        n = C.c_size_t(0)
+        self._chk(self.lib.mot_state_save(self._h, None, C.c_size_t(0), C.byref(n)))
+        buf = np.zeros(n.value, np.uint8)
+        self._chk(self.lib.mot_state_save(self._h, _vp(buf), C.c_size_t(n.value), None))
+        return buf
+
+    def state_load(self, record: np.ndarray):
+        """resume from a record of state_save() (fresh context of the same configuration)"""
+        rec = np.ascontiguousarray(record, np.uint8)
+        self._chk(self.lib.mot_state_load(self._h, _vp(rec), C.c_size_t(rec.size)))
+
     def debug_trace(self):
         """(MOT_TRACE=1) int32 [2][16][max_tracks][8]: predict / update records of the last 16 frames by (frame & 15, slot); None when tracing is off"""
         n = C.c_size_t(0)

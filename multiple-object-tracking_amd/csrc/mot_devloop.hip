@@ -751,6 +751,94 @@ int mot_debug_trace_read(mot_ctx* c, int* out, size_t cap_ints, size_t* n_ints)
     return MOT_OK;
 }
 
+// ---- checkpoint / resume of the device-resident loop (state dump / load) -------------------------------------------------
+// One flat host record: header, the live list and its counters (the int arena, ids, boxes), the per-slot tracker state (KCF: model, alpha, pos,
+// scale, first-update flag, response map, pending detection + the spectra of the last frame's detections, which the next predict blends in first;
+// Kalman: x, P).  Loading needs a FRESH context of the same configuration; the loop then continues bit for bit as the saved one would have
+// (tests/test_gpu_devloop.py::test_state_save_load_resumes_bit_for_bit).  Single template size only (no size classes).
+namespace {
+struct StateHeader { unsigned magic, version; int kind, cap, max_dets, rows, cols, world, rank, defer, split, nbins, nb; unsigned frame_no; unsigned long long ints_n, tids_n, boxes_n, spec_n, total; };
+const unsigned kStateMagic = 0x4D4F5453u;   // "MOTS"
+struct StatePart { void* dev; size_t bytes; };
+int state_parts(mot_ctx* c, DevLoop* d, std::vector<StatePart>& parts, StateHeader& h)
+{
+    const DLState& S = d->S;
+    if (S.ncls > 1) return fail(MOT_ERR_STATE, "state save / load: per-track template sizes are not supported");
+    memset(&h, 0, sizeof h);
+    h.magic = kStateMagic; h.version = 1; h.kind = S.kind; h.cap = S.cap; h.max_dets = S.max_dets; h.rows = S.rows; h.cols = S.cols; h.world = S.world; h.rank = S.rank;
+    h.defer = d->defer ? 1 : 0; h.split = d->split ? 1 : 0; h.frame_no = d->frame_no;
+    h.ints_n = d->ints.n; h.tids_n = d->tids.n; h.boxes_n = d->boxes.n;
+    parts.push_back({d->ints.p, d->ints.n * sizeof(int)}); parts.push_back({d->tids.p, d->tids.n * sizeof(unsigned)}); parts.push_back({d->boxes.p, d->boxes.n * sizeof(bbox_t)});
+    if (S.kind == MOT_TRACKER_KCF) {
+        PoolHost& ph = *c->pools[d->pool];
+        h.nbins = ph.dev.nbins; h.nb = ph.dev.nb;
+        parts.push_back({ph.xm.p, ph.xm.n * sizeof(float2)}); parts.push_back({ph.alpha.p, ph.alpha.n * sizeof(float)}); parts.push_back({ph.pos.p, ph.pos.n * sizeof(bbox_t)});
+        parts.push_back({ph.scale.p, ph.scale.n * sizeof(float2)}); parts.push_back({ph.first.p, ph.first.n * sizeof(int)}); parts.push_back({ph.response.p, ph.response.n * sizeof(float)});
+        if (d->defer) {
+            h.spec_n = d->spec_stride;
+            parts.push_back({d->pend.p, d->pend.n * sizeof(int)});
+            parts.push_back({d->det_spec.p + (size_t)d->buf_prev * d->spec_stride, d->spec_stride * sizeof(float2)});   // the last frame's detection spectra (pending blends read them)
+        }
+    } else {
+        parts.push_back({c->kal_x.p, c->kal_x.n * sizeof(double)}); parts.push_back({c->kal_P.p, c->kal_P.n * sizeof(double)});
+        parts.push_back({c->d_gather.p, c->d_gather.n * sizeof(bbox_t)});     // the Kalman predict is in / out on the boxes the lifecycle step left in the segment (kalman.cpp:112-115)
+    }
+    size_t total = sizeof(StateHeader);
+    for (const StatePart& p : parts) total += p.bytes;
+    h.total = total;
+    return MOT_OK;
+}
+int quiesce(mot_ctx* c, DevLoop* d)
+{
+    if (d->begun) return fail(MOT_ERR_STATE, "state save / load between mot_step_begin_device and mot_step_finish_device");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (d->side) HIPCHK(hipStreamSynchronize(d->side));
+    if (d->copy) HIPCHK(hipStreamSynchronize(d->copy));
+    return devloop_check(c);
+}
+} // namespace
+
+int mot_state_save(mot_ctx* c, void* host_buf, size_t cap_bytes, size_t* bytes)
+{
+    if (!c) return fail(MOT_ERR_ARG, "null ctx");
+    int rc = ensure_device(c); if (rc) return rc;
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    std::vector<StatePart> parts; StateHeader h;
+    rc = state_parts(c, d, parts, h); if (rc) return rc;
+    if (bytes) *bytes = (size_t)h.total;
+    if (!host_buf) return MOT_OK;
+    if (cap_bytes < h.total) return fail(MOT_ERR_CAPACITY, "state record needs %llu bytes, buffer holds %zu", h.total, cap_bytes);
+    rc = quiesce(c, d); if (rc) return rc;
+    char* q = (char*)host_buf;
+    memcpy(q, &h, sizeof h); q += sizeof h;
+    for (const StatePart& p : parts) { HIPCHK(hipMemcpy(q, p.dev, p.bytes, hipMemcpyDeviceToHost)); q += p.bytes; }
+    return MOT_OK;
+}
+
+int mot_state_load(mot_ctx* c, const void* host_buf, size_t bytes)
+{
+    if (!c || !host_buf || bytes < sizeof(StateHeader)) return fail(MOT_ERR_ARG, "bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    if (c->devloop && c->devloop->frame_no != 0) return fail(MOT_ERR_STATE, "mot_state_load needs a fresh context (this one has already stepped %u frames)", c->devloop->frame_no);
+    DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
+    std::vector<StatePart> parts; StateHeader h, in;
+    rc = state_parts(c, d, parts, h); if (rc) return rc;
+    memcpy(&in, host_buf, sizeof in);
+    if (in.magic != kStateMagic || in.version != 1) return fail(MOT_ERR_ARG, "not a state record of this library version");
+    if (in.kind != h.kind || in.cap != h.cap || in.max_dets != h.max_dets || in.rows != h.rows || in.cols != h.cols || in.world != h.world || in.rank != h.rank ||
+        in.defer != h.defer || in.split != h.split || in.ints_n != h.ints_n || in.tids_n != h.tids_n || in.boxes_n != h.boxes_n || in.spec_n != h.spec_n || in.nbins != h.nbins || in.total != h.total || bytes < in.total)
+        return fail(MOT_ERR_ARG, "state record does not fit this context (tracker kind, capacities, template size, rank / world or frame structure differ)");
+    rc = quiesce(c, d); if (rc) return rc;
+    // the spectra of the saved frame go into the buffer this context regards as "previous" (a fresh context: buffer 0)
+    const char* q = (const char*)host_buf + sizeof in;
+    for (const StatePart& p : parts) { HIPCHK(hipMemcpy(p.dev, q, p.bytes, hipMemcpyHostToDevice)); q += p.bytes; }
+    HIPCHK(hipDeviceSynchronize());
+    d->frame_no = in.frame_no;
+    d->pf_valid = false; d->have_cur = false; d->feat_early = false; d->feat_joined = false; d->mid_valid = false; d->mid_by_predict = false;
+    for (bool& b : d->spec_side) b = false;
+    return MOT_OK;
+}
+
 int mot_live_tracks(mot_ctx* c, bbox_t* boxes, unsigned* tids, int* ages, int* n_live)
 {
     if (!c) return fail(MOT_ERR_ARG, "null ctx");

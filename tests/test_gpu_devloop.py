@@ -552,3 +552,54 @@ def test_setup_fills_are_ordered_before_the_first_frame(mot, oracle):
         assert np.abs(xm).max() > 0 and np.abs(al).max() > 0
     del big
     m.close(); c.close()
+
+
+def _full_state(c):
+    boxes, tids, ages = c.live_tracks()
+    parts = [bnp(boxes).tobytes(), tids.tobytes(), ages.tobytes()]
+    for i in range(len(tids)):
+        xm, al, pos, sc, first, pend = c.live_model(i)
+        if first:                                                       # never predicted: the slot still holds its previous owner's model
+            xm = np.zeros_like(xm); al = np.zeros_like(al); resp = np.zeros(1, np.float32)
+        else:
+            resp = c.live_response(i)
+        parts += [xm.tobytes(), al.tobytes(), pos.tobytes(), sc.tobytes(), resp.tobytes(), bytes([first & 255, pend & 255, (pend >> 8) & 255])]
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("kind,n,cap", [(0, 120, 256), (0, 300, 1024), (1, 60, 128)])
+def test_state_save_load_resumes_bit_for_bit(mot, oracle, kind, n, cap):
+    """mot_state_save / mot_state_load (state dump / load): a stream is run for 5 frames, checkpointed into a host record and
+    resumed in a FRESH context; frames 5..9 of the resumed loop must give the oracle's live lists, and -- KCF -- leave the same bits in device memory
+    as the uninterrupted run (models, alphas, positions, flags, response maps of every live track).  Noisy streams: tracks die, spawn and keep their
+    predicted boxes across the checkpoint; the pending (deferred) model updates and the spectra they refer to travel with the record."""
+    from multiple_object_tracking_amd import synth
+    scene = synth.Scene(n, 80, stream_id=31 + kind, miss_pct=5, fp_pct=3)
+    items = list(scene.frames(10))
+    frames = [f for f, _ in items]; dets = [d[:cap] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    m = orc.OracleMot(oracle, kind, 0, cap)
+    refs = [m.step(frames[f], dets[f]) for f in range(10)]
+    m.close()
+
+    def run(c, f0, f1):
+        for f in range(f0, f1):
+            c.step_frame_device(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]))
+            boxes, tids, _ = c.live_tracks()
+            assert np.array_equal(tids, refs[f]["tids"]) and np.array_equal(bnp(boxes), bnp(refs[f]["live"])), f"frame {f}"
+    a = mot.MotContext(tracker_kind=kind, max_tracks=cap, max_dets=cap)
+    run(a, 0, 10)
+    end_a = _full_state(a) if kind == 0 else None
+    a.close()
+    b = mot.MotContext(tracker_kind=kind, max_tracks=cap, max_dets=cap)
+    run(b, 0, 5)
+    record = b.state_save()
+    b.close()
+    c = mot.MotContext(tracker_kind=kind, max_tracks=cap, max_dets=cap)
+    c.state_load(record)
+    run(c, 5, 10)
+    if kind == 0:
+        assert _full_state(c) == end_a, "the resumed loop left different bits in device memory than the uninterrupted one"
+    with pytest.raises(mot.MotError):
+        c.state_load(record)                                            # not a fresh context any more
+    c.close()
