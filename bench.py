@@ -373,15 +373,21 @@ def main():
         # the line so a scaling run can be checked against DESIGN.md section 5's table
         rank_stages = None
         if n_rank_prof:
-            acc4 = np.zeros(4)
-            for _ in range(n_rank_prof):
-                ctx.debug_profile_stages(True)
-                step(f); f += 1
-                acc4 += ctx.debug_profile_stages(False, read=True)
-            mine = {"rank": rank, **{k: float(v) for k, v in zip(("predict_ms", "gather_ms", "chain_ms", "update_ms"), acc4 / n_rank_prof)}}
+            try:                                                        # an informative leg: it must never cost the line
+                acc4 = np.zeros(4)
+                for _ in range(n_rank_prof):
+                    ctx.debug_profile_stages(True)
+                    step(f); f += 1
+                    acc4 += ctx.debug_profile_stages(False, read=True)
+                mine = {"rank": rank, **{k: float(v) for k, v in zip(("predict_ms", "gather_ms", "chain_ms", "update_ms"), acc4 / n_rank_prof)}}
+            except Exception as e:
+                mine = {"rank": rank, "error": str(e)[:200]}
             rows = [None] * world
-            dist.all_gather_object(rows, mine)
-            rank_stages = rows
+            try:
+                dist.all_gather_object(rows, mine)
+                rank_stages = rows
+            except Exception as e:
+                rank_stages = [{"rank": rank, "error": "all_gather_object: " + str(e)[:200]}]
 
         # the predict launch as it runs IN the loop (look-ahead feature launch beside it, deferred blend in its prologue): its own begin / end
         # stamps over 20 ordinary frames -- the duration rocprofv3 --kernel-trace reports for it in this configuration (roofline.avg_launch_ms)
