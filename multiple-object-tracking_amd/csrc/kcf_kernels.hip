@@ -1818,17 +1818,25 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
 // the pool descriptor by reference, which makes the compiler copy the by-value kernel arguments to private memory in the kernel's ENTRY block (19
 // scratch stores per lane: 20 MB and 4 us per empty launch when the body was inlined here); the body is therefore a function of its own that
 // receives the descriptors BY VALUE -- the copy happens at the call, behind the test.
-// kView stays false here (kMode 7): with the folded copy of the descriptor (pool_view) inside THIS function one residual update of a noisy stream
-// (tests/test_gpu_devloop.py::test_device_loop_vs_oracle[0-48-80-9], frame 8) came out two cells off, reproducibly, while the same folded copy in
-// the direct update kernel, the predict and the feature kernels passes every test and is bit-identical to the general kernels on every stream tried:
-// a code-generation issue around the by-value descriptor of an out-of-line function, not pursued.
+// kView stays false here (kMode 7).  With the folded copy of the descriptor (pool_view) inside THIS function hipcc (ROCm 7.2) emits a wrong
+// program: behind the divergent loop of the second channel half's transform the exit block holds seven v_mov_b64 -- the undo of a register
+// rotation the allocator split around the loop -- IN FRONT OF the EXEC restore (the loop's own restore was folded into the enclosing region's,
+// -amdgpu-remove-redundant-endcf), so they run for no lane and the old-model registers xold[7], [9], [11], [13] keep foreign values: a wrong
+// model in exactly those slots of every thread (tests/test_gpu_devloop.py::test_device_loop_vs_oracle[0-48-80-9], frame 8, came out two cells
+// off).  tools/isa_exec0_scan.py finds the pattern in code objects; over the 12,000 loop exits / joins of the shipped library this function
+// was the only hit, and with -mllvm -amdgpu-remove-redundant-endcf=0 it is gone and the results equal the general kernels' (DESIGN.md
+// section 6).  The instantiation is compiled only for that demonstration (-DMOT_KCF_SPARSE_VIEW=1, `make endcf`).
 template <int kMode, bool kView = false>
 __device__ __attribute__((noinline)) void kcf_update_sparse_run(KcfPool p, KcfLaunch l, int cnt)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int item = blockIdx.x; item < cnt; item += gridDim.x) { kcf_update_body<kMode, kView>(p, l, item, smem); __syncthreads(); }
 }
-// (investigation, MOT_KCF_K80 bit 3) the folded descriptor inside the out-of-line body as well
+#ifndef MOT_KCF_SPARSE_VIEW
+#define MOT_KCF_SPARSE_VIEW 0
+#endif
+#if MOT_KCF_SPARSE_VIEW
+// (demonstration builds only, MOT_KCF_K80 bit 3) the folded descriptor inside the out-of-line body as well: see above
 template <int kMode>
 __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_view_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
@@ -1836,6 +1844,7 @@ __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREAD
     if ((int)blockIdx.x >= cnt) return;
     kcf_update_sparse_run<kMode, true>(p, l, cnt);
 }
+#endif
 template <int kMode>
 __global__ void __launch_bounds__((kMode & 1) ? MOT_KCF_THREADS : MOT_KCF_THREADS_SLAB, ((kMode & 1) || MOT_KCF_THREADS_SLAB > 512) ? 4 : 2) kcf_update_sparse_kernel(const KcfPool p, const KcfLaunch l, int n)
 {
@@ -2134,11 +2143,14 @@ hipError_t launch_kcf_update(const KcfPool& p, const KcfLaunch& l_in, int n, hip
         KCF_LAUNCH3(kcf_features_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 2)), n, lds, s, p, l, n);
         return hipGetLastError();
     }
+#if MOT_KCF_SPARSE_VIEW
     if (l.grid_stride && p.use_lds && p.fft20 && p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 8)) {
         hipError_t e_ = set_lds_attr(kcf_update_sparse_view_kernel<7>, lds); if (e_ != hipSuccess) return e_;
         hipLaunchKernelGGL(kcf_update_sparse_view_kernel<7>, dim3(grid), dim3(MOT_KCF_THREADS), lds, s, p, l, n);
+        return hipGetLastError();
     }
-    else if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 4)), grid, lds, s, p, l, n);
+#endif
+    if (l.grid_stride) KCF_LAUNCH3(kcf_update_sparse_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 4)), grid, lds, s, p, l, n);
     else KCF_LAUNCH3(kcf_update_kernel, 2, 5, p.r1_lds, !p.fft20, (p.rows == 80 && p.cols == 80 && (mot_impl::env().k80 & 4)), grid, lds, s, p, l, n);
     return hipGetLastError();
 }

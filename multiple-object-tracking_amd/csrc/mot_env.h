@@ -27,8 +27,8 @@ struct EnvSwitches {
     int dft_mfma;            // MOT_DFT_MFMA=0: HBM-slab templates use the generic DFT instead of the MFMA products
     int dft_inplace;         // MOT_DFT_INPLACE=0: LDS-resident templates with the direct transforms keep the ping-pong buffer (region T)
     int k80;                 // MOT_KCF_K80: which kernels of an 80 x 80 px pool run with the geometry folded in (bit 0 predict, 1 feature, 2 update; default 7, 0: none);
-                             // bit 3 (8, investigation only): the folded copy inside the out-of-line body of the sparse update kernel as well -- a build in which hipcc's
-                             // SGPR spilling to VGPR lanes corrupts part of that function's model write-back (profiles/README.md)
+                             // bit 3 (8; only in builds with -DMOT_KCF_SPARSE_VIEW=1, `make endcf`): the folded copy inside the out-of-line body of the sparse update
+                             // kernel as well -- the instantiation hipcc miscompiles (register copies in front of a folded EXEC restore: kcf_update_sparse_run)
     int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)

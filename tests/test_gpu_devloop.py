@@ -495,11 +495,24 @@ def test_folded_geometry_kernels_bit_equal_general_kernels(args):
     if len(args) == 6:
         assert _state_hashes({"MOT_KCF_K80": "7", "MOT_DEFER_BLEND": "0"}, args) == _state_hashes({"MOT_KCF_K80": "0", "MOT_DEFER_BLEND": "0"}, args), \
             "direct update kernel: folded <7> differs from the general <1>"
-    # bit 3 (the folded copy inside the out-of-line body of the sparse update kernel) is NOT part of the product: that instantiation writes a wrong
-    # model (whole planes; which ones changes with -mllvm -amdgpu-spill-sgpr-to-vgpr, while every shipped kernel is insensitive to that flag:
-    # profiles/README.md, round 5) -- if a compiler release ever fixes it this reminder fails and the variant can be reconsidered
-    if len(args) == 6 and args[0] == 48:
-        assert _state_hashes({"MOT_KCF_K80": "15"}, args) != general, "the folded sparse-update body now equals the general kernels: re-evaluate MOT_KCF_K80 bit 3"
+
+
+def test_sparse_view_miscompile_and_its_fix():
+    """Round-4 advisor finding, closed in round 5: the sparse update body with the FOLDED descriptor (MOT_KCF_K80 bit 3, compiled only into the
+    demonstration libraries of `make endcf`) writes a wrong model because hipcc places register copies in front of a folded EXEC restore
+    (kcf_kernels.hip, kcf_update_sparse_run; tools/isa_exec0_scan.py).  Same source with -mllvm -amdgpu-remove-redundant-endcf=0: the bits of the
+    general kernels.  The default build of it must still differ -- when a compiler release fixes it, this reminder fails and the folded
+    instantiation can be reconsidered."""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiple-object-tracking_amd")
+    view, fixed = os.path.join(pkg, "libmot_amd_view.so"), os.path.join(pkg, "libmot_amd_view_endcf.so")
+    if not (os.path.exists(view) and os.path.exists(fixed)):
+        pytest.skip("demonstration libraries not built (make -C multiple-object-tracking_amd/csrc endcf)")
+    args = (48, 128, 8, 4, 9, 21)
+    general = _state_hashes({"MOT_KCF_K80": "0"}, args)
+    assert len(general) == args[4]
+    assert _state_hashes({"MOT_AMD_LIB": fixed, "MOT_KCF_K80": "15"}, args) == general, "inner EXEC restores kept: the folded sparse update must equal the general kernels"
+    assert _state_hashes({"MOT_AMD_LIB": fixed, "MOT_KCF_K80": "7"}, args) == general
+    assert _state_hashes({"MOT_AMD_LIB": view, "MOT_KCF_K80": "15"}, args) != general, "the default build of the folded sparse update now equals the general kernels: re-evaluate MOT_KCF_K80 bit 3"
 
 
 def test_finish_refuses_a_different_detection_list(mot):
