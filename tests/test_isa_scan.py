@@ -71,3 +71,29 @@ def test_demonstration_library_is_flagged():
     assert hits and all("kcf_update_sparse_run" in h[1] and "Lb1E" in h[1] for h in hits), hits
     assert any(len(h[3]) == 7 and all(s.startswith("v_mov_b64") for _, s in h[3]) for h in hits)
     assert mod.scan_file(fixed)[0] == []
+
+
+def test_hot_kernels_keep_their_register_budget():
+    """What the design's occupancy figures rest on, read from the shipped code objects' metadata: the 80-px KCF
+    kernels run two 512-thread workgroups per CU (<= 128 VGPRs) without scratch; the association's one-workgroup kernels have 1024 threads
+    (<= 128 VGPRs) and no scratch either.  `python tools/kernel_resources.py` prints the whole table (profiles/r05_kernel_resources.txt)."""
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
+    if not os.path.exists(kr.READELF): pytest.skip("llvm-readelf not found")
+    lib = os.path.join(PKG, "libmot_amd.so")
+    if not os.path.exists(lib): pytest.skip("libmot_amd.so not built")
+    ks = kr.kernels(lib); names = kr.demangle(list(ks))
+    by_name = {}
+    for n, d in ks.items():
+        pretty = names[n].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        by_name[pretty] = d
+    hot = ["kcf_predict_kernel<7>", "kcf_features_kernel<7>", "kcf_predict_features_kernel<7, false>", "kcf_update_kernel<7>", "kcf_predict_multi_kernel<7>",
+           "kcf_predict_kernel<1>", "kcf_features_kernel<1>", "kcf_update_kernel<1>", "kcf_predict_multi_kernel<1>", "kcf_predict_multi_kernel<3>", "kcf_update_multi_kernel<3>",
+           "lap_rowscan_kernel", "lap_solve_kernel", "lap_solve2_kernel<false>", "mk_sparse_kernel<false>", "munkres_kernel<false>", "lap_dense_kernel",
+           "kalman_predict_kernel", "kalman_update_kernel"]
+    for k in hot:
+        assert k in by_name, f"{k} not in the library (have: {sorted(by_name)[:8]} ...)"
+        d = by_name[k]
+        assert d["private_segment_fixed_size"] == 0, f"{k}: {d['private_segment_fixed_size']} B/lane of scratch"
+        assert d["vgpr_count"] <= 128, f"{k}: {d['vgpr_count']} VGPRs"
+    assert by_name["kcf_features_kernel<7>"]["vgpr_count"] <= 88             # (round 4's figure; three workgroups per CU would need <= 84)
