@@ -143,8 +143,10 @@ def cpu_baseline(n_tracks, size, budget_s=12.0):
 
 def dropin_timing(device, n=16, reps=12):
     """us per call of the reference's per-object interface (td.cpp:229-232) through libmot_dropin_kcf.so -- the literal drop-in
-    mode: every call is a batch of ONE (H2D of the 25.6 KB gray patch + one-workgroup launch + sync) -- next to the reference's
-    own tracker_predict / tracker_update (kcf.cpp:455-476) on one host core, same patches"""
+    mode: every call is a batch of ONE -- next to the reference's own tracker_predict / tracker_update (kcf.cpp:455-476) on one host
+    core, same patches.  Calls are issued in td.cpp's order: per frame, tracker_predict for every object (td.cpp:344-384), then
+    tracker_update for every object (td.cpp:512-582).  `per_object_frame_us` is the wall time of a whole frame's calls / objects (it
+    contains every wait, whichever call it falls into)."""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
@@ -163,27 +165,34 @@ def dropin_timing(device, n=16, reps=12):
         hs = [C.c_void_p(new_f(C.byref(b))) for b in boxes]
         for h, p, b in zip(hs, patches, boxes):
             upd_f(h, orc.P(p), C.byref(b))                              # first update (eta = 1), td.cpp:631-640
+        pb = mot_amd.BBox()
+        pred_f(hs[0], orc.P(patches[0]), C.byref(pb))                   # (drains whatever the first updates left queued)
         tp, tu = [], []
+        t_all = time.perf_counter()
         for _ in range(reps):
+            for h, p in zip(hs, patches):
+                t0 = time.perf_counter(); pred_f(h, orc.P(p), C.byref(pb)); tp.append((time.perf_counter() - t0) * 1e6)
             for h, p, b in zip(hs, patches, boxes):
-                pb = mot_amd.BBox()
-                t0 = time.perf_counter(); pred_f(h, orc.P(p), C.byref(pb)); t1 = time.perf_counter()
-                upd_f(h, orc.P(p), C.byref(b)); t2 = time.perf_counter()
-                tp.append((t1 - t0) * 1e6); tu.append((t2 - t1) * 1e6)
+                t0 = time.perf_counter(); upd_f(h, orc.P(p), C.byref(b)); tu.append((time.perf_counter() - t0) * 1e6)
+        pred_f(hs[0], orc.P(patches[0]), C.byref(pb))                   # the last updates have run when this returns
+        t_all = (time.perf_counter() - t_all) * 1e6
         for h in hs:
             del_f(h)
-        return np.array(tp), np.array(tu)
+        return np.array(tp), np.array(tu), t_all / (reps * n)
     run(new, pred, upd, dele)                                          # warm-up (context creation, first launches)
-    p_us, u_us = run(new, pred, upd, dele)
+    p_us, u_us, frame_us = run(new, pred, upd, dele)
     out = {"tracker_predict_us": float(p_us.mean()), "tracker_update_us": float(u_us.mean()),
            "tracker_predict_p50_p90_us": [float(np.percentile(p_us, 50)), float(np.percentile(p_us, 90))],
            "tracker_update_p50_p90_us": [float(np.percentile(u_us, 50)), float(np.percentile(u_us, 90))],
-           "calls": n * reps, "patch": "80x80 float gray (caller memory)",
-           "note": "per-object interface = batch of one per call (zero-copy: the kernel reads the pinned patch and writes the box itself; one launch + one stream synchronisation); the batch ABI (mot_step_frame_device) is the measured path"}
+           "per_object_frame_us": float(frame_us),
+           "calls": n * reps, "patch": "80x80 float gray (caller memory)", "order": "td.cpp: all predicts of a frame, then all updates",
+           "note": "per-object interface = batch of one per call, zero-copy (the kernel reads the pinned patch and writes the box itself): tracker_predict = one launch + one stream "
+                   "synchronisation; tracker_update returns with its launch queued (two staging halves), so back-to-back updates run at the kernel's rate and the first predict of the "
+                   "next frame waits for the last one; the batch ABI (mot_step_frame_device) is the measured path"}
     if orc.ref_available():
         k = orc.load_ref("kcf")
-        rp, ru = run(lambda b: k.refkcf_new(b), k.refkcf_predict, k.refkcf_update, k.refkcf_delete)
-        out.update({"reference_tracker_predict_us": float(rp.mean()), "reference_tracker_update_us": float(ru.mean()), "reference_cores": 1})
+        rp, ru, rf = run(lambda b: k.refkcf_new(b), k.refkcf_predict, k.refkcf_update, k.refkcf_delete)
+        out.update({"reference_tracker_predict_us": float(rp.mean()), "reference_tracker_update_us": float(ru.mean()), "reference_per_object_frame_us": float(rf), "reference_cores": 1})
     return out
 
 

@@ -136,7 +136,13 @@ int mot_delete_batch(mot_ctx* ctx, const int* ids, int n);
 
 /* Same stages fed with caller-supplied gray patches instead of the bound frame:
  * patches[i] is the column-major rows x cols float patch the reference passes as
- * `float* rgb` (trackers/kcf.cpp:455-476).  Used by the per-object drop-in layer. */
+ * `float* rgb` (trackers/kcf.cpp:455-476).  Used by the per-object drop-in layer.
+ * Completion: every call copies the caller's patches and boxes before it returns.  A predict returns the boxes and therefore waits
+ * for its kernel.  An UPDATE of at most 8 tracks returns with its launch queued on the context's stream (pinned, device-mapped staging
+ * in two halves; MOT_ZC_ASYNC=0: it waits) -- the model is updated for every later call on this context, which the stream orders behind
+ * it, and a device-side failure surfaces at the next call that waits (mot_ctx_sync, any predict).  td.cpp's update loop
+ * (td.cpp:512-582: crop + resize on the host, then tracker_update, per object) thereby overlaps its host work with the previous
+ * object's kernel. */
 int mot_tracks_new_nofirst(mot_ctx* ctx, const bbox_t* boxes, int n, int* ids_out); /* tracker_new only */
 int mot_predict_batch_patches(mot_ctx* ctx, const int* ids, int n, const float* const* patches, bbox_t* boxes_out);
 int mot_update_batch_patches(mot_ctx* ctx, const int* ids, int n, const float* const* patches, const bbox_t* boxes);

@@ -46,6 +46,21 @@ struct PoolHost {
 
 struct TrackRec { int kind; int pool; int slot; int rows, cols; bool live; };
 
+// Staging of the per-object calls that bring their own patch (tracker_predict / tracker_update of the drop-in interface, kcf.cpp:455-476: a
+// batch of <= 8): pinned, device-mapped, the kernels read and write it in place (zero-copy).  TWO halves with an event each, so that an
+// UPDATE can return as soon as its launch is queued -- the caller's patch has been copied, nothing comes back -- while the next call stages
+// into the other half: td.cpp's update loop (crop + resize on the host, then tracker_update, per object: td.cpp:512-582) overlaps its host
+// work with the previous object's kernel.  A predict returns a box and still waits.  Nothing else uses these buffers.
+struct ZcRing {
+    static constexpr int kItems = 8;
+    PinBuf<int> slots; PinBuf<bbox_t> boxes_a, boxes_b; PinBuf<float> patches;
+    int* d_slots = nullptr; bbox_t* d_boxes_a = nullptr; bbox_t* d_boxes_b = nullptr; float* d_patches = nullptr;
+    size_t half_floats = 0;                          // patch capacity of one half
+    hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int next = 0;
+    bool tried = false, ok = false;
+    ~ZcRing() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+};
+
 struct LiveInfo {                    // tracker_info_t (td.cpp:271-290)
     int id; unsigned tid; int age, visible, invisible; bbox_t bbox;
 };
@@ -78,7 +93,8 @@ struct mot_ctx {
     int stage_cap = 0;
     mot_impl::DevBuf<int> d_slots; mot_impl::DevBuf<bbox_t> d_boxes_a, d_boxes_b, d_dets; mot_impl::DevBuf<float> d_patches; size_t patches_cap = 0;
     // device-side addresses of the pinned staging buffers (zero-copy path of small batches, run_batch); null when the mapping is not available
-    int* zc_slots = nullptr; bbox_t* zc_boxes_a = nullptr; bbox_t* zc_boxes_b = nullptr; float* zc_patches = nullptr;
+    int* zc_slots = nullptr; bbox_t* zc_boxes_a = nullptr; bbox_t* zc_boxes_b = nullptr;
+    mot_impl::ZcRing zc_ring;
     mot_impl::PinBuf<int> h_slots; mot_impl::PinBuf<bbox_t> h_boxes_a, h_boxes_b; mot_impl::PinBuf<int> h_assign; mot_impl::PinBuf<int> h_hint; mot_impl::PinBuf<double> h_cost; mot_impl::PinBuf<float> h_patches;
     // association
     AssocWs assoc{}; mot_impl::DevBuf<double> a_dist; mot_impl::DevBuf<unsigned long long> a_zr, a_zc, a_linemin; mot_impl::DevBuf<int> a_assign, a_status; mot_impl::DevBuf<double> a_cost;

@@ -31,6 +31,7 @@ struct EnvSwitches {
                              // kernel as well -- the instantiation hipcc miscompiles (register copies in front of a folded EXEC restore: kcf_update_sparse_run)
     int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
+    int zc_async;            // MOT_ZC_ASYNC=0: per-object updates with a caller patch wait for their kernel before they return (round-5 default: they do not)
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
 };
 
@@ -55,6 +56,7 @@ inline const EnvSwitches& env()
         s.k80 = geti("MOT_KCF_K80", 7);                                  // bit 0 predict, 1 feature, 2 update kernels
         s.dft_inplace = off("MOT_DFT_INPLACE") ? 0 : 1;
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
+        s.zc_async = off("MOT_ZC_ASYNC") ? 0 : 1;
         s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
         return s;
     }();

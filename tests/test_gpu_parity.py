@@ -126,6 +126,50 @@ def test_kcf_sequence_golden(mot, name, fft_mode):
     c.close()
 
 
+def test_back_to_back_patch_updates_through_the_staging_ring(mot, oracle):
+    """Round 5: a per-object update with a caller patch (tracker_update, kcf.cpp:455-476) returns with its launch queued and stages through one of
+    two pinned halves.  Seven tracks updated back to back, one call each, nothing synchronised in between and the caller's patch buffer
+    overwritten right after every call, for five rounds with different patches; then one predict per track.  Models and responses
+    against the oracle: a half reused too early, or a patch read after the call returned, shows up here."""
+    rng = np.random.default_rng(11)
+    n, rounds = 7, 5
+    c = mot.MotContext(max_tracks=8, max_dets=8)
+    boxes = [(40 + 90 * i, 60 + 7 * i, 60 + 7 * i + 79, 40 + 90 * i + 79, i % 3, 0.9) for i in range(n)]
+    ids = c.tracks_new(boxes, first_update=False)
+    oks = [C.c_void_p(oracle.orc_kcf_new(P(orc.boxes_array([b])), 0)) for b in boxes]
+    scratch = np.zeros(6400, np.float32)                                # the caller's ONE patch buffer, as td.cpp's grayImage is per tracker but reused per frame
+    for r in range(rounds):
+        pats = [np.ascontiguousarray(rng.integers(0, 256, 6400).astype(np.float32)) for _ in range(n)]
+        for i in range(n):
+            scratch[:] = pats[i]
+            c.update_batch_patches([ids[i]], [scratch], [boxes[i]])
+            scratch[:] = -1.0                                           # overwritten at once: the library must have copied it
+        for i, k in enumerate(oks):
+            oracle.orc_kcf_update(k, P(pats[i]), P(orc.boxes_array([boxes[i]])))
+    probe = [np.ascontiguousarray(rng.integers(0, 256, 6400).astype(np.float32)) for _ in range(n)]
+    for i, k in enumerate(oks):
+        pred = c.predict_batch_patches([ids[i]], [probe[i]])
+        pb = BBox(); oracle.orc_kcf_predict(k, P(probe[i]), C.byref(pb))
+        assert tuple(boxes_to_np(pred)[0])[:4] == (pb.l, pb.t, pb.b, pb.r), f"track {i}: predicted box"
+        resp = c.get_response(ids[i]); ref = orc.arr(oracle.orc_kcf_response(k), 400)
+        assert resp.argmax() == ref.argmax(), f"track {i}: arg-max"
+        assert abs(resp.max() - ref.max()) <= PEAK_RTOL * abs(ref.max()), f"track {i}: peak {resp.max()} vs {ref.max()}"
+        _, alpha = c.get_model(ids[i]); ra = orc.arr(oracle.orc_kcf_alpha(k), alpha.size)
+        np.testing.assert_allclose(alpha, ra, rtol=0, atol=2e-5 * np.abs(ra).max())
+    for k in oks:
+        oracle.orc_kcf_delete(k)
+    c.close()
+
+
+def test_patch_updates_that_wait_for_their_kernel():
+    """the off-variant of the switch (MOT_ZC_ASYNC=0, read once per process): the same test in a process of its own"""
+    import subprocess, sys
+    env = dict(os.environ, MOT_ZC_ASYNC="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_back_to_back_patch_updates_through_the_staging_ring"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("rows,cols", [(120, 164), (164, 124), (148, 100), (100, 156)])
 def test_kcf_nonsquare_templates_vs_oracle(mot, oracle, rows, cols):
     """non-square templates, most of them beyond the LDS limit (HBM-slab kernels, MFMA DFT with hb != wb): predict / update of a few
