@@ -150,3 +150,24 @@ def test_round5_committed_lines():
         import pytest
         pytest.skip("round-5 profiles not collected yet")
     _check_committed_round("r05")
+
+
+def test_round5_final_tree_line():
+    """the default bench of the round's last commit: the contract's keys, parity, and the per-object leg in td.cpp's call order"""
+    path = os.path.join(ROOT, "profiles", "r05_bench_n1024_final_tree.json")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("not collected")
+    j = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "steady_state", "latency_bound", "h2d_inclusive", "parity_checked"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 200 and j["warmup"] == 20 and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert j["parity_checked"]["ok"] is True and j["parity_checked"]["equal_to"] == {"port": True, "reference": True}
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["alg_bytes_per_launch"] == 1024 * 185592
+    assert abs(j["value"] - j["config"]["live_tracks_end"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    d = j["cpu_baseline"]["dropin"]
+    assert d["order"].startswith("td.cpp") and d["calls"] == 192
+    assert 0 < d["per_object_frame_us"] < d["reference_per_object_frame_us"], "the per-object interface must beat the reference's own calls per object and frame"
+    assert d["tracker_update_us"] < d["reference_tracker_update_us"] and d["tracker_predict_us"] < d["reference_tracker_predict_us"]
