@@ -1,0 +1,101 @@
+// dft_ct.h -- the column pass of the general (LDS-resident, not 20 x 20 cells) forward transform as TWO short passes instead of one direct DFT
+// (kcf.cpp:178-195 plans an FFT of any size with FFTW; the direct pass costs wb multiply-adds per output, this one N1 + N2 for wb = N1 * N2).
+//
+//   x[n], n = N2*n1 + n2        X[k], k = k1 + N1*k2        W = exp(-2 pi i / wb)
+//   step A (in place):   Y[k1][n2] = W^(n2*k1) * sum_n1 x[N2*n1 + n2] * W^(N2*n1*k1)      stored at line N2*k1 + n2
+//   step C (to region B): X[k1 + N1*k2] = sum_n2 Y[k1][n2] * W^(N1*n2*k2)
+//
+// Step A's work item is (plane, n2, two adjacent bins): it owns the N1 lines {N2*n1 + n2} of its bins -- reads them all into registers, then
+// overwrites the same set {N2*k1 + n2} -- so it needs no second buffer and no barrier of its own; N1 is the SMALL factor (2..5), so the item
+// holds at most 5 x 2 complex inputs.  Step C is the old direct pass with N2 terms instead of wb and a block of consecutive input lines.
+// Both take every twiddle from the line's own table (tw[j] = (cos, sin)(2 pi j / wb), the forward transform conjugates it), no new tables.
+// Plain pointers and ints only: the same text compiles for the host, where tests/test_dft_ct.py checks it against numpy for every line
+// length from 8 to 64 (DFTCT_FN / DFTCT_HOST).  Round 5: compiled into the kernels only with -DMOT_FFT_MIXED=1 (`make fftmix`).
+#pragma once
+#ifndef DFTCT_FN
+#define DFTCT_FN __device__ __forceinline__
+#endif
+
+// the split of a line of n cells: N1 in {2, 3, 4, 5} dividing n that minimises N1 + n / N1; 0 when none divides n or the line is short
+DFTCT_FN int dftct_small_factor(int n)
+{
+    if (n < 8) return 0;
+    int best = 0, cost = n;                                            // the direct pass costs n per output
+    for (int f = 2; f <= 5; f++) if (n % f == 0 && f + n / f < cost) { cost = f + n / f; best = f; }
+    return best;
+}
+
+// a / b for small non-negative ints with inv = 1.0f / b computed once per pass (the passes visit a few items per thread: three hardware
+// integer divisions per item would cost as much as the multiply-adds the split saves); the float estimate is off by at most one
+DFTCT_FN int dftct_div(int a, int b, float inv, int& rem)
+{
+    int q = (int)((float)a * inv);
+    int r = a - q * b;
+    if (r < 0) { q--; r += b; } else if (r >= b) { q++; r -= b; }
+    rem = r;
+    return q;
+}
+
+// step A, in place on T[(ch*n + x)*fh + k]
+DFTCT_FN void dftct_cols_a(float2* T, const float2* tw, int n, int N1, int fh, int nch, int tid, int nt)
+{
+    const int N2 = (int)((float)n / (float)N1 + 0.5f), kb = (fh + 1) >> 1, per = N2 * kb, total = nch * per;
+    const float inv_per = 1.0f / (float)per, inv_kb = 1.0f / (float)kb;
+    for (int i = tid; i < total; i += nt) {
+        int rem, kq;
+        const int ch = dftct_div(i, per, inv_per, rem), n2 = dftct_div(rem, kb, inv_kb, kq), k0 = 2 * kq, kc = (k0 + 1 < fh) ? k0 + 1 : k0;
+        float2* base = T + (size_t)ch * n * fh;
+        float2 a[5], b[5];
+#pragma unroll
+        for (int n1 = 0; n1 < 5; n1++) if (n1 < N1) { const float2* sx = base + (N2 * n1 + n2) * fh; a[n1] = sx[k0]; b[n1] = sx[kc]; }
+#pragma unroll
+        for (int k1 = 0; k1 < 5; k1++) if (k1 < N1) {
+            float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f; int j = 0;  // j = ((n1 * k1) mod N1) * N2
+#pragma unroll
+            for (int n1 = 0; n1 < 5; n1++) if (n1 < N1) {
+                const float2 w = tw[j]; const float wi = -w.y;          // forward
+                ar += a[n1].x * w.x - a[n1].y * wi; ai += a[n1].x * wi + a[n1].y * w.x;
+                br += b[n1].x * w.x - b[n1].y * wi; bi += b[n1].x * wi + b[n1].y * w.x;
+                j += k1 * N2; if (j >= n) j -= n;
+            }
+            const float2 w = tw[n2 * k1]; const float wi = -w.y;        // n2 * k1 < N2 * N1
+            float2* o = base + (N2 * k1 + n2) * fh;
+            float2 ra; ra.x = ar * w.x - ai * wi; ra.y = ar * wi + ai * w.x;
+            float2 rb; rb.x = br * w.x - bi * wi; rb.y = br * wi + bi * w.x;
+            o[k0] = ra;
+            if (k0 + 1 < fh) o[k0 + 1] = rb;
+        }
+    }
+}
+
+// step C: T (as step A left it) -> out[(ch*n + x')*fh + k], x' = k1 + N1*k2
+DFTCT_FN void dftct_cols_c(const float2* T, float2* out, const float2* tw, int n, int N1, int fh, int nch, int tid, int nt)
+{
+    const int N2 = (int)((float)n / (float)N1 + 0.5f), kb = (fh + 3) >> 2, per = n * kb, total = nch * per, plane = n * fh;
+    const float inv_per = 1.0f / (float)per, inv_kb = 1.0f / (float)kb, inv_n1 = 1.0f / (float)N1;
+    for (int i = tid; i < total; i += nt) {
+        int rem, kq, k1;
+        const int ch = dftct_div(i, per, inv_per, rem), xp = dftct_div(rem, kb, inv_kb, kq), k0 = 4 * kq;
+        const int q1 = (k0 + 1 < fh) ? k0 + 1 : fh - 1, q2 = (k0 + 2 < fh) ? k0 + 2 : fh - 1, q3 = (k0 + 3 < fh) ? k0 + 3 : fh - 1;
+        const int k2 = dftct_div(xp, N1, inv_n1, k1);
+        const float2* src = T + (size_t)ch * plane + (size_t)(N2 * k1) * fh;
+        float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;   // j = ((n2 * k2) mod N2) * N1
+        const int step = k2 * N1;
+#pragma unroll 2
+        for (int n2 = 0; n2 < N2; n2++) {
+            const float2 w = tw[j]; const float wi = -w.y;              // forward
+            const float2* sx = src + n2 * fh;
+            const float2 a = sx[k0], b = sx[q1], c = sx[q2], d = sx[q3];
+            re0 += a.x * w.x - a.y * wi; im0 += a.x * wi + a.y * w.x;
+            re1 += b.x * w.x - b.y * wi; im1 += b.x * wi + b.y * w.x;
+            re2 += c.x * w.x - c.y * wi; im2 += c.x * wi + c.y * w.x;
+            re3 += d.x * w.x - d.y * wi; im3 += d.x * wi + d.y * w.x;
+            j += step; if (j >= n) j -= n;
+        }
+        float2* o = out + (size_t)ch * plane + (size_t)xp * fh;
+        float2 r0; r0.x = re0; r0.y = im0; o[k0] = r0;
+        if (k0 + 1 < fh) { float2 r; r.x = re1; r.y = im1; o[k0 + 1] = r; }
+        if (k0 + 2 < fh) { float2 r; r.x = re2; r.y = im2; o[k0 + 2] = r; }
+        if (k0 + 3 < fh) { float2 r; r.x = re3; r.y = im3; o[k0 + 3] = r; }
+    }
+}

@@ -771,6 +771,14 @@ __device__ __forceinline__ void dft2_generic_inplace(int hb, int wb, int fh, Fas
     }
 }
 
+// (round 5, prepared for round 6: -DMOT_FFT_MIXED=1, `make fftmix`) the column pass as two short passes for line lengths with a factor 2..5
+#ifndef MOT_FFT_MIXED
+#define MOT_FFT_MIXED 0
+#endif
+#if MOT_FFT_MIXED
+#include "dft_ct.h"
+#endif
+
 // ---- DFTs as f32 matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 multiply-adds, k-ordered) ----
 // A line transform of prime length (37 cells at 148 px) has no butterfly; as a product with the constant twiddle matrix
 // it runs at the MFMA rate instead of one multiply-add and one twiddle fetch per VALU slot.  The constant operand comes
@@ -1219,6 +1227,15 @@ __device__ __forceinline__ void fft_forward(const KcfPool& p, float* __restrict_
             }
             dft_rows_generic4(p, sF, sT, twr, g, tid, nt);                // lines longer than MOT_DFT_MFMA_MAX cells (templates beyond 164 px)
             __syncthreads();
+#if MOT_FFT_MIXED
+            if (const int n1 = dftct_small_factor(p.wb)) {
+                dftct_cols_a(sT, twc, p.wb, n1, p.fh, g, tid, nt);
+                __syncthreads();
+                dftct_cols_c(sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, p.wb, n1, p.fh, g, tid, nt);
+                __syncthreads();
+                continue;
+            }
+#endif
             dft_cols_generic4(p, sT, reinterpret_cast<float2*>(regB) + (size_t)c0 * p.nbins, twc, g, tid, nt);
             __syncthreads();
         }
@@ -1231,6 +1248,15 @@ __device__ __forceinline__ void fft_forward(const KcfPool& p, float* __restrict_
         float2* T = reinterpret_cast<float2*>(regT);
         dft_rows_generic4(p, regB, T, twr, nch, tid, nt);
         __syncthreads();
+#if MOT_FFT_MIXED
+        if (const int n1 = dftct_small_factor(p.wb)) {                 // wb = n1 * N2: step A in place on T, step C into region B (dft_ct.h)
+            dftct_cols_a(T, twc, p.wb, n1, p.fh, nch, tid, nt);
+            __syncthreads();
+            dftct_cols_c(T, reinterpret_cast<float2*>(regB), twc, p.wb, n1, p.fh, nch, tid, nt);
+            __syncthreads();
+            return;
+        }
+#endif
         dft_cols_generic4(p, T, reinterpret_cast<float2*>(regB), twc, nch, tid, nt);
         __syncthreads();
     }
