@@ -68,34 +68,45 @@ DFTCT_FN void dftct_cols_a(float2* T, const float2* tw, int n, int N1, int fh, i
     }
 }
 
+// one work item of step C: the sums of output line x' = k1 + N1*k2 of one plane (as step A left it) for the bins k0 .. k0 + 3 (clamped to fh - 1)
+// -> acc = re0, im0, re1, im1, re2, im2, re3, im3.  Also the column pass of the in-place variant (kcf_kernels.hip, dft2_generic_inplace), which
+// keeps its outputs in registers across a barrier instead of writing to a second buffer.
+DFTCT_FN void dftct_cols_c_item(const float2* plane, const float2* tw, int n, int N1, int N2, int fh, int xp, int k0, float inv_n1, float* acc)
+{
+    const int q1 = (k0 + 1 < fh) ? k0 + 1 : fh - 1, q2 = (k0 + 2 < fh) ? k0 + 2 : fh - 1, q3 = (k0 + 3 < fh) ? k0 + 3 : fh - 1;
+    int k1;
+    const int k2 = dftct_div(xp, N1, inv_n1, k1);
+    const float2* src = plane + (size_t)(N2 * k1) * fh;
+    float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;   // j = ((n2 * k2) mod N2) * N1
+    const int step = k2 * N1;
+#pragma unroll 2
+    for (int n2 = 0; n2 < N2; n2++) {
+        const float2 w = tw[j]; const float wi = -w.y;                  // forward
+        const float2* sx = src + n2 * fh;
+        const float2 a = sx[k0], b = sx[q1], c = sx[q2], d = sx[q3];
+        re0 += a.x * w.x - a.y * wi; im0 += a.x * wi + a.y * w.x;
+        re1 += b.x * w.x - b.y * wi; im1 += b.x * wi + b.y * w.x;
+        re2 += c.x * w.x - c.y * wi; im2 += c.x * wi + c.y * w.x;
+        re3 += d.x * w.x - d.y * wi; im3 += d.x * wi + d.y * w.x;
+        j += step; if (j >= n) j -= n;
+    }
+    acc[0] = re0; acc[1] = im0; acc[2] = re1; acc[3] = im1; acc[4] = re2; acc[5] = im2; acc[6] = re3; acc[7] = im3;
+}
+
 // step C: T (as step A left it) -> out[(ch*n + x')*fh + k], x' = k1 + N1*k2
 DFTCT_FN void dftct_cols_c(const float2* T, float2* out, const float2* tw, int n, int N1, int fh, int nch, int tid, int nt)
 {
     const int N2 = (int)((float)n / (float)N1 + 0.5f), kb = (fh + 3) >> 2, per = n * kb, total = nch * per, plane = n * fh;
     const float inv_per = 1.0f / (float)per, inv_kb = 1.0f / (float)kb, inv_n1 = 1.0f / (float)N1;
     for (int i = tid; i < total; i += nt) {
-        int rem, kq, k1;
+        int rem, kq;
         const int ch = dftct_div(i, per, inv_per, rem), xp = dftct_div(rem, kb, inv_kb, kq), k0 = 4 * kq;
-        const int q1 = (k0 + 1 < fh) ? k0 + 1 : fh - 1, q2 = (k0 + 2 < fh) ? k0 + 2 : fh - 1, q3 = (k0 + 3 < fh) ? k0 + 3 : fh - 1;
-        const int k2 = dftct_div(xp, N1, inv_n1, k1);
-        const float2* src = T + (size_t)ch * plane + (size_t)(N2 * k1) * fh;
-        float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;   // j = ((n2 * k2) mod N2) * N1
-        const int step = k2 * N1;
-#pragma unroll 2
-        for (int n2 = 0; n2 < N2; n2++) {
-            const float2 w = tw[j]; const float wi = -w.y;              // forward
-            const float2* sx = src + n2 * fh;
-            const float2 a = sx[k0], b = sx[q1], c = sx[q2], d = sx[q3];
-            re0 += a.x * w.x - a.y * wi; im0 += a.x * wi + a.y * w.x;
-            re1 += b.x * w.x - b.y * wi; im1 += b.x * wi + b.y * w.x;
-            re2 += c.x * w.x - c.y * wi; im2 += c.x * wi + c.y * w.x;
-            re3 += d.x * w.x - d.y * wi; im3 += d.x * wi + d.y * w.x;
-            j += step; if (j >= n) j -= n;
-        }
+        float acc[8];
+        dftct_cols_c_item(T + (size_t)ch * plane, tw, n, N1, N2, fh, xp, k0, inv_n1, acc);
         float2* o = out + (size_t)ch * plane + (size_t)xp * fh;
-        float2 r0; r0.x = re0; r0.y = im0; o[k0] = r0;
-        if (k0 + 1 < fh) { float2 r; r.x = re1; r.y = im1; o[k0 + 1] = r; }
-        if (k0 + 2 < fh) { float2 r; r.x = re2; r.y = im2; o[k0 + 2] = r; }
-        if (k0 + 3 < fh) { float2 r; r.x = re3; r.y = im3; o[k0 + 3] = r; }
+        float2 r0; r0.x = acc[0]; r0.y = acc[1]; o[k0] = r0;
+        if (k0 + 1 < fh) { float2 r; r.x = acc[2]; r.y = acc[3]; o[k0 + 1] = r; }
+        if (k0 + 2 < fh) { float2 r; r.x = acc[4]; r.y = acc[5]; o[k0 + 2] = r; }
+        if (k0 + 3 < fh) { float2 r; r.x = acc[6]; r.y = acc[7]; o[k0 + 3] = r; }
     }
 }

@@ -676,6 +676,17 @@ __device__ __forceinline__ void dft_cols_generic4(const KcfPool& p, const float2
     }
 }
 
+// (round 5, prepared for round 6: -DMOT_FFT_MIXED=1, `make fftmix`) the column pass as two short passes for line lengths with a factor 2..5
+#ifndef MOT_FFT_MIXED
+#define MOT_FFT_MIXED 0
+#endif
+#ifndef MOT_FFT_MIXED_INPLACE            /* the in-place variant (72 / 76 px single pools) too: host-checked, never run on a GPU; costs kcf_predict_kernel<5> 544 B/lane of scratch */
+#define MOT_FFT_MIXED_INPLACE 0
+#endif
+#if MOT_FFT_MIXED
+#include "dft_ct.h"
+#endif
+
 // The same two passes IN PLACE (LDS-resident templates other than 20 x 20 cells, KcfPool::dft_inplace): a line's row spectrum occupies exactly the
 // floats of the line (fh complex = ldf floats), a plane's spectrum those of its row spectra -- so every thread first computes ALL its outputs of a
 // pass into registers (<= MOT_DFT_INPLACE_ITEMS items of 8 floats), the workgroup meets at a barrier, and only then the outputs overwrite the
@@ -732,11 +743,20 @@ __device__ __forceinline__ void dft2_generic_inplace(int hb, int wb, int fh, Fas
     {   // columns: item = (plane, output line x', group of four bins)
         const int kb = (fh + 3) >> 2, per = wb * kb, total = nch * per;
         float2* S = reinterpret_cast<float2*>(B);
+#if MOT_FFT_MIXED && MOT_FFT_MIXED_INPLACE
+        // wb = n1 * N2: step A of dft_ct.h in place first; the items below then take step C's sums (dftct_cols_c_item) instead of the direct ones
+        const int n1 = dftct_small_factor(wb);
+        const float inv_n1 = n1 ? 1.0f / (float)n1 : 0.f;
+        if (n1) { dftct_cols_a(S, twc, wb, n1, fh, nch, tid, nt); __syncthreads(); }
+#endif
 #pragma unroll
         for (int it = 0; it < MOT_DFT_INPLACE_ITEMS; it++) {
             const int i = tid + it * nt;
             if (i < total) {
                 const int ch = i / per, rem = i - ch * per, xp = rem / kb, k0 = 4 * (rem - xp * kb);
+#if MOT_FFT_MIXED && MOT_FFT_MIXED_INPLACE
+                if (n1) { dftct_cols_c_item(S + ch * plane, twc, wb, n1, wb / n1, fh, xp, k0, inv_n1, acc[it]); continue; }
+#endif
                 const int k1 = min(k0 + 1, fh - 1), k2 = min(k0 + 2, fh - 1), k3 = min(k0 + 3, fh - 1);
                 const float2* src = S + ch * plane;
                 float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;
@@ -770,14 +790,6 @@ __device__ __forceinline__ void dft2_generic_inplace(int hb, int wb, int fh, Fas
         __syncthreads();
     }
 }
-
-// (round 5, prepared for round 6: -DMOT_FFT_MIXED=1, `make fftmix`) the column pass as two short passes for line lengths with a factor 2..5
-#ifndef MOT_FFT_MIXED
-#define MOT_FFT_MIXED 0
-#endif
-#if MOT_FFT_MIXED
-#include "dft_ct.h"
-#endif
 
 // ---- DFTs as f32 matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 multiply-adds, k-ordered) ----
 // A line transform of prime length (37 cells at 148 px) has no butterfly; as a product with the constant twiddle matrix

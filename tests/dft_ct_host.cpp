@@ -17,3 +17,23 @@ extern "C" void ct_cols_a_reversed(float* T, const float* tw, int n, int N1, int
 {
     for (int tid = nt - 1; tid >= 0; tid--) dftct_cols_a(reinterpret_cast<float2*>(T), reinterpret_cast<const float2*>(tw), n, N1, fh, nch, tid, nt);
 }
+// the in-place variant (kcf_kernels.hip, dft2_generic_inplace under MOT_FFT_MIXED): step A, then every item's sums into "registers", a barrier,
+// and only then the outputs overwrite the inputs
+#include <vector>
+extern "C" void ct_cols_inplace(float* S, const float* tw_, int n, int N1, int fh, int nch)
+{
+    float2* T = reinterpret_cast<float2*>(S); const float2* tw = reinterpret_cast<const float2*>(tw_);
+    for (int tid = 0; tid < 64; tid++) dftct_cols_a(T, tw, n, N1, fh, nch, tid, 64);
+    const int kb = (fh + 3) >> 2, per = n * kb, total = nch * per, plane = n * fh;
+    std::vector<float> acc((size_t)total * 8);
+    const float inv_n1 = 1.0f / (float)N1;
+    for (int i = 0; i < total; i++) {
+        const int ch = i / per, rem = i - ch * per, xp = rem / kb, k0 = 4 * (rem - xp * kb);
+        dftct_cols_c_item(T + (size_t)ch * plane, tw, n, N1, n / N1, fh, xp, k0, inv_n1, &acc[(size_t)i * 8]);
+    }
+    for (int i = 0; i < total; i++) {
+        const int ch = i / per, rem = i - ch * per, xp = rem / kb, k0 = 4 * (rem - xp * kb);
+        float2* o = T + (size_t)ch * plane + (size_t)xp * fh;
+        for (int q = 0; q < 4; q++) if (k0 + q < fh) { o[k0 + q].x = acc[(size_t)i * 8 + 2 * q]; o[k0 + q].y = acc[(size_t)i * 8 + 2 * q + 1]; }
+    }
+}

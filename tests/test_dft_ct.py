@@ -20,6 +20,7 @@ def lib():
     l.ct_small_factor.argtypes = [C.c_int]
     l.ct_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5
     l.ct_cols_a_reversed.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
+    l.ct_cols_inplace.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
     yield l
     os.unlink(out)
 
@@ -61,3 +62,18 @@ def test_step_a_is_order_independent(lib):
     lib.ct_cols(a.ctypes.data, out.ctypes.data, tw.ctypes.data, n, N1, fh, nch, 96)
     lib.ct_cols_a_reversed(b.ctypes.data, tw.ctypes.data, n, N1, fh, nch, 40)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [16, 18, 19 * 2, 21, 22, 24, 25, 27, 30])
+def test_in_place_variant_equals_numpy(lib, n):
+    """the column pass of dft2_generic_inplace under MOT_FFT_MIXED: step A, step C's sums held back across the barrier, then written over the inputs"""
+    rng = np.random.default_rng(100 + n)
+    N1 = lib.ct_small_factor(n)
+    assert N1
+    for fh, nch in ((n // 2 + 1, 3), (9, 2)):
+        x = (rng.standard_normal((nch, n, fh)) + 1j * rng.standard_normal((nch, n, fh))).astype(np.complex64)
+        ref = np.fft.fft(x.astype(np.complex128), axis=1)
+        S = np.ascontiguousarray(x.view(np.float32)); tw = _tw(n)
+        lib.ct_cols_inplace(S.ctypes.data, tw.ctypes.data, n, N1, fh, nch)
+        got = S.view(np.complex64).reshape(nch, n, fh)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6, (n, N1, fh)
