@@ -83,6 +83,7 @@ def test_hot_kernels_keep_their_register_budget():
     lib = os.path.join(PKG, "libmot_amd.so")
     if not os.path.exists(lib): pytest.skip("libmot_amd.so not built")
     ks = kr.kernels(lib); names = kr.demangle(list(ks))
+    if all(names[n] == n for n in ks): pytest.skip("c++filt not available")
     by_name = {}
     for n, d in ks.items():
         pretty = names[n].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
