@@ -110,3 +110,91 @@ DFTCT_FN void dftct_cols_c(const float2* T, float2* out, const float2* tw, int n
         if (k0 + 3 < fh) { float2 r; r.x = acc[6]; r.y = acc[7]; o[k0 + 3] = r; }
     }
 }
+
+// ---- the ROWS pass (real input, half spectrum out) as two short passes ----
+//   x[y], y = N2*n1 + n2 (real)        X[k], k < fh = n/2 + 1
+//   step A (in place on the real line): for every n2 the N1-point REAL DFT Y[k1][n2] = sum_n1 x[N2*n1 + n2] W_N1^(n1*k1); N1 real inputs have
+//            N1 real degrees of freedom in their spectrum (Y[N1-k1] = conj Y[k1]), so the result is stored half-complex-packed in the item's
+//            own N1 slots {N2*s + n2}: slot 0 = Re Y0, slots 2k1-1 / 2k1 = Re / Im Y[k1] for 0 < 2*k1 < N1, last slot = Re Y[N1/2] for even N1
+//   step C (to region T): X[k] = sum_n2 Y[k mod N1][n2] * W^(n2*k)   -- the twiddle of step B folded in: the exponent is the direct pass's own
+//            (n2 * k mod n), only over N2 terms instead of n.  Complex multiply-adds (4 flops) instead of real ones (2): the pass costs 2 / N1 of
+//            the direct one -- worth it for N1 >= 3.
+DFTCT_FN int dftct_rows_factor(int n)
+{
+    if (n < 12) return 0;
+    int best = 0; float cost = 1.0f;                                   // relative to the direct pass
+    for (int f = 3; f <= 5; f++) if (n % f == 0 && 2.0f / (float)f < cost) { cost = 2.0f / (float)f; best = f; }
+    return best;
+}
+
+DFTCT_FN void dftct_rows_a(float* F, const float2* tw, int n, int N1, int ldf, int lines, int tid, int nt)
+{
+    const int N2 = (int)((float)n / (float)N1 + 0.5f), total = lines * N2;
+    const float inv_n2 = 1.0f / (float)N2;
+    for (int i = tid; i < total; i += nt) {
+        int n2;
+        const int line = dftct_div(i, N2, inv_n2, n2);
+        float* base = F + (size_t)line * ldf + n2;
+        float x[5];
+#pragma unroll
+        for (int n1 = 0; n1 < 5; n1++) if (n1 < N1) x[n1] = base[N2 * n1];
+        float s0 = 0.f, alt = 0.f;
+#pragma unroll
+        for (int n1 = 0; n1 < 5; n1++) if (n1 < N1) { s0 += x[n1]; alt += (n1 & 1) ? -x[n1] : x[n1]; }
+        float re[2] = {0.f, 0.f}, im[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k1 = 1; k1 <= 2; k1++) if (2 * k1 < N1) {
+            int j = 0;                                                  // ((n1 * k1) mod N1) * N2
+#pragma unroll
+            for (int n1 = 0; n1 < 5; n1++) if (n1 < N1) {
+                const float2 w = tw[j];
+                re[k1 - 1] += x[n1] * w.x; im[k1 - 1] -= x[n1] * w.y;   // forward
+                j += k1 * N2; if (j >= n) j -= n;
+            }
+        }
+        base[0] = s0;
+#pragma unroll
+        for (int k1 = 1; k1 <= 2; k1++) if (2 * k1 < N1) { base[N2 * (2 * k1 - 1)] = re[k1 - 1]; base[N2 * (2 * k1)] = im[k1 - 1]; }
+        if ((N1 & 1) == 0) base[N2 * (N1 - 1)] = alt;
+    }
+}
+
+// step C: item = (group of four lines, bin k), as the direct rows pass; F as step A left it -> T[line*fh + k]
+DFTCT_FN void dftct_rows_c(const float* F, float2* T, const float2* tw, int n, int N1, int fh, int ldf, int lines, int tid, int nt)
+{
+    const int N2 = (int)((float)n / (float)N1 + 0.5f), total = ((lines + 3) >> 2) * fh;
+    const float inv_fh = 1.0f / (float)fh, inv_n1 = 1.0f / (float)N1;
+    for (int i = tid; i < total; i += nt) {
+        int k, k1;
+        const int g = dftct_div(i, fh, inv_fh, k);
+        (void)dftct_div(k, N1, inv_n1, k1);
+        // where Y[k1] sits in the packed slots: real part in slot sa, imaginary part (times sgn) in slot sb, none for the two real lines
+        int sa, sb = 0; float sgn = 0.f;
+        if (k1 == 0) sa = 0;
+        else if (2 * k1 == N1) sa = N1 - 1;
+        else if (2 * k1 < N1) { sa = 2 * k1 - 1; sb = 2 * k1; sgn = 1.f; }
+        else { const int kk = N1 - k1; sa = 2 * kk - 1; sb = 2 * kk; sgn = -1.f; }
+        const int l0 = 4 * g;
+        const int l1 = (l0 + 1 < lines) ? l0 + 1 : lines - 1, l2 = (l0 + 2 < lines) ? l0 + 2 : lines - 1, l3 = (l0 + 3 < lines) ? l0 + 3 : lines - 1;
+        const float* a0 = F + (size_t)l0 * ldf + N2 * sa; const float* b0 = F + (size_t)l0 * ldf + N2 * sb;
+        const float* a1 = F + (size_t)l1 * ldf + N2 * sa; const float* b1 = F + (size_t)l1 * ldf + N2 * sb;
+        const float* a2 = F + (size_t)l2 * ldf + N2 * sa; const float* b2 = F + (size_t)l2 * ldf + N2 * sb;
+        const float* a3 = F + (size_t)l3 * ldf + N2 * sa; const float* b3 = F + (size_t)l3 * ldf + N2 * sb;
+        float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f, re3 = 0.f, im3 = 0.f; int j = 0;
+#pragma unroll 2
+        for (int n2 = 0; n2 < N2; n2++) {
+            const float2 w = tw[j];
+            const float r0 = a0[n2], i0 = sgn * b0[n2], r1 = a1[n2], i1 = sgn * b1[n2], r2 = a2[n2], i2 = sgn * b2[n2], r3 = a3[n2], i3 = sgn * b3[n2];
+            re0 += r0 * w.x + i0 * w.y; im0 += i0 * w.x - r0 * w.y;     // (r + i i)(cos - i sin)
+            re1 += r1 * w.x + i1 * w.y; im1 += i1 * w.x - r1 * w.y;
+            re2 += r2 * w.x + i2 * w.y; im2 += i2 * w.x - r2 * w.y;
+            re3 += r3 * w.x + i3 * w.y; im3 += i3 * w.x - r3 * w.y;
+            j += k; if (j >= n) j -= n;
+        }
+        float2* o = T + (size_t)l0 * fh + k;
+        float2 r; r.x = re0; r.y = im0; o[0] = r;
+        if (l0 + 1 < lines) { r.x = re1; r.y = im1; o[fh] = r; }
+        if (l0 + 2 < lines) { r.x = re2; r.y = im2; o[2 * fh] = r; }
+        if (l0 + 3 < lines) { r.x = re3; r.y = im3; o[3 * fh] = r; }
+    }
+}

@@ -680,6 +680,9 @@ __device__ __forceinline__ void dft_cols_generic4(const KcfPool& p, const float2
 #ifndef MOT_FFT_MIXED
 #define MOT_FFT_MIXED 0
 #endif
+#ifndef MOT_FFT_MIXED_ROWS               /* the rows pass (real input) in two steps as well: host-checked (tests/test_dft_ct.py), never run on a GPU */
+#define MOT_FFT_MIXED_ROWS 0
+#endif
 #ifndef MOT_FFT_MIXED_INPLACE            /* the in-place variant (72 / 76 px single pools) too: host-checked, never run on a GPU; costs kcf_predict_kernel<5> 544 B/lane of scratch */
 #define MOT_FFT_MIXED_INPLACE 0
 #endif
@@ -1237,6 +1240,13 @@ __device__ __forceinline__ void fft_forward(const KcfPool& p, float* __restrict_
                 __syncthreads();
                 continue;
             }
+#if MOT_FFT_MIXED && MOT_FFT_MIXED_ROWS
+            if (const int r1 = dftct_rows_factor(p.hb)) {
+                dftct_rows_a(sF, twr, p.hb, r1, 2 * p.fh, g * p.wb, tid, nt);
+                __syncthreads();
+                dftct_rows_c(sF, sT, twr, p.hb, r1, p.fh, 2 * p.fh, g * p.wb, tid, nt);
+            } else
+#endif
             dft_rows_generic4(p, sF, sT, twr, g, tid, nt);                // lines longer than MOT_DFT_MFMA_MAX cells (templates beyond 164 px)
             __syncthreads();
 #if MOT_FFT_MIXED
@@ -1258,6 +1268,13 @@ __device__ __forceinline__ void fft_forward(const KcfPool& p, float* __restrict_
         dft2_generic_inplace(p.hb, p.wb, p.fh, p.d_fh, regB, twr, twc, nch, tid, nt);
     } else {
         float2* T = reinterpret_cast<float2*>(regT);
+#if MOT_FFT_MIXED && MOT_FFT_MIXED_ROWS
+        if (const int r1 = dftct_rows_factor(p.hb)) {                  // hb = r1 * N2: step A in place on the feature lines, step C into region T (dft_ct.h)
+            dftct_rows_a(regB, twr, p.hb, r1, 2 * p.fh, nch * p.wb, tid, nt);
+            __syncthreads();
+            dftct_rows_c(regB, T, twr, p.hb, r1, p.fh, 2 * p.fh, nch * p.wb, tid, nt);
+        } else
+#endif
         dft_rows_generic4(p, regB, T, twr, nch, tid, nt);
         __syncthreads();
 #if MOT_FFT_MIXED

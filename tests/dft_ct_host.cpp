@@ -37,3 +37,10 @@ extern "C" void ct_cols_inplace(float* S, const float* tw_, int n, int N1, int f
         for (int q = 0; q < 4; q++) if (k0 + q < fh) { o[k0 + q].x = acc[(size_t)i * 8 + 2 * q]; o[k0 + q].y = acc[(size_t)i * 8 + 2 * q + 1]; }
     }
 }
+// rows: F = lines of ldf floats (n real values each, overwritten by step A), T = lines of fh complex bins
+extern "C" int ct_rows_factor(int n) { return dftct_rows_factor(n); }
+extern "C" void ct_rows(float* F, float* T, const float* tw, int n, int N1, int fh, int ldf, int lines, int nt)
+{
+    for (int tid = 0; tid < nt; tid++) dftct_rows_a(F, reinterpret_cast<const float2*>(tw), n, N1, ldf, lines, tid, nt);
+    for (int tid = 0; tid < nt; tid++) dftct_rows_c(F, reinterpret_cast<float2*>(T), reinterpret_cast<const float2*>(tw), n, N1, fh, ldf, lines, tid, nt);
+}

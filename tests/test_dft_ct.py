@@ -21,6 +21,8 @@ def lib():
     l.ct_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5
     l.ct_cols_a_reversed.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
     l.ct_cols_inplace.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    l.ct_rows_factor.argtypes = [C.c_int]
+    l.ct_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
     yield l
     os.unlink(out)
 
@@ -77,3 +79,22 @@ def test_in_place_variant_equals_numpy(lib, n):
         lib.ct_cols_inplace(S.ctypes.data, tw.ctypes.data, n, N1, fh, nch)
         got = S.view(np.complex64).reshape(nch, n, fh)
         assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6, (n, N1, fh)
+
+
+@pytest.mark.parametrize("n", [n for n in range(8, 65) if any(n % q == 0 for q in (2, 3, 4, 5))])
+def test_two_step_rows_equal_numpy(lib, n):
+    """real lines -> half spectrum: step A packs the short real DFTs into the line itself, step C folds the twiddles into its sums"""
+    rng = np.random.default_rng(1000 + n)
+    fh = n // 2 + 1; ldf = 2 * fh
+    for N1 in [q for q in (2, 3, 4, 5) if n % q == 0]:
+        for lines, nt in ((7, 64), (48, 512), (1, 5)):
+            x = rng.standard_normal((lines, n)).astype(np.float32)
+            ref = np.fft.rfft(x.astype(np.float64), axis=1)
+            F = np.full((lines, ldf), 7.0, np.float32); F[:, :n] = x
+            T = np.zeros((lines, fh, 2), np.float32); tw = _tw(n)
+            lib.ct_rows(F.ctypes.data, T.ctypes.data, tw.ctypes.data, n, N1, fh, ldf, lines, nt)
+            got = T.view(np.complex64).reshape(lines, fh)
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6, (n, N1, lines, nt)
+            assert np.all(F[:, n:] == 7.0), "the pad floats of a line are not the pass's to touch"
+    f = lib.ct_rows_factor(n)
+    assert f in (0, 3, 4, 5) and (f == 0 or n % f == 0)
