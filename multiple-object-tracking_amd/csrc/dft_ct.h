@@ -9,6 +9,7 @@
 // overwrites the same set {N2*k1 + n2} -- so it needs no second buffer and no barrier of its own; N1 is the SMALL factor (2..5), so the item
 // holds at most 5 x 2 complex inputs.  Step C is the old direct pass with N2 terms instead of wb and a block of consecutive input lines.
 // Both take every twiddle from the line's own table (tw[j] = (cos, sin)(2 pi j / wb), the forward transform conjugates it), no new tables.
+// The rows pass (real input) has its two-step form further down (dftct_rows_a / dftct_rows_c).
 // Plain pointers and ints only: the same text compiles for the host, where tests/test_dft_ct.py checks it against numpy for every line
 // length from 8 to 64 (DFTCT_FN / DFTCT_HOST).  Round 5: compiled into the kernels only with -DMOT_FFT_MIXED=1 (`make fftmix`).
 #pragma once

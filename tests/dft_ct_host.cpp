@@ -44,3 +44,13 @@ extern "C" void ct_rows(float* F, float* T, const float* tw, int n, int N1, int 
     for (int tid = 0; tid < nt; tid++) dftct_rows_a(F, reinterpret_cast<const float2*>(tw), n, N1, ldf, lines, tid, nt);
     for (int tid = 0; tid < nt; tid++) dftct_rows_c(F, reinterpret_cast<float2*>(T), reinterpret_cast<const float2*>(tw), n, N1, fh, ldf, lines, tid, nt);
 }
+// the whole forward transform of `nch` planes as fft_forward's general branch strings the passes together under MOT_FFT_MIXED (+ _ROWS):
+// B[(ch*wb + x)*ldf + y] real -> rows -> T[(ch*wb + x)*fh + k] -> columns -> out[(ch*wb + x')*fh + k]
+extern "C" void ct_forward2d(float* B, float* T, float* out, const float* twr, const float* twc, int hb, int wb, int nch, int r1, int c1, int nt)
+{
+    const int fh = hb / 2 + 1, ldf = 2 * fh, lines = nch * wb;
+    for (int tid = 0; tid < nt; tid++) dftct_rows_a(B, reinterpret_cast<const float2*>(twr), hb, r1, ldf, lines, tid, nt);
+    for (int tid = 0; tid < nt; tid++) dftct_rows_c(B, reinterpret_cast<float2*>(T), reinterpret_cast<const float2*>(twr), hb, r1, fh, ldf, lines, tid, nt);
+    for (int tid = 0; tid < nt; tid++) dftct_cols_a(reinterpret_cast<float2*>(T), reinterpret_cast<const float2*>(twc), wb, c1, fh, nch, tid, nt);
+    for (int tid = 0; tid < nt; tid++) dftct_cols_c(reinterpret_cast<const float2*>(T), reinterpret_cast<float2*>(out), reinterpret_cast<const float2*>(twc), wb, c1, fh, nch, tid, nt);
+}

@@ -22,6 +22,7 @@ def lib():
     l.ct_cols_a_reversed.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
     l.ct_cols_inplace.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
     l.ct_rows_factor.argtypes = [C.c_int]
+    l.ct_forward2d.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6
     l.ct_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
     yield l
     os.unlink(out)
@@ -98,3 +99,19 @@ def test_two_step_rows_equal_numpy(lib, n):
             assert np.all(F[:, n:] == 7.0), "the pad floats of a line are not the pass's to touch"
     f = lib.ct_rows_factor(n)
     assert f in (0, 3, 4, 5) and (f == 0 or n % f == 0)
+
+
+@pytest.mark.parametrize("hb,wb", [(24, 24), (16, 18), (18, 16), (21, 24), (24, 15), (50, 50), (42, 30), (20, 25)])
+def test_forward_2d_as_the_kernel_strings_the_passes(lib, hb, wb):
+    """rows then columns through the layouts the kernel uses (feature lines of ldf = 2*fh floats, x slow, y fast; half spectrum along y)"""
+    rng = np.random.default_rng(hb * 100 + wb)
+    nch, fh = 5, hb // 2 + 1; ldf = 2 * fh
+    r1 = lib.ct_rows_factor(hb); c1 = lib.ct_small_factor(wb)
+    assert r1 and c1
+    x = rng.standard_normal((nch, wb, hb)).astype(np.float32)
+    ref = np.fft.fft(np.fft.rfft(x.astype(np.float64), axis=2), axis=1)            # [ch][x'][k]
+    B = np.zeros((nch, wb, ldf), np.float32); B[:, :, :hb] = x
+    T = np.zeros((nch, wb, fh, 2), np.float32); out = np.zeros_like(T)
+    lib.ct_forward2d(B.ctypes.data, T.ctypes.data, out.ctypes.data, _tw(hb).ctypes.data, _tw(wb).ctypes.data, hb, wb, nch, r1, c1, 512)
+    got = out.view(np.complex64).reshape(nch, wb, fh)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-6
