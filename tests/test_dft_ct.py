@@ -112,6 +112,7 @@ def test_forward_2d_as_the_kernel_strings_the_passes(lib, hb, wb):
     ref = np.fft.fft(np.fft.rfft(x.astype(np.float64), axis=2), axis=1)            # [ch][x'][k]
     B = np.zeros((nch, wb, ldf), np.float32); B[:, :, :hb] = x
     T = np.zeros((nch, wb, fh, 2), np.float32); out = np.zeros_like(T)
-    lib.ct_forward2d(B.ctypes.data, T.ctypes.data, out.ctypes.data, _tw(hb).ctypes.data, _tw(wb).ctypes.data, hb, wb, nch, r1, c1, 512)
+    twr, twc = _tw(hb), _tw(wb)                                            # (kept alive across the call)
+    lib.ct_forward2d(B.ctypes.data, T.ctypes.data, out.ctypes.data, twr.ctypes.data, twc.ctypes.data, hb, wb, nch, r1, c1, 512)
     got = out.view(np.complex64).reshape(nch, wb, fh)
     assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-6
