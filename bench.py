@@ -87,6 +87,32 @@ def _cpu_worker(args, want_state=False):
     return n * done, dt, done
 
 
+def committed_traffic(dom, n_tracks, plain_workload, defer, split, prof_dir=None):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (profiles/rNN_traffic.json), or (None, None).
+    The counters were collected on ONE workload -- N tracks of 80 x 80 px on the plain synthetic stream -- and the key carries N only, so any
+    other workload (another template size, per-track sizes, detection sizes, detector noise) gets null: round-5 verdict, a 64-96 px per-track
+    run carried the 80-px figure of a launch that is not that kernel."""
+    if not plain_workload:
+        return None, None
+    prof_dir = prof_dir or os.path.join(ROOT, "profiles")
+    for cand_file in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(prof_dir, cand_file)
+        if not os.path.exists(tpath):
+            continue
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(("kcf_predict" if dom.startswith("kcf_predict") else "kcf_update_blend" if split else "kcf_update") + f"_bytes_per_launch_n{n_tracks}")
+            if defer and "deferred_blend" not in tj:
+                traffic = None                                          # counter passes of a build without the deferred blend: not this kernel
+        except Exception:
+            traffic = None
+        if traffic is None:
+            return None, None
+        return traffic, (f"profiles/{cand_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command "
+                         "(tools/collect_profiles.sh), not measured by this run")
+    return None, None
+
+
 def cpu_baseline(n_tracks, size, budget_s=12.0):
     """CPU baseline on the host cores of this box (rank 0, N = 1 only), bounded samples of the same synthetic workload:
       * value / kind "reference": the reference's own code (oracle/_ref, when present), ONE core (the reference's tracker thread is
@@ -382,15 +408,17 @@ def main():
         # the line so a scaling run can be checked against DESIGN.md section 5's table
         rank_stages = None
         if n_rank_prof:
-            try:                                                        # an informative leg: it must never cost the line
-                acc4 = np.zeros(4)
-                for _ in range(n_rank_prof):
-                    ctx.debug_profile_stages(True)
-                    step(f); f += 1
-                    acc4 += ctx.debug_profile_stages(False, read=True)
-                mine = {"rank": rank, **{k: float(v) for k, v in zip(("predict_ms", "gather_ms", "chain_ms", "update_ms"), acc4 / n_rank_prof)}}
-            except Exception as e:
-                mine = {"rank": rank, "error": str(e)[:200]}
+            # an informative leg: it must never cost the line -- and never leave the other ranks alone in a collective (round-5 advisor finding):
+            # every rank ALWAYS executes its n_rank_prof frames (each holds the frame's all-gather); only the profile calls may fail
+            acc4 = np.zeros(4); perr = None
+            for _ in range(n_rank_prof):
+                try: ctx.debug_profile_stages(True)
+                except Exception as e: perr = perr or str(e)[:200]
+                step(f); f += 1
+                try: acc4 += ctx.debug_profile_stages(False, read=True)
+                except Exception as e: perr = perr or str(e)[:200]
+            if perr is None: mine = {"rank": rank, **{k: float(v) for k, v in zip(("predict_ms", "gather_ms", "chain_ms", "update_ms"), acc4 / n_rank_prof)}}
+            else: mine = {"rank": rank, "error": perr}
             rows = [None] * world
             try:
                 dist.all_gather_object(rows, mine)
@@ -511,20 +539,8 @@ def main():
             # rocprofv3 --kernel-trace of this command reports; the isolated launch of the profile frames is given beside it
             launch_ms = inloop_ms if (inloop_ms is not None and dom.startswith("kcf_predict")) else isolated_ms
             achieved = per_launch / (launch_ms * 1e-3) / 1e9
-            traffic = None; tj = {}; traffic_src = None
-            for cand_file in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-                tpath = os.path.join(ROOT, "profiles", cand_file)
-                if os.path.exists(tpath):
-                    try:
-                        tj = json.load(open(tpath))
-                        traffic = tj.get(("kcf_predict" if dom.startswith("kcf_predict") else "kcf_update_blend" if split else "kcf_update") + f"_bytes_per_launch_n{n_tracks}")
-                        if defer and "deferred_blend" not in tj:
-                            traffic = None                              # counter passes of a build without the deferred blend: not this kernel
-                        if traffic is not None:
-                            traffic_src = f"profiles/{cand_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (tools/collect_profiles.sh), not measured by this run"
-                    except Exception:
-                        traffic = None
-                    break
+            plain = size == 80 and not (args.det_sizes or args.per_track_sizes or args.miss_pct or args.fp_pct or args.nms)
+            traffic, traffic_src = committed_traffic(dom, n_tracks, plain, defer, split)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "alg_bytes_per_launch": per_launch, "avg_launch_ms": launch_ms,

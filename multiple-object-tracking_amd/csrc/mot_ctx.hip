@@ -323,6 +323,15 @@ int run_batch(mot_ctx* c, bool predict, const int* ids, int n, const float* cons
             HIPCHK(launch_kalman_predict(c->kal, slots_dev, nullptr, n, boxes_b_dev, clamp, c->stream));
         } else HIPCHK(launch_kalman_update(c->kal, slots_dev, nullptr, n, boxes_a_dev, c->stream));
     } else {
+        // The groups of a batch lie one behind the other in the staging area at a RUNNING float offset: a group's own npx as the stride of the
+        // item index would put a later, smaller-template group inside an earlier group's patches (round-5 advisor finding: with the zero-copy
+        // path the earlier kernel is still reading them over PCIe).  n * patch_floats (the largest template) bounds the total.
+        size_t poff = 0;
+        if (patches && !ring && (size_t)n * patch_floats > c->patches_cap) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->patches_cap = (size_t)n * patch_floats * 2;
+            HIPCHK(c->d_patches.alloc(c->patches_cap)); HIPCHK(c->h_patches.alloc(c->patches_cap));
+        }
         for (size_t gi = 0; gi + 1 < g.start.size(); gi++) {
             const int s = g.start[gi], cnt = g.start[gi + 1] - s;
             PoolHost& ph = *c->pools[g.pool[gi]];
@@ -331,19 +340,15 @@ int run_batch(mot_ctx* c, bool predict, const int* ids, int n, const float* cons
             if (patches) {
                 const size_t npx = (size_t)ph.dev.rows * ph.dev.cols;
                 if (ring) {
-                    float* hp = R.patches.p + (size_t)half * R.half_floats;
-                    for (int q = 0; q < cnt; q++) memcpy(hp + (size_t)(s + q) * npx, patches[g.order[s + q]], npx * sizeof(float));
-                    l.patches = R.d_patches + (size_t)half * R.half_floats + (size_t)s * npx;
+                    float* hp = R.patches.p + (size_t)half * R.half_floats + poff;
+                    for (int q = 0; q < cnt; q++) memcpy(hp + (size_t)q * npx, patches[g.order[s + q]], npx * sizeof(float));
+                    l.patches = R.d_patches + (size_t)half * R.half_floats + poff;
                 } else {
-                    if ((size_t)n * npx > c->patches_cap) {
-                        HIPCHK(hipStreamSynchronize(c->stream));
-                        c->patches_cap = (size_t)n * npx * 2;
-                        HIPCHK(c->d_patches.alloc(c->patches_cap)); HIPCHK(c->h_patches.alloc(c->patches_cap));
-                    }
-                    for (int q = 0; q < cnt; q++) memcpy(c->h_patches.p + (size_t)(s + q) * npx, patches[g.order[s + q]], npx * sizeof(float));
-                    HIPCHK(hipMemcpyAsync(c->d_patches.p + (size_t)s * npx, c->h_patches.p + (size_t)s * npx, (size_t)cnt * npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
-                    l.patches = c->d_patches.p + (size_t)s * npx;
+                    for (int q = 0; q < cnt; q++) memcpy(c->h_patches.p + poff + (size_t)q * npx, patches[g.order[s + q]], npx * sizeof(float));
+                    HIPCHK(hipMemcpyAsync(c->d_patches.p + poff, c->h_patches.p + poff, (size_t)cnt * npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
+                    l.patches = c->d_patches.p + poff;
                 }
+                poff += (size_t)cnt * npx;
             }
             l.boxes_in = boxes_in ? boxes_a_dev + s : nullptr;
             l.boxes_out = predict ? boxes_b_dev + s : nullptr;

@@ -319,12 +319,14 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     RoctxRange range_("mot.frame.assoc_update");
     DLState& S = d->S;
     if (!d->begun) return fail(MOT_ERR_STATE, "mot_step_finish_device without mot_step_begin_device");
-    d->begun = false;
+    // A refused call leaves the frame BEGUN (round-5 advisor finding: the checks used to run behind `begun = false`, so a finish with a wrong list
+    // lost the frame -- its predict had run and consumed the pending updates -- and could not be repeated with the right one).
     if (nD < 0 || nD > S.max_dets || (nD && !dets_dev)) return fail(MOT_ERR_ARG, "bad detection list (%d, max %d)", nD, S.max_dets);
     // the two-call form: the spectra of this frame were computed (or adopted from a look-ahead launch) for the list given to the begin call -- the
     // list associated here must be that one (round-4 advisor finding: a different list silently got the other list's spectra)
     if ((d->feat_early || d->have_cur) && (dets_dev != d->begin_dets || nD != d->begin_nD))
         return fail(MOT_ERR_ARG, "mot_step_finish_device: detection list (%p, %d) differs from the one given to the begin call (%p, %d)", dets_dev, nD, d->begin_dets, d->begin_nD);
+    d->begun = false;
     const bbox_t* g = gathered ? (const bbox_t*)gathered : S.gather;
     const bbox_t* trk = g;
     if (S.world > 1) { hipLaunchKernelGGL(dl_scatter_kernel, dim3(1), dim3(1024), 0, c->stream, S, g); HIPCHK(hipGetLastError()); trk = S.pred; }
@@ -725,7 +727,7 @@ int mot_debug_snapshot(mot_ctx* c, void* dst_dev, size_t* bytes)
     char* q = (char*)dst_dev;
     auto put = [&](const void* src, size_t n) -> hipError_t { hipError_t e = src ? hipMemcpyAsync(q, src, n, hipMemcpyDeviceToDevice, c->stream) : hipMemsetAsync(q, 0xFF, n, c->stream); q += n; return e; };
     HIPCHK(put(S.nlive, 4)); HIPCHK(put(S.upd_count, 4)); HIPCHK(put(S.loc_count, 4));
-    { const unsigned fno = d->frame_no; HIPCHK(hipMemsetAsync(q, 0, 4, c->stream)); (void)fno; q += 4; }
+    { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)q, (int)d->frame_no, 1, c->stream)); q += 4; }   // word [3]: frames stepped so far (the value travels in the fill packet: no host source to keep alive)
     HIPCHK(put(S.tid, 4 * cap)); HIPCHK(put(S.bbox, 24 * cap));
     HIPCHK(put(S.gather + (size_t)S.rank * S.spr, 24 * cap));
     HIPCHK(put(S.slot, 4 * cap));

@@ -7,8 +7,11 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+ORACLE_SRC_DIR = os.path.join(ROOT, "oracle")
+# MOT_ORACLE_DIR: load the checker libraries from another build of the same sources -- oracle/_asan (make -C oracle asan: AddressSanitizer +
+# UBSan, tests/test_sanitizers.py); such a directory is used as built, never rebuilt from here
+ORACLE_DIR = os.environ.get("MOT_ORACLE_DIR") or ORACLE_SRC_DIR
+REF_DIR = os.path.join(ORACLE_SRC_DIR, "_ref")
 
 
 class BBox(C.Structure):
@@ -25,8 +28,8 @@ def P(a):
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "libmot_oracle.so")
-    src = os.path.join(ORACLE_DIR, "mot_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    src = os.path.join(ORACLE_SRC_DIR, "mot_oracle.c")
+    if ORACLE_DIR == ORACLE_SRC_DIR and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
     return so
 

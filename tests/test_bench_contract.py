@@ -171,3 +171,15 @@ def test_round5_final_tree_line():
     assert d["order"].startswith("td.cpp") and d["calls"] == 192
     assert 0 < d["per_object_frame_us"] < d["reference_per_object_frame_us"], "the per-object interface must beat the reference's own calls per object and frame"
     assert d["tracker_update_us"] < d["reference_tracker_update_us"] and d["tracker_predict_us"] < d["reference_tracker_predict_us"]
+
+
+def test_traffic_is_keyed_by_the_workload():
+    """round-5 verdict (measurement hygiene): the committed PMC passes belong to ONE workload -- N tracks of 80 x 80 px on the plain stream; a run
+    of any other workload (template size, per-track sizes, detection sizes, detector noise) must carry `traffic: null`, not that figure"""
+    bench = _load(os.path.join(ROOT, "bench.py"), "bench_mod_traffic")
+    dom = "kcf_predict (+ deferred model update of the previous frame)"
+    got, src = bench.committed_traffic(dom, 1024, True, True, True)
+    assert got is not None and got > 150e6 and "profiles/r0" in src
+    assert bench.committed_traffic(dom, 1024, False, True, True) == (None, None)          # per-track sizes / 148 px / detector noise
+    assert bench.committed_traffic(dom, 999, True, True, True) == (None, None)            # a track count nobody measured
+    assert bench.committed_traffic(dom, 1024, True, True, True, prof_dir="/nonexistent") == (None, None)

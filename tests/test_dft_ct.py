@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def lib():
     out = os.path.join(tempfile.gettempdir(), f"dft_ct_host_{os.getpid()}.so")
-    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-o", out, os.path.join(ROOT, "tests", "dft_ct_host.cpp")])
+    # MOT_DFT_CT_FLAGS: extra compiler flags (tests/test_sanitizers.py: -fsanitize=address,undefined)
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off"] + os.environ.get("MOT_DFT_CT_FLAGS", "").split() +
+                          ["-o", out, os.path.join(ROOT, "tests", "dft_ct_host.cpp")])
     l = C.CDLL(out)
     l.ct_small_factor.argtypes = [C.c_int]
     l.ct_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5

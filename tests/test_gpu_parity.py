@@ -161,6 +161,41 @@ def test_back_to_back_patch_updates_through_the_staging_ring(mot, oracle):
     c.close()
 
 
+def test_mixed_template_sizes_with_caller_patches_in_one_batch(mot, oracle):
+    """Round-5 advisor finding (mot_ctx.hip, run_batch): the groups of a batch that mixes template sizes were staged at item index x the group's OWN
+    patch size, so a later group with the smaller template landed inside the earlier group's patches -- which, on the zero-copy path, the earlier
+    group's kernel is still reading over PCIe.  Three 96 x 96 and three 64 x 64 tracks (the larger pool is created first, so its group comes first),
+    ids interleaved, ONE batch of six with caller patches: updates, then a predict, both through the zero-copy ring (<= 8 items) and through the
+    staged path (a batch of 12 > 8); models and responses against the oracle (kcf.cpp:455-476 per object)."""
+    rng = np.random.default_rng(23)
+    for n_each in (3, 6):                                               # 6 items: zero-copy ring; 12 items: staged copies
+        c = mot.MotContext(max_tracks=16, max_dets=16)
+        sizes = [96] * n_each + [64] * n_each
+        boxes = [(20 + 100 * (i % 12), 30 + 110 * (i // 12), 30 + 110 * (i // 12) + s - 1, 20 + 100 * (i % 12) + s - 1, i % 3, 0.9) for i, s in enumerate(sizes)]
+        ids = c.tracks_new(boxes, first_update=False)
+        oks = [C.c_void_p(oracle.orc_kcf_new(P(orc.boxes_array([b])), 0)) for b in boxes]
+        order = [j for pair in zip(range(n_each), range(n_each, 2 * n_each)) for j in pair]     # 96, 64, 96, 64, ...
+        for r in range(3):
+            pats = [np.ascontiguousarray(rng.integers(0, 256, s * s).astype(np.float32)) for s in sizes]
+            c.update_batch_patches([ids[j] for j in order], [pats[j] for j in order], [boxes[j] for j in order])
+            for j, k in enumerate(oks):
+                oracle.orc_kcf_update(k, P(pats[j]), P(orc.boxes_array([boxes[j]])))
+        probe = [np.ascontiguousarray(rng.integers(0, 256, s * s).astype(np.float32)) for s in sizes]
+        pred = c.predict_batch_patches([ids[j] for j in order], [probe[j] for j in order])
+        for q, j in enumerate(order):
+            k = oks[j]; nb = (sizes[j] // 4) ** 2
+            pb = BBox(); oracle.orc_kcf_predict(k, P(probe[j]), C.byref(pb))
+            assert tuple(boxes_to_np(pred[q:q + 1])[0])[:4] == (pb.l, pb.t, pb.b, pb.r), f"{2 * n_each} items, track {j}: predicted box"
+            resp = c.get_response(ids[j]); ref = orc.arr(oracle.orc_kcf_response(k), nb)
+            assert resp.argmax() == ref.argmax(), f"track {j}: arg-max"
+            assert abs(resp.max() - ref.max()) <= PEAK_RTOL * abs(ref.max()), f"track {j}: peak {resp.max()} vs {ref.max()}"
+            _, alpha = c.get_model(ids[j]); ra = orc.arr(oracle.orc_kcf_alpha(k), alpha.size)
+            np.testing.assert_allclose(alpha, ra, rtol=0, atol=2e-5 * np.abs(ra).max())
+        for k in oks:
+            oracle.orc_kcf_delete(k)
+        c.close()
+
+
 def test_patch_updates_that_wait_for_their_kernel():
     """the off-variant of the switch (MOT_ZC_ASYNC=0, read once per process): the same test in a process of its own"""
     import subprocess, sys

@@ -25,7 +25,7 @@ class Info(C.Structure):
 def model():
     orc.build_oracle()
     so = os.path.join(orc.ORACLE_DIR, "liblap_model.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(orc.ORACLE_DIR, "lap_model.c")):
+    if orc.ORACLE_DIR == orc.ORACLE_SRC_DIR and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(orc.ORACLE_SRC_DIR, "lap_model.c"))):
         subprocess.check_call(["make", "-C", orc.ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     lib.lapm_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

@@ -24,7 +24,7 @@ class MksInfo(C.Structure):
 def mks():
     orc.build_oracle()
     so = os.path.join(orc.ORACLE_DIR, "libmk_sparse_model.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(orc.ORACLE_DIR, "mk_sparse_model.c")):
+    if orc.ORACLE_DIR == orc.ORACLE_SRC_DIR and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(orc.ORACLE_SRC_DIR, "mk_sparse_model.c"))):
         subprocess.check_call(["make", "-C", orc.ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
     return C.CDLL(so)
 

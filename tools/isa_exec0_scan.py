@@ -36,6 +36,7 @@ import sys
 import tempfile
 
 OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+ARCH = os.environ.get("MOT_ARCH", "gfx950")          # the Makefile's ARCH; --arch overrides
 _EXEC_WRITE = re.compile(r"^\s*s_\w+\s+exec(_lo|_hi)?\b|^\s*s_\w*saveexec\w*\s|^\s*s_\w*wrexec\w*\s")
 _VECTOR = re.compile(r"^\s*(v_|ds_|flat_|global_|scratch_|buffer_|image_)\w+\s")
 _NO_EXEC = re.compile(r"^\s*(v_readlane_b32|v_writelane_b32|v_readfirstlane_b32)\s")
@@ -123,7 +124,7 @@ def code_objects(path):
         for _ in range(num):
             o, sz, tl = struct.unpack_from("<QQQ", data, off); off += 24
             triple = data[off:off + tl].decode(errors="replace"); off += tl
-            if "gfx950" in triple and sz: out.append(data[i + o:i + o + sz])
+            if ARCH in triple and sz: out.append(data[i + o:i + o + sz])
         pos = i + len(magic)
     return out
 
@@ -142,15 +143,24 @@ def scan_file(path):
 
 
 def main(argv):
-    bad = 0
+    """exit 1 on a hit, 2 when a file yields implausibly few sites (--min-sites N, default 1: a build gate that examines nothing -- another --offload-arch,
+    a compressed offload bundle, a changed objdump listing -- must not pass vacuously; round-5 advisor finding)"""
+    bad = 0; min_sites = 1; thin = 0
+    if "--min-sites" in argv:
+        i = argv.index("--min-sites"); min_sites = int(argv[i + 1]); argv = argv[:i] + argv[i + 2:]
+    if "--arch" in argv:
+        i = argv.index("--arch"); global ARCH; ARCH = argv[i + 1]; argv = argv[:i] + argv[i + 2:]
     for p in argv:
         hits, loops = scan_file(p)
+        if loops < min_sites:
+            thin += 1
+            print(f"{p}: only {loops} sites examined (expected >= {min_sites}): no {ARCH} code object found, or the listing format changed")
         print(f"{p}: {loops} loop exits / if joins examined, {len(hits)} with vector instructions in front of the EXEC restore")
         for rule, func, line, found in hits:
             bad += 1
             print(f"  {func}  ({rule}; branch at line {line}): {len(found)} instruction(s) run for the wrong lanes")
             for n, s in found[:16]: print(f"      {n}: {s}")
-    return 1 if bad else 0
+    return 1 if bad else (2 if thin else 0)
 
 
 if __name__ == "__main__":
