@@ -319,6 +319,9 @@ int mot_get_assoc_stats(mot_ctx* ctx, int* out16);
  *   [9] augmentations [10] step-5 passes [11] step-3 events [12..14] 10 ns ticks: steps 3+4, step 5, total;
  *   [15] what decided this launch: 0 certificate, 1 sparse emulation (accepted by its after-the-fact check), 2 dense emulation
  * [16..20] cumulative launch counts of this context by certificate outcome 0..4; [24] sparse emulation accepted, [25] refused;
+ * [21..23] device loop, cumulative: tie frames committed PROVISIONALLY (one pair of tracks could swap their detections at equal cost: the
+ *   solver's optimum is committed at once, the next predict computes both alternatives for the pair, and the order-exact emulation -- running
+ *   beside that predict -- only names the one the reference returns), swaps applied, frames whose bit the dense emulation had to decide;
  * [26..28] dense solver (frames whose far matches defeat the sparse one: detector misses + false positives) in the most recent launch:
  *   settled columns, free rows after the greedy start, time in 10 ns ticks; [29] launches in which it ran, [30] ... and were certified */
 int mot_get_lap_stats(mot_ctx* ctx, int* out32);

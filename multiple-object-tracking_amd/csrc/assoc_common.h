@@ -104,7 +104,22 @@ struct AssocArgs {
     u64* linemin;        // [MK_MAXN] keys
     int* dims;           // [4]: nR, nC, rowsAreTrackers, minIsPerRow
     double* cost_only;   // assoc_cost_kernel output
+    // round 6: every launch chain has a sequence number (host counter, >= 1); the protocol words between the solver's workgroup, the sparse
+    // emulation and the final kernel carry it in their upper bits, so a word left by another frame is never mistaken for this frame's
+    unsigned seq;
+    int stream_emu;      // the sparse emulation runs as a kernel of its own on the emulation stream (device loop, provisional commits possible)
+    bbox_t* det_copy;    // stream_emu: the row scan copies the detection list here; the emulation's kernel reads this copy (the caller may overwrite its list behind the call)
 };
+
+// tagged protocol word: (seq << 2) | value.  Value of `word` for chain `seq`: its low bits if the tag is this chain's, `newer` if a LATER chain
+// has written the word since (this chain's reader is obsolete), 0 (nothing yet) if the word is older
+__device__ __forceinline__ int tagged_value(int word, unsigned seq, int newer)
+{
+    const unsigned t = (unsigned)word >> 2, s = seq & 0x3FFFFFFFu;
+    if (t == s) return word & 3;
+    return ((t - s) & 0x3FFFFFFFu) < 0x20000000u ? newer : 0;
+}
+__device__ __forceinline__ int tagged_word(unsigned seq, int v) { return (int)(((seq & 0x3FFFFFFFu) << 2) | (unsigned)v); }
 
 __device__ __forceinline__ void resolve_dims(const AssocArgs& a, int& nR, int& nC, bool& rowsTrk)
 {

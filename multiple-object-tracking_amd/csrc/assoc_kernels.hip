@@ -405,11 +405,12 @@ __device__ void mk_fused_cost(const AssocArgs& a, MkShared& S, int nR, int nC, b
 // workgroup itself (thread = row, rows <= columns): what assoc_sub_kernel does chip-wide.  Behind the fast path the dense
 // emulation is the rare last resort, so its preparation is not launched per frame any more (one early-exit launch less on every
 // frame); a stream that keeps needing it gets the chip-wide kernel back through the host-side hint.  ~0.4 ms at 1024 x 1024.
-__device__ void mk_prepare_dense(const AssocArgs& a, int nR, int nC, bool rowsTrk)
+// cc_rmin (patch step of a provisionally committed frame): the line minima have been re-armed since; the row's minimum is its first candidate
+__device__ void mk_prepare_dense(const AssocArgs& a, int nR, int nC, bool rowsTrk, const double* cc_rmin = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = tid, wordsR = (nR + 63) >> 6, wordsC = (nC + 63) >> 6;
-    const double rmin = r < nR ? dunkey(a.linemin[r]) : 0.0;            // the row scan left the row minima here
+    const double rmin = r < nR ? (cc_rmin ? cc_rmin[(size_t)r * LAP_K] : dunkey(a.linemin[r])) : 0.0;            // the row scan left the row minima here
     u64 zw = 0;
     for (int c = 0; c < nC; c++) {
         bool z = false;
@@ -438,14 +439,65 @@ __device__ inline void lap_final_bookkeeping(const AssocArgs& a, int mode, bool 
     if (mode == 1) L.hdr[LAP_H_CUM + (certified ? 8 : 9)] += 1;
     // re-arm for the next launch (this workgroup is the last reader)
     L.hdr[LAP_H_NEDGES] = 0; L.hdr[LAP_H_VIOL] = 0; L.hdr[LAP_H_BAD] = 0; L.hdr[LAP_H_SOLVE] = 5; L.hdr[LAP_H_SPVIOL] = 0; L.hdr[LAP_H_MODE] = 2;
-    L.hdr[LAP_H_DENSE] = 0; L.hdr[LAP_H_DONE] = 0; L.hdr[LAP_H_CERT] = 0; L.hdr[LAP_H_VERDICT] = 0; *L.cmaxkey = 0ull;
+    L.hdr[LAP_H_DENSE] = 0; L.hdr[LAP_H_DONE] = 0; L.hdr[LAP_H_CERT] = 0; *L.cmaxkey = 0ull;
+    // (LAP_H_VERDICT / LAP_H_EMU carry their chain's sequence number since round 6: a stale value is recognised, and the emulation's kernel
+    //  of a certified frame may still be about to read the verdict -- they are not re-armed)
+}
+
+// ---- provisional commits (round 6; mot_dev.h: ProvRec, lap_kernels.hip: lap_try_provisional) ---------------------------------------
+// The patch step: `asg` is what an order-exact emulation returned for the provisionally committed frame.  It must be the committed matching M
+// (lap.colOfRow) or M with the columns of rows A and B exchanged; in the second case the two tracks take over what their shadow slots hold --
+// model, alpha, response, position, scale, flags: the state of "adopted the other detection", with or without the predict in between -- and,
+// if a predict launch ran in between, the shadow items' predicted boxes.  Anything else latches a device error (never seen; the certificate's
+// argument excludes it).  One 1024-thread workgroup.
+template <typename AT>
+__device__ void prov_apply(const AssocArgs& a, const LifeArgs& life, const AT* asg, int nR, bbox_t* pred_cur, bool by_dense)
+{
+    const int tid = threadIdx.x;
+    const LapWs& L = a.ws.lap;
+    const ProvRec* rec = life.prov.rec;
+    const DLState& D = life.S;
+    const KcfPool& kp = life.kp;
+    const int rA = rec->rowA, rB = rec->rowB, cA = rec->colA, cB = rec->colB;
+    const int gA = (int)asg[rA], gB = (int)asg[rB];
+    const bool same = gA == cA && gB == cB, swapped = gA == cB && gB == cA;
+    bool bad = !(same || swapped);
+    if (tid < nR && tid != rA && tid != rB && (int)asg[tid] != (int)L.colOfRow[tid]) bad = true;   // every other row is forced
+    const bool anybad = __syncthreads_or(bad) != 0;
+    if (swapped && !anybad) {
+        const int tot = MOT_NCHAN * kp.nbins;
+        for (int k = 0; k < 2; k++) {
+            const ProvTrack t = rec->t[k];
+            if (t.sh < 0) continue;
+            const float2* xs = kp.xm + (size_t)t.sh * tot; float2* xd = kp.xm + (size_t)t.slot * tot;
+            for (int i = tid; i < tot; i += MK_THREADS) xd[i] = xs[i];
+            for (int i = tid; i < kp.nbins; i += MK_THREADS) kp.alpha[(size_t)t.slot * kp.nbins + i] = kp.alpha[(size_t)t.sh * kp.nbins + i];
+            for (int i = tid; i < kp.nb; i += MK_THREADS) kp.response[(size_t)t.slot * kp.nb + i] = kp.response[(size_t)t.sh * kp.nb + i];
+            if (tid == 0) {
+                kp.pos[t.slot] = kp.pos[t.sh]; kp.scale[t.slot] = kp.scale[t.sh]; kp.first_update[t.slot] = kp.first_update[t.sh];
+                D.pend_det[t.slot] = D.pend_det[t.sh];
+                D.bbox[t.newpos] = t.box_alt;                          // tracker_info.bbox = the adopted detection (td.cpp:519-521)
+                if (pred_cur) pred_cur[t.newpos] = pred_cur[rec->n_new + (t.sh - life.prov.sh_base)];
+            }
+        }
+    }
+    if (tid == 0) {
+        if (anybad) D.err[5] = rec->seq;                               // sticky: devloop_check reports it
+        for (int k = 0; k < 2; k++) if (rec->t[k].sh >= 0) D.pend_det[rec->t[k].sh] = -1;
+        *D.loc_count = rec->n_new;                                     // the shadow items leave the predict list
+        L.hdr[LAP_H_PROV] = 0; L.hdr[LAP_H_PMODE] = 0;
+        if (swapped && !anybad) L.hdr[LAP_H_PSTAT + 1] += 1;
+        if (by_dense) { L.hdr[LAP_H_PSTAT + 2] += 1; L.hdr[LAP_H_LAST + 15] = 2; L.hdr[LAP_H_CUM + 9] += 1; } else L.hdr[LAP_H_CUM + 8] += 1;
+    }
 }
 
 // HELP = false: one workgroup does everything (no helper code compiled in: it would cost the hot loops registers).
 // HELP = true : launched with 1 + MK_HELPERS workgroups; workgroups 1.. run mk_helper_loop.
 // lap_mode: the fast path (lap_kernels.hip) ran in front of this launch; if its certificate holds (lap_certify.h) the
 // solver's matching IS the reference's assignment and the emulation is skipped.
-template <bool HELP>
+// PATCH: the instantiation launched as the patch step of a provisionally committed frame (launch_prov_patch; a kernel of its own so that the
+// final kernel of every frame keeps its registers)
+template <bool HELP, bool PATCH = false>
 __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int want_cost, LifeArgs life, int lap_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char mk_raw[];
@@ -462,7 +514,47 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     // then stay behind one L2 (-0.4 us per step 5; placement only affects speed, never correctness).  The other blocks exit.
     // an earlier kernel of the chain (the solver's fused tail / the sparse emulation) has already decided AND committed this frame
     // (lifecycle step included): bookkeeping only.  (The live count, and with it nR / nC, already belong to the next frame.)
-    const bool committed = lap_mode && a.ws.lap.hdr[LAP_H_DONE] != 0;
+    // lap_mode: bit 0 the fast path ran in front of this launch; bit 1 (round 6) its sparse emulation is a kernel of its own on the emulation
+    // stream; bit 2 this launch is the PATCH STEP of the chain a.seq (launched behind the next frame's predict, or at a synchronisation point)
+    constexpr bool patch = PATCH;
+    if (patch) {
+        const LapWs& Lp = a.ws.lap;
+        if (Lp.hdr[LAP_H_PROV] != (int)a.seq || Lp.hdr[LAP_H_PROV] == 0) return;   // that frame owes nothing (certified, or committed by an emulation): the usual case
+        // the emulation's kernel was running when the frame was committed provisionally (lap_try_provisional checked): wait for its end
+        for (int spins = 0;; spins++) {
+            if (tid == 0) S.flag[6] = tagged_value(__hip_atomic_load(&Lp.hdr[LAP_H_EMU], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), a.seq, 2);
+            __syncthreads();
+            const int st = S.flag[6];
+            __syncthreads();
+            if (st == 2) break;
+            if (spins > 50000000) { if (tid == 0) { life.S.err[5] = (int)a.seq; *life.S.loc_count = life.prov.rec->n_new; Lp.hdr[LAP_H_PROV] = 0; } return; }   // ("cannot happen")
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (Lp.hdr[LAP_H_PMODE] == 1) { prov_apply(a, life, Lp.spAssign, nR, reinterpret_cast<bbox_t*>(a.cost_only), false); return; }
+        // the sparse emulation refused (an entry outside its candidate lists could have mattered): the dense emulation below decides the bit
+    } else if ((lap_mode & 2) != 0 && (!HELP || blockIdx.x == 0)) {
+        // Stream emulation, frame neither certified nor committed provisionally (verdict 2): the emulation's kernel decides -- and commits -- the
+        // frame; wait for its end, or, if it has not even started, take the frame away from it (it then returns at once: exactly one writer)
+        const LapWs& Lp = a.ws.lap;
+        for (int spins = 0;; spins++) {
+            if (tid == 0) {
+                int go = 1;
+                if (tagged_value(__hip_atomic_load(&Lp.hdr[LAP_H_VERDICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.seq, 0) == 2) {
+                    const int old = __hip_atomic_load(&Lp.hdr[LAP_H_EMU], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    const int st = tagged_value(old, a.seq, 2);
+                    if (st == 0) go = atomicCAS(&Lp.hdr[LAP_H_EMU], old, tagged_word(a.seq, 3)) == old ? 1 : 0;
+                    else if (st == 1) go = spins > 50000000 ? 1 : 0;
+                }
+                S.flag[6] = go;
+            }
+            __syncthreads();
+            const int go = S.flag[6];
+            __syncthreads();
+            if (go) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    const bool committed = (lap_mode & 1) && a.ws.lap.hdr[LAP_H_DONE] != 0;
     if (HELP && blockIdx.x > 0) { if (blockIdx.x % MK_XCDS == 0 && nR > 0 && nC > 0 && !committed) mk_helper_loop(a, S, nR, nC, (want_cost >> 3) & 1); return; }
     if (committed) {
         const int mode = a.ws.lap.hdr[LAP_H_MODE];
@@ -487,7 +579,8 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
     // mk_postcheck_kernel found no entry outside the candidate lists that could have mattered -- in both cases the assignment
     // is the reference's and the dense emulation below is skipped
     bool certified = false; const short* given = nullptr;
-    if (lap_mode) {
+    if (patch) mk_prepare_dense(a, nR, nC, rowsTrk, a.ws.lap.ccost);
+    if (lap_mode & 1) {
         const LapWs& L = a.ws.lap;
         const int mode = L.hdr[LAP_H_MODE], spviol = L.hdr[LAP_H_SPVIOL];
         if (mode == 0) { certified = true; given = L.colOfRow; }
@@ -989,6 +1082,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         __syncthreads();
         if (tid == 0) { double cst = 0.0; for (int r = 0; r < nR; r++) if (S.starColOfRow[r] >= 0) cst += vals[r]; *a.ws.cost = cst; }
     }
+    if (patch) { __syncthreads(); prov_apply(a, life, a.ws.assignment, nR, reinterpret_cast<bbox_t*>(a.cost_only), true); return; }
     // device-resident loop: the lifecycle step (td.cpp:472-644) runs here instead of in a launch of its own
     if (life.enabled) {
         __syncthreads();                                               // the assignment vector is complete (same workgroup wrote it)
@@ -1040,15 +1134,23 @@ bool dense_arming_step(volatile int* h, int nD)
     return h[1] > 0 || h[6] > 0;
 }
 
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch);   // lap_kernels.hip
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch, const AssocEmu* emu);   // lap_kernels.hip
 hipError_t launch_lap_dense(const AssocArgs& a, int gR, int gC, hipStream_t s);                     // lap_dense.hip
 hipError_t launch_mk_sparse(const AssocArgs& a, int gR, int gC, hipStream_t s, const LifeArgs& life);   // mk_sparse.hip
 
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
-                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid, const LifeArgs* life_in)
+                        const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid, const LifeArgs* life_in, const AssocEmu* emu, unsigned* seq_out)
 {
     LifeArgs life{}; if (life_in) life = *life_in;
-    AssocArgs a;
+    AssocArgs a{};
+    // every launch chain gets a sequence number (>= 1; host counter beside the scheduling hints): the protocol words of its kernels carry it
+    {
+        static unsigned fallback = 0;
+        unsigned* ctr = ws.dense_hint ? reinterpret_cast<unsigned*>(ws.dense_hint) + 8 : &fallback;
+        *ctr = (*ctr + 1) & 0x3FFFFFFFu; if (*ctr == 0) *ctr = 1;
+        a.seq = *ctr;
+        if (seq_out) *seq_out = a.seq;
+    }
     a.trk = trk; a.det = det; a.nT_dev = nT_dev; a.nT = nT; a.nD = nD;
     a.user = user_dist; a.userR = nR; a.userC = nC;
     a.ws = ws;
@@ -1069,6 +1171,7 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     // scheduling hint left by the final kernel of earlier launches in pinned host memory, read without synchronisation (stale by a
     // frame or two: it only picks grids, never results): the stream keeps needing the dense emulation / the dense solver
     bool hinted_now = false, prep_in_kernel = false;                  // (evaluated behind the countdown update below)
+    bool stream_emu = false;
     // small problems: the Munkres workgroup computes cost, minima and bitmaps itself (mk_fused_cost)
     const bool fused = lines <= MK_FUSE_LINES && !lap;
     hipError_t e = hipSuccess;
@@ -1095,7 +1198,11 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
             // (speculative start, lap_kernels.hip); MOT_LAP_TWO_BLOCK=0 keeps the separate launch
             const int two_block_on = E.two_block, mk_batch_on = E.mk_batch;   // MOT_LAP_TWO_BLOCK / MOT_MK_BATCH, MOT_MK_LAZY, MOT_MK_TIMING
             const bool two_block = two_block_on && !a.user && !want_dense;
-            e = launch_lap_front(a, gR, gC, s, ev_mid, life, two_block, mk_batch_on); if (e != hipSuccess) return e;
+            // device loop with an emulation stream: the emulation leaves the solver's launch for a kernel of its own there (provisional commits)
+            stream_emu = two_block && emu && emu->stream && life.enabled;
+            a.stream_emu = stream_emu ? 1 : 0; a.det_copy = stream_emu ? emu->det_copy : nullptr;
+            if (!stream_emu) life.prov.enabled = 0;
+            e = launch_lap_front(a, gR, gC, s, ev_mid, life, two_block, mk_batch_on, stream_emu ? emu : nullptr); if (e != hipSuccess) return e;
             ev_mid = nullptr;
             if (want_dense) { e = launch_lap_dense(a, gR, gC, s); if (e != hipSuccess) return e; }
             if (!two_block) { e = launch_mk_sparse(a, gR, gC, s, life); if (e != hipSuccess) return e; }
@@ -1125,8 +1232,25 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
     const bool hinted = hinted_now;                                    // (a noisy stream: the countdown above is armed)
     const bool big = !prep_in_kernel && ws.ctl && (helpers == 1 ? lines > 256 : (helpers == 2 && lines > MK_HELP_MIN && (!lap || hinted)));
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
-    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (force_cov << 3), life, lap ? 1 : 0);
-    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0) | (prep_in_kernel ? 4 : 0), life, lap ? 1 : 0);
+    const int lap_mode = (lap ? 1 : 0) | (stream_emu ? 2 : 0);
+    if (!stream_emu) life.prov.enabled = 0;
+    if (big) hipLaunchKernelGGL(munkres_kernel<true>, dim3(1 + MK_XCDS * MK_HELPERS), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (force_cov << 3), life, lap_mode);
+    else hipLaunchKernelGGL(munkres_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, (want_cost & 1) | (fused ? 2 : 0) | (prep_in_kernel ? 4 : 0), life, lap_mode);
+    return hipGetLastError();
+}
+
+// the patch step of chain `seq` (see prov_apply): the final kernel's single-workgroup instantiation in patch mode -- it returns at once unless that
+// frame was committed provisionally, applies the sparse emulation's answer, and holds the dense emulation for the case that one refused
+hipError_t launch_prov_patch(const AssocWs& ws, const LifeArgs& life, const bbox_t* trk, const bbox_t* det, int nD, unsigned seq, bbox_t* pred_cur, hipStream_t s)
+{
+    AssocArgs a{};
+    a.trk = trk; a.det = det; a.nT_dev = &life.prov.rec->pad; a.nT = life.S.cap; a.nD = nD;    // ProvRec::pad: the live count the frame was associated with
+    a.ws = ws; a.linemin = ws.linemin; a.dims = ws.status + 4;
+    a.cost_only = reinterpret_cast<double*>(pred_cur);                  // (patch mode: the slot carries the predicted boxes of the launch in between)
+    a.seq = seq;
+    hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(munkres_kernel<false, true>), (int)sizeof(MkShared)); if (e != hipSuccess) return e;
+    mot_impl::lds_poison(s);
+    hipLaunchKernelGGL((munkres_kernel<false, true>), dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, 4, life, 4);
     return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@
 // Both take every twiddle from the line's own table (tw[j] = (cos, sin)(2 pi j / wb), the forward transform conjugates it), no new tables.
 // The rows pass (real input) has its two-step form further down (dftct_rows_a / dftct_rows_c).
 // Plain pointers and ints only: the same text compiles for the host, where tests/test_dft_ct.py checks it against numpy for every line
-// length from 8 to 64 (DFTCT_FN / DFTCT_HOST).  Round 5: compiled into the kernels only with -DMOT_FFT_MIXED=1 (`make fftmix`).
+// length from 8 to 64 (DFTCT_FN / DFTCT_HOST).  Round 6: the default build (MOT_FFT_MIXED, kcf_kernels.hip); the rows pass still only with -DMOT_FFT_MIXED_ROWS=1 (`make fftvar`).
 #pragma once
 #ifndef DFTCT_FN
 #define DFTCT_FN __device__ __forceinline__

@@ -231,4 +231,5 @@ struct LifeArgs {
     int enabled;
     DLState S; KcfPool kp; KalmanPool kal;
     const bbox_t* trk_pred; const bbox_t* dets; int nD;
+    LapProv prov;             // provisional commits of two-row tie frames (mot_dev.h)
 };

@@ -676,9 +676,10 @@ __device__ __forceinline__ void dft_cols_generic4(const KcfPool& p, const float2
     }
 }
 
-// (round 5, prepared for round 6: -DMOT_FFT_MIXED=1, `make fftmix`) the column pass as two short passes for line lengths with a factor 2..5
+// the column pass as two short passes for line lengths with a factor 2..5 (dft_ct.h).  Round 6: the DEFAULT build -- the whole GPU suite ran on it
+// (profiles/r06_fftmix_full_suite.log: 133 passed); -DMOT_FFT_MIXED=0 keeps the direct column pass for A/B builds
 #ifndef MOT_FFT_MIXED
-#define MOT_FFT_MIXED 0
+#define MOT_FFT_MIXED 1
 #endif
 #ifndef MOT_FFT_MIXED_ROWS               /* the rows pass (real input) in two steps as well: host-checked (tests/test_dft_ct.py), never run on a GPU */
 #define MOT_FFT_MIXED_ROWS 0

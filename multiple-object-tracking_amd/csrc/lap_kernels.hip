@@ -20,6 +20,7 @@
 // assignment costs at least eps more => the reference returns exactly this one.  Otherwise (a tie, or any doubt) the
 // order-exact emulation runs as before.  lap_model.c (CPU model, test infrastructure) is the CPU model of this file; tests/test_lap_model.py
 // fuzzes "certified => equal to the reference" on CPU, tests/test_gpu_parity.py on the device.
+#include <hip/hip_ext.h>
 #include "assoc_common.h"
 #include "lap_certify.h"
 #include "lap_grid.h"
@@ -42,6 +43,10 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
         // first kernel of the chain: the per-frame protocol words start from zero whatever the previous launch left (its final kernel
         // re-arms them, but not on its early-out for an empty side)
         a.ws.lap.hdr[LAP_H_VERDICT] = 0; a.ws.lap.hdr[LAP_H_DONE] = 0; a.ws.lap.hdr[LAP_H_CERT] = 0;
+    }
+    if (a.det_copy && !a.user) {                                       // stream emulation: its kernel reads a private copy of the detection list (24-byte boxes as 4-byte words)
+        const int g = blockIdx.x * 256 + threadIdx.x;
+        if (g < a.nD * 6) reinterpret_cast<int*>(a.det_copy)[g] = reinterpret_cast<const int*>(a.det)[g];
     }
     const int r = blockIdx.x * 4 + wave;
     const LapWs& L = a.ws.lap;
@@ -201,6 +206,103 @@ __device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-
 {
     const u64 b = (u64)__double_as_longlong(x);
     return __longlong_as_double((long long)readlane64(b, src));
+}
+
+// ---- provisional commit (round 6; mot_dev.h: ProvRec) ----------------------------------------------------------------------------
+// Called (workgroup-uniform) when lap_certify found a cycle among the near-tight edges.  ed[0, ne) is the edge list in LDS, alive[] what the
+// certificate's forward peel left (nodes with a path INTO a cycle).  Peeling from the other side as well (a node stays only if an alive node
+// has an edge into it) until nothing changes leaves the nodes that lie ON a cycle or between two cycles.  If that is exactly two rows A, B
+// with A -> B and B -> A, the cycle A <-> B is the only one: every assignment within eps of the optimum is M or M with the columns of A and
+// B exchanged (lap_certify.h: any other assignment differs from M along cycles of near-tight edges or costs at least eps - n tol more), so
+// the reference returns one of the two.  Both rows are matched in both, so the lifecycle step (td.cpp:472-644) sees the same counters,
+// deaths and spawns -- only the box / spectrum the two tracks adopt differs.  M is committed here; the two tracks are cloned into the pool's
+// shadow slots, which adopt the OTHER detection, and appended to the predict list: the next predict launch computes both alternatives and
+// prov_patch (assoc_kernels.hip) keeps the one the order-exact emulation names.  Refused (-> today's path, verdict 2) when the core is
+// anything else, when a free column is part of it, or when the emulation's kernel is not running yet (the patch step waits for it by
+// polling: that is only safe for a kernel that is already resident).
+__device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, LapShared& S, LapFused& F, int nR, int nC, bool rowsTrk, int ne)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const LapWs& L = a.ws.lap;
+    unsigned* ed = F.certify;
+    unsigned char* alive = reinterpret_cast<unsigned char*>(ed + LAP_EDGES);
+    unsigned char* mark = alive + MK_MAXN + 64;
+    if (tid < 64) {
+        for (int guard = 0; guard < 4 * MK_MAXN; guard++) {
+            bool ch = false;
+            // (every alive node is the source of some edge -- lap_certify starts from the sources -- so walking the edge list reaches all of them)
+            for (int e = lane; e < ne; e += 64) mark[ed[e] >> 16] = 0;
+            for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; if (alive[x >> 16] && alive[x & 0xFFFF]) mark[x & 0xFFFF] = 1; }   // has an edge coming in
+            for (int e = lane; e < ne; e += 64) { const unsigned s = ed[e] >> 16; if (alive[s] && !mark[s]) { alive[s] = 0; ch = true; } }
+            for (int e = lane; e < ne; e += 64) mark[ed[e] >> 16] = 0;
+            for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e]; if (alive[x >> 16] && alive[x & 0xFFFF]) mark[x >> 16] = 1; }      // has an edge going out
+            for (int e = lane; e < ne; e += 64) { const unsigned s = ed[e] >> 16; if (alive[s] && !mark[s]) { alive[s] = 0; ch = true; } }
+            if (!__ballot(ch)) break;
+        }
+        unsigned lo = 0xFFFFFFFFu, hi = 0;
+        for (int e = lane; e < ne; e += 64) { const unsigned s = ed[e] >> 16; if (alive[s]) { lo = s < lo ? s : lo; hi = s > hi ? s : hi; } }
+        lo = wave_min_u32_dpp(lo); hi = ~wave_min_u32_dpp(~hi);
+        bool other = false, e1 = false, e2 = false;
+        for (int e = lane; e < ne; e += 64) {
+            const unsigned x = ed[e], s = x >> 16, d = x & 0xFFFF;
+            if (alive[s] && s != lo && s != hi) other = true;
+            if (s == lo && d == hi) e1 = true;
+            if (s == hi && d == lo) e2 = true;
+        }
+        const bool ok = lo != 0xFFFFFFFFu && lo < hi && hi < (unsigned)nR && !__ballot(other) && __ballot(e1) && __ballot(e2);
+        // the emulation's kernel must be resident already: the patch step polls for its end
+        const int emu = tagged_value(__hip_atomic_load(&L.hdr[LAP_H_EMU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.seq, 0);
+        if (lane == 0) { S.flag[2] = (ok && emu == 1) ? 1 : 0; S.flag[3] = (int)lo; S.flag[4] = (int)hi; }
+    }
+    __syncthreads();
+    if (!S.flag[2]) return false;
+    const DLState& D = life.S;
+    const int rA = S.flag[3], rB = S.flag[4], cA = S.colOfRow[rA], cB = S.colOfRow[rB];
+    const int T[2] = { rowsTrk ? rA : cA, rowsTrk ? rB : cB };         // the two tracks ...
+    const int Dm[2] = { rowsTrk ? cA : rA, rowsTrk ? cB : rB };        // ... and the detections they adopt in M; the alternative: each adopts the other's
+    const int slotT[2] = { D.slot[T[0]], D.slot[T[1]] };               // (live order of THIS frame: read before the lifecycle step compacts the list)
+    const int nT_now = *D.nlive;
+    __syncthreads();
+    if (tid < nR) a.ws.assignment[tid] = S.colOfRow[tid];
+    __threadfence_block();
+    __syncthreads();
+    dl_lifecycle_body(D, life.kp, life.kal, life.trk_pred, life.dets, life.nD, a.ws.assignment, F.life);
+    __threadfence_block();
+    __syncthreads();
+    const int n_new = *D.nlive;
+    int* posn = S.wave_tot;                                            // [0], [1]: where the two tracks sit in the new live list (-1: the track died -- nothing to patch for it)
+    if (tid < 2) posn[tid] = -1;
+    __syncthreads();
+    if (tid < n_new) { const int sl = D.slot[tid]; if (sl == slotT[0]) posn[0] = tid; if (sl == slotT[1]) posn[1] = tid; }
+    __syncthreads();
+    const KcfPool& kp = life.kp;
+    const int tot = MOT_NCHAN * kp.nbins;
+    int nvalid = 0;
+    ProvRec* rec = life.prov.rec;
+    for (int k = 0; k < 2; k++) {
+        if (posn[k] < 0) { if (tid == 0) { rec->t[k].newpos = -1; rec->t[k].slot = slotT[k]; rec->t[k].sh = -1; rec->t[k].det_alt = Dm[k ^ 1]; } continue; }
+        const int sh = life.prov.sh_base + nvalid, sl = slotT[k], dalt = Dm[k ^ 1];
+        // the clone: the model as it is BEFORE the pending blend (the lifecycle step only noted which spectrum the slot adopts)
+        const float2* xs = kp.xm + (size_t)sl * tot; float2* xd = kp.xm + (size_t)sh * tot;
+        for (int i = tid; i < tot; i += MK_THREADS) xd[i] = xs[i];
+        for (int i = tid; i < kp.nbins; i += MK_THREADS) kp.alpha[(size_t)sh * kp.nbins + i] = kp.alpha[(size_t)sl * kp.nbins + i];
+        if (tid == 0) {
+            const bbox_t bb = life.dets[dalt];
+            kp.pos[sh] = bb;                                           // tracker_update's bookkeeping for the other detection (kcf.cpp:470-472), as the lifecycle step does it
+            kp.scale[sh] = make_float2(((float)(bb.r - bb.l + 1)) / ((float)kp.cols), ((float)(bb.b - bb.t + 1)) / ((float)kp.rows));
+            kp.first_update[sh] = kp.first_update[sl];
+            D.pend_det[sh] = dalt;
+            D.loc_slots[n_new + nvalid] = sh;
+            rec->t[k].newpos = posn[k]; rec->t[k].slot = sl; rec->t[k].sh = sh; rec->t[k].det_alt = dalt; rec->t[k].box_alt = bb;
+        }
+        nvalid++;
+    }
+    if (tid == 0) {
+        rec->seq = (int)a.seq; rec->rowA = rA; rec->rowB = rB; rec->colA = cA; rec->colB = cB; rec->nvalid = nvalid; rec->n_new = n_new; rec->pad = nT_now;
+        *D.loc_count = n_new + nvalid;
+        L.hdr[LAP_H_PMODE] = 0; L.hdr[LAP_H_PROV] = (int)a.seq; L.hdr[LAP_H_PSTAT] += 1;
+    }
+    return true;
 }
 
 // fused != 0 (box costs, not a caller matrix): the dual check, the uniqueness certificate and -- device loop, certified frame --
@@ -508,7 +610,14 @@ __device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life
         if (reason == 0) L.hdr[LAP_H_MODE] = 0;
         L.hdr[55] = (int)(wall_clock64() - t_tail);                      // (debug: dual check + certificate ticks)
     }
-    if (reason != 0) return 2;
+    if (reason != 0) {
+        // a tie -- but if all that ties is ONE pair of rows that could swap their columns, the frame is committed now and the emulation only owes the swap bit
+        if (reason == 4 && life.enabled && life.prov.enabled && a.stream_emu && ne <= 16 * 64 && lap_try_provisional(a, life, S, F, nR, nC, rowsTrk, ne)) {
+            if (tid == 0) { L.hdr[LAP_H_DONE] = 1; L.hdr[56] = (int)(wall_clock64() - t_tail); }
+            return 3;
+        }
+        return 2;
+    }
     if (!life.enabled) return 1;
     // certified and in the device loop: commit the frame here (td.cpp:472-644); the rest of the chain returns at once
     if (tid < nR) a.ws.assignment[tid] = S.colOfRow[tid];
@@ -522,7 +631,40 @@ __device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life
 __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int fused, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
-    (void)lap_solve_run(a, fused, life, lap_raw);
+    const int verdict = lap_solve_run(a, fused, life, lap_raw);
+    if (!a.stream_emu) return;
+    // stream emulation (round 6): the sparse emulation runs beside this kernel as a kernel of its own and learns the verdict from the same word
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&a.ws.lap.hdr[LAP_H_VERDICT], tagged_word(a.seq, verdict), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The sparse order-exact emulation as a kernel of its own on the context's EMULATION stream (device loop with provisional commits): started
+// behind the row scan, beside the solver's kernel, it may run on while the main stream goes ahead with the next frame's predict.  LAP_H_EMU
+// says where it is: the final kernel of an uncommitted frame and the patch step of a provisionally committed one wait for "finished".
+template <bool TIMING>
+__global__ void __launch_bounds__(MK_THREADS) mk_sparse_stream_kernel(AssocArgs a, LifeArgs life, int mk_batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
+    __shared__ int go;
+    int* ew = &a.ws.lap.hdr[LAP_H_EMU];
+    if (threadIdx.x == 0) {
+        int old = __hip_atomic_load(ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            if (tagged_value(old, a.seq, 3) == 3) { go = 0; break; }   // the final kernel took the frame before this kernel started (or a later chain is running): nothing to do
+            const int seen = atomicCAS(ew, old, tagged_word(a.seq, 1));
+            if (seen == old) { go = 1; break; }
+            old = seen;
+        }
+    }
+    __syncthreads();
+    if (!go) return;
+    AssocArgs b = a; LifeArgs lf = life;
+    if (a.det_copy) { b.det = a.det_copy; lf.dets = a.det_copy; }
+    mk_sparse_run<true, TIMING>(b, mk_batch, 1, lf, lap_raw);
+    __threadfence();                                                   // whatever the run published (results, or a whole committed frame) before "finished"
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ew, tagged_word(a.seq, 2), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Two workgroups, one launch (box costs, device loop or host API): workgroup 0 is the solver with its fused tail, workgroup 1 the sparse
@@ -540,7 +682,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve2_kernel(AssocArgs a, Lif
     const int verdict = lap_solve_run(a, 1, life, lap_raw);
     __threadfence();                                                   // everything this workgroup wrote (duals, header, lifecycle) before the verdict
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&a.ws.lap.hdr[LAP_H_VERDICT], verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(&a.ws.lap.hdr[LAP_H_VERDICT], tagged_word(a.seq, verdict), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- stage 3 ----------------------------------------------------------------------------------------------------
@@ -614,7 +756,7 @@ __global__ void __launch_bounds__(256) lap_verify_kernel(AssocArgs a, int again)
 } // namespace
 
 // two_block: the caller will NOT launch mk_sparse_kernel behind this (no dense solver in between): the emulation rides in the solver's launch
-hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch)
+hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, hipEvent_t ev_mid, const LifeArgs& life, bool two_block, int mk_batch, const AssocEmu* emu)
 {
     hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(lap_solve_kernel), (int)sizeof(LapShared)); if (e != hipSuccess) return e;
     const int lds2i = (int)(sizeof(LapShared) > sizeof(SpShared) ? sizeof(LapShared) : sizeof(SpShared));
@@ -623,6 +765,22 @@ hipError_t launch_lap_front(const AssocArgs& a, int gR, int gC, hipStream_t s, h
     // device loop: the detection features of the split update start on the side stream as soon as the predict is done, beside the
     // row scan (behind it: 2.86 instead of 2.94 M updates/s at 1024 tracks, round 2)
     if (ev_mid) { e = hipEventRecord(ev_mid, s); if (e != hipSuccess) return e; }
+    if (a.stream_emu && emu) {
+        // Stream emulation (round 6): row scan (its completion event rides in its own packet) -> [emulation stream: the sparse emulation, behind
+        // that event] beside [this stream: the solver's workgroup].  The emulation's kernel may outlive this chain: whoever needs its result
+        // waits for LAP_H_EMU (the final kernel of an uncommitted frame, the patch step of a provisionally committed one).
+        e = mot_impl::func_lds_once(reinterpret_cast<const void*>(mk_sparse_stream_kernel<false>), (int)sizeof(SpShared)); if (e != hipSuccess) return e;
+        e = mot_impl::func_lds_once(reinterpret_cast<const void*>(mk_sparse_stream_kernel<true>), (int)sizeof(SpShared)); if (e != hipSuccess) return e;
+        hipExtLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, nullptr, emu->ev_rowscan, 0, a);
+        e = hipGetLastError(); if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(emu->stream, emu->ev_rowscan, 0); if (e != hipSuccess) return e;
+        mot_impl::lds_poison(emu->stream);
+        if (mk_batch & SP_TIMING) hipLaunchKernelGGL(mk_sparse_stream_kernel<true>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), emu->stream, a, life, mk_batch);
+        else hipLaunchKernelGGL(mk_sparse_stream_kernel<false>, dim3(1), dim3(MK_THREADS), sizeof(SpShared), emu->stream, a, life, mk_batch);
+        mot_impl::lds_poison(s);
+        hipLaunchKernelGGL(lap_solve_kernel, dim3(1), dim3(MK_THREADS), sizeof(LapShared), s, a, 1, life);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(lap_rowscan_kernel, dim3((gR * 64 + 3) / 4), dim3(256), 0, s, a);
     mot_impl::lds_poison(s);                                           // (debug) MOT_LDS_POISON
     // box costs: solver + dual check + certificate (+ lifecycle) in one workgroup; caller matrices keep the dense dual check

@@ -67,24 +67,29 @@ __device__ __forceinline__ void lds_clear_bit64(u64* words, int i) { atomicAnd(r
 // SPEC: speculative run beside the solver (second workgroup of its launch).  Nothing is known about the solver's outcome at the start;
 // the run polls L.hdr[LAP_H_VERDICT] (0 pending, 1 certified: the solver's workgroup decides and commits the frame, 2 not certified: this
 // run's result is wanted) once per step-5 cycle, gives up as soon as it reads 1, and publishes nothing before it has read 2.
-__device__ __forceinline__ int sp_verdict(const LapWs& L) { return __hip_atomic_load(&L.hdr[LAP_H_VERDICT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// Round 6: the verdict word is TAGGED with the launch chain's sequence number (assoc_common.h: tagged_word), because the speculative run may now be a
+// kernel of its own on the emulation stream that outlives its chain's final kernel: a word some other frame left is "nothing yet" if older, "not
+// wanted" if newer.  Values: 1 certified (this run is discarded), 2 not certified (this run decides AND commits the frame), 3 not certified, but the
+// solver's workgroup has committed its matching provisionally (mot_dev.h: ProvRec): this run only reports -- LAP_H_PMODE, lap.spAssign -- and the
+// patch step reads off which of the two optima the reference returns.
+__device__ __forceinline__ int sp_verdict(const LapWs& L, unsigned seq) { return tagged_value(__hip_atomic_load(&L.hdr[LAP_H_VERDICT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), seq, 1); }
 // the in-loop look: only the word's value matters there (nothing the partner wrote is read on its strength -- the run ends by
 // sp_wait_verdict's acquire load before it publishes anything), so no cache invalidate and no wait at the load
-__device__ __forceinline__ int sp_verdict_peek(const LapWs& L) { return __hip_atomic_load(&L.hdr[LAP_H_VERDICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int sp_verdict_peek(const LapWs& L, unsigned seq) { return tagged_value(__hip_atomic_load(&L.hdr[LAP_H_VERDICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), seq, 1); }
 
-// workgroup-uniform: waits until the solver's workgroup has published its verdict; false = certified there (this run is discarded)
-__device__ inline bool sp_wait_verdict(const LapWs& L, int* flag)
+// workgroup-uniform: waits until the solver's workgroup has published its verdict and returns it (1: certified there, this run is discarded)
+__device__ inline int sp_wait_verdict(const LapWs& L, int* flag, unsigned seq)
 {
     for (int spins = 0;; spins++) {
-        if (threadIdx.x == 0) *flag = sp_verdict(L);
+        if (threadIdx.x == 0) *flag = sp_verdict(L, seq);
         __syncthreads();
         const int v = *flag;
         __syncthreads();
-        if (v) return v == 2;
+        if (v) return v;
         // the partner never published a verdict ("cannot happen"): this run is NOT committed -- two writers must never be possible.  The
         // verdict word for the final kernel keeps its armed value (2: the dense order-exact emulation decides the frame, or the solver's
         // workgroup if it does certify after all); status word 3 records the time-out (mot_get_lap_stats()[8])
-        if (spins > 4000000) { if (threadIdx.x == 0) L.hdr[LAP_H_LAST + 8] = 3; return false; }
+        if (spins > 4000000) { if (threadIdx.x == 0) L.hdr[LAP_H_LAST + 8] = 3; return 1; }
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -110,11 +115,13 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         t_cert = wall_clock64();
         if (reason == 0) { if (tid == 0) L.hdr[LAP_H_MODE] = 0; return; }
     }
-    if (bad) {                                                         // negative / non-finite costs: dense emulation
-        if (SPEC && !sp_wait_verdict(L, &S.flag[6])) return;
-        if (tid == 0) L.hdr[LAP_H_MODE] = 2;
-        return;
-    }
+    // "this run cannot decide the frame": published -- like everything else -- only once the verdict says the run is wanted
+    auto refuse = [&](int st) {
+        const int v = SPEC ? sp_wait_verdict(L, &S.flag[6], a.seq) : 2;
+        if (v == 1) return;
+        if (tid == 0) { if (v == 3) L.hdr[LAP_H_PMODE] = 2; else { L.hdr[LAP_H_MODE] = 2; if (st) L.hdr[LAP_H_LAST + 8] = st; } }
+    };
+    if (bad) { refuse(0); return; }                                    // negative / non-finite costs: dense emulation
     // ---- set-up: candidate entries (values in registers: only the row's own thread ever touches them), d = c - row minimum
     // (hungarian.cpp:83-89), zero masks, transposed lists ----
     const int r = tid;
@@ -150,11 +157,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         const int mycnt = tid < nC ? S.cnt[tid] : 0;
         if (mycnt > SP_TLS) S.flag[0] = 1;
         __syncthreads();
-        if (S.flag[0]) {
-            if (SPEC && !sp_wait_verdict(L, &S.flag[6])) return;
-            if (tid == 0) { L.hdr[LAP_H_MODE] = 2; L.hdr[LAP_H_LAST + 8] = 2; }
-            return;
-        }
+        if (S.flag[0]) { refuse(2); return; }
         S.cnt[tid] = 0;
         {   // every slot starts as "no entry" (0xFFFF sorts behind every row): 64 KB, 8-byte stores (the array is 8-byte aligned)
             uint2* t8 = reinterpret_cast<uint2*>(S.tl);
@@ -316,7 +319,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         // ========== steps 3 / 4 / 2a / 2b (:240-334, :192-237): wavefront 0 ==========
         if (wave == 0) {
             // (speculative run) this cycle's look at the verdict word: the load is issued here and consumed at the end of the event phase
-            const int vnow = (SPEC && vseen != 2) ? sp_verdict_peek(L) : vseen;   // once the result is wanted the word is final: no more looks   (a second look every 8 events inside long phases was measured: -1.5 % overall)
+            const int vnow = (SPEC && vseen < 2) ? sp_verdict_peek(L, a.seq) : vseen;   // once the result is wanted the word is final: no more looks   (a second look every 8 events inside long phases was measured: -1.5 % overall)
             int action = 0; bool found = false;
             unsigned fm = ~0u;                                         // columns >= `from` (the sweep position, :249)
             if (hz_dirty) {                                            // after a step 5: the columns whose zero masks changed (usually a handful)
@@ -642,11 +645,14 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         if (timing) t_s5 += wall_clock64() - t_b;
     }
     __syncthreads();
-    if (SPEC && !sp_wait_verdict(L, &S.flag[6])) return;               // certified there: nothing of this run is published
+    const int vfin = SPEC ? sp_wait_verdict(L, &S.flag[6], a.seq) : 2;
+    if (vfin == 1) return;                                             // certified there: nothing of this run is published
+    const bool report_only = vfin == 3;                                // the frame is committed provisionally: this run owes the swap bit, nothing else
     if (tid < nR) L.spAssign[tid] = S.starColOfRow[tid];
     L.spS[tid] = S.Scol[tid];
     if (tid == 0) {
-        L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
+        if (!report_only) L.hdr[LAP_H_MODE] = status == 0 ? 1 : 2;
+        else if (status != 0) L.hdr[LAP_H_PMODE] = 2;
         L.hdr[LAP_H_LAST + 8] = status; L.hdr[LAP_H_LAST + 9] = n_aug; L.hdr[LAP_H_LAST + 10] = n_s5; L.hdr[LAP_H_LAST + 11] = n_prime;   // (wave-0 / thread-0 counts)
         L.hdr[LAP_H_LAST + 12] = (int)t_s3; L.hdr[LAP_H_LAST + 13] = (int)t_s5; L.hdr[LAP_H_LAST + 14] = (int)(wall_clock64() - t_begin);
         L.hdr[48] = (int)t_setup; L.hdr[53] = (int)(t_cert - t_begin); L.hdr[54] = (int)(t_lists - t_cert);
@@ -692,6 +698,7 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
         }
     }
     const int spviol = __syncthreads_or(pviol) ? 1 : 0;
+    if (report_only) { if (tid == 0) { L.hdr[LAP_H_PMODE] = spviol ? 2 : 1; L.hdr[57] = (int)(wall_clock64() - t_post); } return; }
     if (tid == 0) { L.hdr[LAP_H_SPVIOL] = spviol; L.hdr[57] = (int)(wall_clock64() - t_post); }
     if (spviol || !life.enabled) return;
     // accepted and in the device loop: commit the frame here (td.cpp:472-644); the final kernel only does its bookkeeping

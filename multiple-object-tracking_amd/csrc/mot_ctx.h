@@ -118,5 +118,8 @@ namespace mot_impl {
 int ensure_device(mot_ctx* c);
 int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch = false);   // shared_scratch: no HBM slab of its own (the caller points gscratch at a shared one)
 int devloop_check(mot_ctx* c);   // mot_devloop.hip
+int devloop_flush(mot_ctx* c);   // mot_devloop.hip: the patch step a provisionally committed frame still owes (round 6), enqueued on the context's stream
+// the synchronisation of every read-back of device-loop state: never shows the caller a provisional frame
+#define MOT_SYNC_CTX(c) do { int rc_ = mot_impl::devloop_flush(c); if (rc_) return rc_; HIPCHK(hipStreamSynchronize((c)->stream)); } while (0)
 int overlay_run(mot_ctx* c, void* frame_dev, const bbox_t* boxes_dev, const unsigned* tids_dev, const int* n_dev, int n_max);   // overlay_kernels.hip
 }

@@ -106,10 +106,12 @@ int get_pool(mot_ctx* c, int rows, int cols, int* out_idx, bool shared_scratch)
     const int cap = c->cfg.max_tracks;
     ph->cap = cap;
     for (int s = cap - 1; s >= 0; s--) ph->free_slots.push_back(s);
-    HIPCHK(ph->xm.alloc((size_t)cap * MOT_NCHAN * p.nbins));
-    HIPCHK(ph->alpha.alloc((size_t)cap * p.nbins));
-    HIPCHK(ph->pos.alloc(cap)); HIPCHK(ph->scale.alloc(cap)); HIPCHK(ph->first.alloc(cap));
-    HIPCHK(ph->response.alloc((size_t)cap * p.nb));
+    // + MOT_SHADOW_SLOTS slots behind the pool's capacity: the clones a device loop predicts for a provisionally committed tie frame (mot_dev.h: ProvRec)
+    const size_t capx = (size_t)cap + MOT_SHADOW_SLOTS;
+    HIPCHK(ph->xm.alloc(capx * MOT_NCHAN * p.nbins));
+    HIPCHK(ph->alpha.alloc(capx * p.nbins));
+    HIPCHK(ph->pos.alloc(capx)); HIPCHK(ph->scale.alloc(capx)); HIPCHK(ph->first.alloc(capx));
+    HIPCHK(ph->response.alloc(capx * p.nb));
     HIPCHK(hipMemsetAsync(ph->xm.p, 0, sizeof(float2) * ph->xm.n, c->stream));
     HIPCHK(hipMemsetAsync(ph->alpha.p, 0, sizeof(float) * ph->alpha.n, c->stream));
     HIPCHK(hipMemsetAsync(ph->response.p, 0, sizeof(float) * ph->response.n, c->stream));
@@ -507,7 +509,7 @@ int mot_ctx_destroy(mot_ctx* c)
 }
 
 void* mot_ctx_stream(mot_ctx* c) { return c ? (void*)c->stream : nullptr; }
-int mot_ctx_sync(mot_ctx* c) { if (!c) return fail(MOT_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return devloop_check(c); }
+int mot_ctx_sync(mot_ctx* c) { if (!c) return fail(MOT_ERR_ARG, "null ctx"); MOT_SYNC_CTX(c); return devloop_check(c); }
 
 int mot_frame_upload(mot_ctx* c, const uint8_t* host_bgr)
 {
@@ -842,9 +844,9 @@ int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long*
 {   // workgroup-0 phase stamps (100 MHz ticks) of the most recent device-loop predict / update launches
     if (!c) return fail(MOT_ERR_ARG, "null ctx");
     // [0..15] predict, [16..31] update phase stamps of workgroup 0; [32 + 3i ..] start, end, hardware id of predict workgroup i (MOT_DBG_WG=1)
-    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32 + 3 * 4096)); HIPCHK(hipMemsetAsync(c->dbg.p, 0, (32 + 3 * 4096) * sizeof(long long), c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+    if (!c->dbg.p) { HIPCHK(c->dbg.alloc(32 + 3 * 4096)); HIPCHK(hipMemsetAsync(c->dbg.p, 0, (32 + 3 * 4096) * sizeof(long long), c->stream)); MOT_SYNC_CTX(c); }
     c->dbg_on = enable != 0;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     if (predict8) HIPCHK(hipMemcpy(predict8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     if (predict8 && getenv("MOT_DBG_CHANNELS")) { long long t[16]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "channels phase: half0 %lld half1 %lld ticks (of %lld, %lld)\n", t[8] - t[4], t[9] - t[5], t[5] - t[4], t[6] - t[5]); }
     if (predict8 && getenv("MOT_DBG_EXTRA")) { long long t[24]; HIPCHK(hipMemcpy(t, c->dbg.p, sizeof t, hipMemcpyDeviceToHost)); fprintf(stderr, "extra stamps (us after stamp 0):"); for (int i = 8; i < 20; i++) fprintf(stderr, " [%d] %.1f", i, (double)(t[i] - t[0]) * 0.01); fprintf(stderr, "\n"); }
@@ -859,7 +861,7 @@ int mot_debug_kcf_phases(mot_ctx* c, int enable, long long* predict8, long long*
 int mot_get_assoc_stats(mot_ctx* c, int* out16)
 {
     if (!c || !out16) return fail(MOT_ERR_ARG, "null argument");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     HIPCHK(hipMemcpy(out16, c->assoc.status, sizeof(int) * 16, hipMemcpyDeviceToHost));
     return MOT_OK;
 }
@@ -867,7 +869,7 @@ int mot_get_assoc_stats(mot_ctx* c, int* out16)
 int mot_get_lap_stats(mot_ctx* c, int* out32)
 {
     if (!c || !out32) return fail(MOT_ERR_ARG, "null argument");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     HIPCHK(hipMemcpy(out32, c->assoc.lap.hdr + LAP_H_LAST, sizeof(int) * 32, hipMemcpyDeviceToHost));
     if (getenv("MOT_LAP_DEBUG")) { int dbg[16]; HIPCHK(hipMemcpy(dbg, c->assoc.lap.hdr + 48, sizeof dbg, hipMemcpyDeviceToHost)); fprintf(stderr, "sparse event loop: %d batch iterations, %d one-event iterations; wave-0 ticks (MOT_MK_TIMING=1): phase start %d, one-event %d, batch %d, augment %d\n", dbg[10], dbg[11], dbg[12], dbg[13], dbg[14], dbg[15]); fprintf(stderr, "lap debug ticks: sparse setup %d (certificate %d, lists %d) post-check + lifecycle %d | solve init %d search %d commit %d final %d tail: check %d, to done %d\n", dbg[0], dbg[5], dbg[6], dbg[9], dbg[1], dbg[2], dbg[3], dbg[4], dbg[7], dbg[8]); }
     return MOT_OK;
@@ -877,7 +879,7 @@ int mot_get_lap_stats(mot_ctx* c, int* out32)
 int mot_debug_assoc_trace(mot_ctx* c, long long* out, int n)
 {
     if (!c || !out || n <= 0) return fail(MOT_ERR_ARG, "bad argument");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     const size_t have = c->a_dist.n;                                   // never read beyond the working matrix (round-4 advisor finding); the rest of `out` is zeroed
     const size_t take = std::min((size_t)n, have);
     if (take < (size_t)n) memset(out + take, 0, sizeof(long long) * ((size_t)n - take));

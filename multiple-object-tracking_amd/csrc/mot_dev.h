@@ -141,11 +141,37 @@ enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 
                               // every later kernel of the chain returns at once; re-armed by the final kernel
        LAP_H_VERDICT = 9,     // two-workgroup solver launch: 0 pending, 1 certified (the solver's workgroup decides and commits), 2 not certified (the
                               // speculative sparse emulation of the second workgroup is wanted); agent-scope release / acquire; re-armed by the final kernel
+       LAP_H_EMU = 10,        // stream-emulation protocol (round 6): (chain sequence number << 2) | state of the sparse emulation's kernel on the emulation
+                              // stream: 1 started, 2 finished (whatever it publishes is visible), 3 claimed by the final kernel before it could start
+       LAP_H_PROV = 11,       // chain sequence number of a PROVISIONALLY committed tie frame whose swap bit is still owed (0: none), see ProvRec
+       LAP_H_PMODE = 12,      // ... the emulation's outcome for that frame: 1 accepted (lap.spAssign), 2 refused (the dense emulation decides the bit)
+       LAP_H_PSTAT = 37,      // [37] provisional commits, [38] swaps applied, [39] bits decided by the dense emulation (cumulative; mot_get_lap_stats()[21..23])
        LAP_H_CERT = 8,        // 1 + the certificate's outcome when the solver's own workgroup already evaluated it (fused dual check, lap_kernels.hip); 0: not yet
        LAP_H_DSTAT = 42,      // [42..44] dense solver of the most recent launch: settled columns, free rows after the greedy start, device time (10 ns);
                               // [45] launches in which it ran, [46] ... and were then certified (cumulative)
        LAP_H_LAST = 16,       // [16..31] statistics of the most recent launch: status, rounds, free rows, searches, commits, edges, cyclic nodes, device time (10 ns)
        LAP_H_CUM = 32 };      // [32..36] cumulative certificate outcomes (0 certified, 1..4 reasons), [40] sparse emulation accepted, [41] refused -> dense
+
+// ---- provisional commit of a tie frame (round 6, lap_kernels.hip: lap_try_provisional) --------------------------------------------
+// When the certificate fails ONLY because of one two-row cycle of near-tight edges -- rows A, B could swap their columns at (almost) equal
+// cost, every other row is forced -- the reference returns the solver's matching M or M with that one swap, and nothing else depends on
+// which: both rows are assigned either way, so counters, deaths, spawns, track ids and the order of the live list are the same.  The
+// solver's workgroup then commits M at once (lifecycle step included) and clones the two tracks into SHADOW slots that adopt the other
+// detection; the next frame's predict launch computes both alternatives while the order-exact emulation (on a stream of its own) is still
+// running, and the patch step (prov_patch, assoc_kernels.hip) copies the shadows over the tracks iff the emulation says "swapped".
+#define MOT_SHADOW_SLOTS 2    /* extra slots at the end of a device-loop KCF pool / predict list / box segment */
+struct ProvTrack { int newpos, slot, sh, det_alt; bbox_t box_alt; };   // live position after the lifecycle step (-1: the track died), pool slot, shadow slot, the detection the shadow adopts + its box
+struct ProvRec {
+    int seq;                  // chain sequence number of the frame (its own copy: LAP_H_PROV is the flag)
+    int rowA, rowB, colA, colB;   // the cycle in the orientation of the assignment problem: M[rowA] = colA, M[rowB] = colB
+    int nvalid, n_new, pad;   // shadow items appended to the predict list; live tracks after the lifecycle step
+    ProvTrack t[2];
+};
+struct LapProv {
+    int enabled;              // 0: no provisional commits (caller matrices, host API, sharded / Kalman / size-class loops, HBM-slab templates, MOT_PROV=0)
+    int sh_base;              // first shadow slot of the pool (= its capacity)
+    ProvRec* rec;
+};
 
 struct AssocWs {
     double* dist;             // [1024*1024] working matrix, column-major
@@ -177,7 +203,14 @@ hipError_t launch_kalman_predict(const KalmanPool& p, const int* slots, const in
 hipError_t launch_kalman_update(const KalmanPool& p, const int* slots, const int* count, int n, const bbox_t* boxes, hipStream_t s);
 hipError_t launch_kalman_init(const KalmanPool& p, const int* slots, int n, const bbox_t* boxes, hipStream_t s);
 
+// host side of the stream emulation (device loops that commit two-row tie frames provisionally): the emulation stream, the event the row scan's
+// launch carries, and where the row scan copies the frame's detection list for the emulation's kernel
+struct AssocEmu { hipStream_t stream; hipEvent_t ev_rowscan; bbox_t* det_copy; };
 hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev, int nT, const bbox_t* det, int nD,
                         const double* user_dist, int nR, int nC, int want_cost, hipStream_t s, hipEvent_t ev_mid = nullptr,
-                        const struct LifeArgs* life = nullptr);   // life: run the device loop's lifecycle step as the kernel's tail (dl_lifecycle.h)   // ev_mid: recorded between the cost kernels and the Munkres kernel
+                        const struct LifeArgs* life = nullptr, const AssocEmu* emu = nullptr, unsigned* seq_out = nullptr);
+// the patch step of a provisionally committed frame (chain `seq`): a no-op unless that frame is still owed its swap bit; trk / det: THAT frame's
+// predicted boxes and detection list (the emulation's copy); pred_cur: the boxes the predict launch in between wrote (its shadow items sit behind
+// the live tracks), or null when no predict has run since
+hipError_t launch_prov_patch(const AssocWs& ws, const struct LifeArgs& life, const bbox_t* trk, const bbox_t* det, int nD, unsigned seq, bbox_t* pred_cur, hipStream_t s);   // life: run the device loop's lifecycle step as the kernel's tail (dl_lifecycle.h)   // ev_mid: recorded between the cost kernels and the Munkres kernel
 hipError_t launch_cost_matrix(const bbox_t* trk, int nT, const bbox_t* det, int nD, double* dist_out, hipStream_t s);

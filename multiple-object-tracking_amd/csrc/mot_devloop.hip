@@ -14,6 +14,7 @@
 #include "mot_env.h"
 #include "dl_lifecycle.h"
 #include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,53 @@ __global__ void __launch_bounds__(1024) dl_scatter_kernel(DLState S, const bbox_
 
 namespace mot_impl {
 
+// Auxiliary streams are shared by all device loops of a process on one device (round 6).  Every HIP stream beyond the first few is another
+// hardware queue, and this stack slows down sharply once a process keeps more than about five of them busy-or-idle on a device (measured:
+// bench.py's host-fed window ran at 1.7 instead of 2.65 M updates/s when the second context brought the count to seven; tools/hostfed_probe.py) --
+// so contexts do not create their own side / emulation streams.  Sharing only ADDS ordering between contexts (their launches serialise on the
+// shared stream), never removes one: each context still orders its own work with its own events.
+struct AuxStreams { int dev; int reserve; hipStream_t side = nullptr; hipStream_t emu = nullptr; int refs = 0; };
+static std::mutex g_aux_mu;
+static std::vector<AuxStreams> g_aux;
+
+static hipError_t aux_acquire(int dev, int reserve, bool want_emu, hipStream_t* side, hipStream_t* emu)
+{
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    AuxStreams* a = nullptr;
+    for (AuxStreams& x : g_aux) if (x.dev == dev && x.reserve == reserve) a = &x;
+    if (!a) { g_aux.push_back(AuxStreams{dev, reserve}); a = &g_aux.back(); }
+    if (!a->side) {
+        // The feature launch gets a stream whose kernels may not use `reserve` (default 32) of the chip's CUs, so the one-workgroup kernels and the
+        // short dense passes of the association chain on the main stream never queue behind detection-feature workgroups (2.44 -> 2.58 M updates/s
+        // at 1024 tracks).  0 (or a refusal by the runtime): a low-priority stream over the whole chip, as in round 1.
+        bool masked = false;
+        if (reserve > 0 && reserve < 256) {
+            uint32_t mask[8];
+            for (int w = 0; w < 8; w++) mask[w] = 0xFFFFFFFFu;
+            for (int b = 0; b < reserve; b++) mask[b >> 5] &= ~(1u << (b & 31));
+            masked = hipExtStreamCreateWithCUMask(&a->side, 8, mask) == hipSuccess;
+            if (!masked) { (void)hipGetLastError(); a->side = nullptr; }
+        }
+        if (!masked) {
+            int lo = 0, hi = 0;
+            hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi); if (e != hipSuccess) return e;   // lo = numerically largest = lowest priority
+            e = hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, lo); if (e != hipSuccess) return e;
+        }
+    }
+    if (want_emu && !a->emu) { hipError_t e = hipStreamCreateWithFlags(&a->emu, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+    a->refs++;
+    *side = a->side; *emu = want_emu ? a->emu : nullptr;
+    return hipSuccess;
+}
+static void aux_release(int dev, int reserve)
+{
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    for (AuxStreams& x : g_aux) if (x.dev == dev && x.reserve == reserve && x.refs > 0 && --x.refs == 0) {
+        if (x.side) { (void)hipStreamSynchronize(x.side); (void)hipStreamDestroy(x.side); x.side = nullptr; }
+        if (x.emu) { (void)hipStreamSynchronize(x.emu); (void)hipStreamDestroy(x.emu); x.emu = nullptr; }
+    }
+}
+
 struct DevLoop {
     DLState S{};
     int pool = -1;
@@ -98,6 +146,15 @@ struct DevLoop {
     std::vector<hipEvent_t> pt; int pt_used = 0;
     DevBuf<int> trace;            // (debug, MOT_TRACE=1) 32 frames x cap x 8 ints: predict records [0, 16), update records [16, 32) (KcfLaunch::trace)
     bool prof_two_call = false;   // (debug) mot_debug_profile_stages: the two-call / sharded step records its stage events (ev[0..5])
+    // Provisional commits (round 6; mot_dev.h: ProvRec).  prov: this loop may commit two-row tie frames at once (single-template LDS-resident KCF,
+    // deferred blend, one rank; MOT_PROV=0 switches it off).  Then: the sparse emulation runs on `emu` behind the row scan's event ev_rs; the
+    // predicted boxes alternate between the two halves of `seg2` by frame parity and the row scan copies the detection list into a half of
+    // `det_copy` (the emulation of frame f may still read both while predict(f + 1) writes and the caller reuses its list); patch_owed: a frame
+    // has been associated since the last patch step -- the next predict launch is followed by one, every synchronisation point runs one first.
+    bool prov = false; hipStream_t emu = nullptr; hipEvent_t ev_rs = nullptr;
+    DevBuf<bbox_t> seg2, det_copy; DevBuf<ProvRec> prov_rec;
+    bool patch_owed = false; unsigned seq_last = 0; int nD_last = 0, par_last = 0;
+    int aux_dev = -1, aux_reserve = 0;   // key of the shared auxiliary streams this loop holds a reference to (aux_acquire)
 };
 
 void devloop_destroy(DevLoop* d)
@@ -106,11 +163,13 @@ void devloop_destroy(DevLoop* d)
     // a detection-feature launch (side stream) or an upload (copy stream) may still be running: nothing is freed under them
     if (d->side) (void)hipStreamSynchronize(d->side);
     if (d->copy) (void)hipStreamSynchronize(d->copy);
+    if (d->emu) (void)hipStreamSynchronize(d->emu);
+    if (d->ev_rs) (void)hipEventDestroy(d->ev_rs);
     if (d->ev_ok) for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->pt) (void)hipEventDestroy(e);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     for (hipEvent_t e : d->ev_spec) if (e) (void)hipEventDestroy(e);
-    if (d->side) (void)hipStreamDestroy(d->side);
+    if (d->aux_dev >= 0) aux_release(d->aux_dev, d->aux_reserve);    // the side / emulation streams are shared (AuxStreams): the last user destroys them
     if (d->host_ok) { d->ev_mid = d->ev_mid0; for (int b = 0; b < 3; b++) { (void)hipEventDestroy(d->ev_up[b]); (void)hipEventDestroy(d->ev_ring[b]); } (void)hipStreamDestroy(d->copy); }
     if (d->ev_mid) (void)hipEventDestroy(d->ev_mid);
     delete d;
@@ -153,14 +212,14 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     } else if (S.kind == MOT_TRACKER_KCF) { int rc = get_pool(c, S.rows, S.cols, &d->pool); if (rc) return rc; }
     const bool multi = S.ncls > 1;
     // one int arena: nlive, next_tid(as tids), nfree, loc_count, upd_count, err[4], then arrays
-    const size_t nints = 16 + (size_t)cap * 9 + 2 * (size_t)(cap + md) + 64 + (multi ? (size_t)cap * 2 + (cap + md) + S.ncls + (size_t)S.ncls * cap : 0);
+    const size_t nints = 16 + (size_t)cap * 9 + MOT_SHADOW_SLOTS + 2 * (size_t)(cap + md) + 64 + (multi ? (size_t)cap * 2 + (cap + md) + S.ncls + (size_t)S.ncls * cap : 0);
     HIPCHK(d->ints.alloc(nints)); HIPCHK(hipMemsetAsync(d->ints.p, 0, nints * sizeof(int), c->stream));
     HIPCHK(d->tids.alloc((size_t)cap + 4)); HIPCHK(hipMemsetAsync(d->tids.p, 0, (cap + 4) * sizeof(unsigned), c->stream));
     HIPCHK(d->boxes.alloc((size_t)cap * 2 + cap + md + 8)); HIPCHK(hipMemsetAsync(d->boxes.p, 0, d->boxes.n * sizeof(bbox_t), c->stream));
     int* ip = d->ints.p;
     S.nlive = ip; S.nfree = ip + 1; S.loc_count = ip + 2; S.upd_count = ip + 3; S.err = ip + 4; ip += 16;
     S.free_slots = ip; ip += cap; S.slot = ip; ip += cap; S.age = ip; ip += cap; S.vis = ip; ip += cap; S.inv = ip; ip += cap;
-    S.rankpos = ip; ip += cap; S.owner = ip; ip += cap; S.loc_slots = ip; ip += cap; S.upd_slots = ip; ip += cap + md; S.upd_det = ip; ip += cap + md;
+    S.rankpos = ip; ip += cap; S.owner = ip; ip += cap; S.loc_slots = ip; ip += cap + MOT_SHADOW_SLOTS; S.upd_slots = ip; ip += cap + md; S.upd_det = ip; ip += cap + md;
     if (multi) { S.cls = ip; ip += cap; S.loc_cls = ip; ip += cap; S.upd_cls = ip; ip += cap + md; S.nfree_c = ip; ip += S.ncls; S.free_c = ip; ip += (size_t)S.ncls * cap; }
     S.next_tid = d->tids.p; S.tid = d->tids.p + 4;
     S.bbox = d->boxes.p; S.pred = S.bbox + cap; S.upd_boxes = S.pred + cap;
@@ -185,25 +244,14 @@ int devloop_get(mot_ctx* c, DevLoop** out)
         // known after the assignment -- the fused update kernel is used)
         if (split_on && !multi) {
             const KcfPool& kp = c->pools[d->pool]->dev;
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // lo = numerically largest = lowest priority
-            // The feature launch gets a stream whose kernels may not use MOT_SIDE_RESERVE (default 32) of the chip's CUs, so the
-            // one-workgroup kernels and the short dense passes of the association chain on the main stream never queue behind
-            // detection-feature workgroups (2.44 -> 2.58 M updates/s at 1024 tracks).  0 (or a refusal by the runtime): a
-            // low-priority stream over the whole chip, as in round 1.
             const int rs = mot_impl::env().side_reserve;                    // MOT_SIDE_RESERVE (-1: by template size)
             // HBM-slab templates run one workgroup per CU for hundreds of microseconds: taking CUs away from them costs a
             // second round (256 tracks at 148 x 148: 322 k -> 240 k updates/s), so only LDS-resident templates reserve by default
             const int reserve = rs >= 0 ? rs : (kp.use_lds ? 32 : 0);
-            bool masked = false;
-            if (reserve > 0 && reserve < 256) {
-                uint32_t mask[8];
-                for (int w = 0; w < 8; w++) mask[w] = 0xFFFFFFFFu;
-                for (int b = 0; b < reserve; b++) mask[b >> 5] &= ~(1u << (b & 31));
-                masked = hipExtStreamCreateWithCUMask(&d->side, 8, mask) == hipSuccess;
-                if (!masked) { (void)hipGetLastError(); d->side = nullptr; }
-            }
-            if (!masked) HIPCHK(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, lo));
+            // provisional commits of two-row tie frames (see DevLoop::prov): one rank, LDS-resident template (HBM-slab launches index their slabs by item)
+            const bool want_prov = mot_impl::env().defer_blend != 0 && S.world == 1 && kp.use_lds && mot_impl::env().prov;
+            HIPCHK(aux_acquire(c->cfg.device, reserve, want_prov, &d->side, &d->emu));
+            d->aux_dev = c->cfg.device; d->aux_reserve = reserve;
             HIPCHK(hipEventCreateWithFlags(&d->ev_mid, MOT_EVENT_FLAGS));
             HIPCHK(hipEventCreateWithFlags(&d->ev_in, MOT_EVENT_FLAGS));
             // Deferred blend (default; MOT_DEFER_BLEND=0 restores the blend launch): the model update of frame f rides in frame f + 1's
@@ -213,10 +261,18 @@ int devloop_get(mot_ctx* c, DevLoop** out)
             HIPCHK(d->det_spec.alloc(d->spec_stride * 3));
             for (int b = 0; b < 3; b++) HIPCHK(hipEventCreateWithFlags(&d->ev_spec[b], MOT_EVENT_FLAGS));
             if (d->defer) {
-                HIPCHK(d->pend.alloc((size_t)cap)); HIPCHK(hipMemsetAsync(d->pend.p, 0xFF, sizeof(int) * cap, c->stream));   // on the context's stream: see mot_ctx_create
+                HIPCHK(d->pend.alloc((size_t)cap + MOT_SHADOW_SLOTS)); HIPCHK(hipMemsetAsync(d->pend.p, 0xFF, sizeof(int) * (cap + MOT_SHADOW_SLOTS), c->stream));   // on the context's stream: see mot_ctx_create
                 S.defer = 1; S.pend_det = d->pend.p;
             }
             d->split = true;
+            // provisional commits of two-row tie frames (see DevLoop::prov): one rank, LDS-resident template (HBM-slab launches index their slabs by item)
+            if (d->defer && d->emu) {
+                HIPCHK(hipEventCreateWithFlags(&d->ev_rs, MOT_EVENT_FLAGS));
+                HIPCHK(d->seg2.alloc(2 * ((size_t)cap + MOT_SHADOW_SLOTS))); HIPCHK(hipMemsetAsync(d->seg2.p, 0, sizeof(bbox_t) * d->seg2.n, c->stream));
+                HIPCHK(d->det_copy.alloc(2 * (size_t)md)); HIPCHK(hipMemsetAsync(d->det_copy.p, 0, sizeof(bbox_t) * d->det_copy.n, c->stream));
+                HIPCHK(d->prov_rec.alloc(1)); HIPCHK(hipMemsetAsync(d->prov_rec.p, 0, sizeof(ProvRec), c->stream));
+                d->prov = true;
+            }
         }
         if (getenv("MOT_TRACE") && atoi(getenv("MOT_TRACE")) && !multi) { HIPCHK(d->trace.alloc((size_t)32 * cap * 8)); HIPCHK(hipMemsetAsync(d->trace.p, 0xFF, sizeof(int) * d->trace.n, c->stream)); }
     }
@@ -231,6 +287,22 @@ int split_early_max()
 {
     const int v = mot_impl::env().split_early_max;
     return v < 0 ? MOT_SPLIT_EARLY_MAX : v;
+}
+
+// The patch step of the last associated frame (launch_prov_patch: a no-op on the device unless that frame was committed provisionally).
+// pred_cur: the boxes a predict launch has written since (its shadow items behind the live tracks), or null.
+int dl_patch(mot_ctx* c, DevLoop* d, bbox_t* pred_cur)
+{
+    if (!d->prov || !d->patch_owed) return MOT_OK;
+    const DLState& S = d->S;
+    LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = c->pools[d->pool]->dev; life.kal = c->kal;
+    life.prov.enabled = 1; life.prov.sh_base = S.cap; life.prov.rec = d->prov_rec.p;
+    const bbox_t* trk = d->seg2.p + (size_t)d->par_last * (S.cap + MOT_SHADOW_SLOTS);
+    const bbox_t* det = d->det_copy.p + (size_t)d->par_last * S.max_dets;
+    life.trk_pred = trk; life.dets = det; life.nD = d->nD_last;
+    HIPCHK(launch_prov_patch(c->assoc, life, trk, det, d->nD_last, d->seq_last, pred_cur, c->stream));
+    d->patch_owed = false;
+    return MOT_OK;
 }
 
 int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, const void* dets_dev = nullptr, int nD = 0)
@@ -257,7 +329,10 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
     if (!d->have_cur) d->spec_side[d->buf_cur] = false;
     float2* spec_cur = d->det_spec.p + (size_t)d->buf_cur * d->spec_stride;            // this frame's detection spectra
     const float2* spec_prev = d->det_spec.p + (size_t)d->buf_prev * d->spec_stride;     // ... the previous frame's
+    const int par = (int)(d->frame_no & 1);
+    if (d->prov) S.gather = d->seg2.p + (size_t)par * (S.cap + MOT_SHADOW_SLOTS);   // this frame's predicted boxes: the half the previous frame's emulation is NOT reading
     bbox_t* seg = S.gather + (size_t)S.rank * S.spr;
+    const int n_pred = S.spr + (d->prov ? MOT_SHADOW_SLOTS : 0);       // the shadow items of a provisionally committed frame ride at the end of the predict list
     d->feat_early = false;
     const int early_max = split_early_max();
     d->feat_joined = false;
@@ -279,7 +354,7 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
             // small frames leave most CUs idle during the predict: the detection features (they only need the frame and the boxes) ride in
             // the SAME launch as extra workgroups -- no side stream, no events (MOT_JOINED_LAUNCH=0: side-stream launch as in round 2)
             if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
-            HIPCHK(launch_kcf_predict_features(c->pools[d->pool]->dev, l, S.spr, lf, nD, c->stream));
+            HIPCHK(launch_kcf_predict_features(c->pools[d->pool]->dev, l, n_pred, lf, nD, c->stream));
             d->feat_early = true; d->feat_joined = true;
         } else {
             if (early) {
@@ -300,8 +375,11 @@ int dl_begin(mot_ctx* c, DevLoop* d, const void* frame_dev, hipEvent_t* ev, cons
             // packet as its completion event instead of a record packet of its own behind it: one dispatch gap (~5 us) less in front of the row scan.
             d->mid_by_predict = false;
             if (!t0 && !t1 && S.ncls <= 1 && d->split && d->ev_mid) { t1 = d->ev_mid; d->mid_by_predict = true; }
-            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, S.spr, c->stream, t0, t1));
+            HIPCHK(launch_kcf_predict(c->pools[d->pool]->dev, l, n_pred, c->stream, t0, t1));
         }
+        // the previous frame's patch step: a no-op unless that frame was committed provisionally -- then it waits for the emulation that has been
+        // running beside this predict, and copies the shadow items' results over the two tracks if the reference's optimum is the swapped one
+        if (d->prov && d->patch_owed) { int rc = dl_patch(c, d, seg); if (rc) return rc; }
     } else { if (ev) HIPCHK(hipEventRecord(ev[0], c->stream)); HIPCHK(launch_kalman_predict(c->kal, S.loc_slots, S.loc_count, S.spr, seg, 1, c->stream)); }
     if (ev && !ext_timed) HIPCHK(hipEventRecord(ev[1], c->stream));
     d->begun = true;
@@ -340,7 +418,17 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
                        (S.cap + S.world - 1) / S.world + d->next_nD > split_early_max();
     // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
     LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
-    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, ((feat_here || ahead || d->want_mid) && !d->mid_by_predict) ? d->ev_mid : nullptr, &life));
+    AssocEmu emu{}; const int par = (int)(d->frame_no & 1);
+    if (d->prov) {
+        if (d->patch_owed) { int rc = dl_patch(c, d, nullptr); if (rc) return rc; }   // (two-call form without a predict in between: cannot happen, but never two frames owed)
+        life.prov.enabled = 1; life.prov.sh_base = S.cap; life.prov.rec = d->prov_rec.p;
+        emu.stream = d->emu; emu.ev_rowscan = d->ev_rs; emu.det_copy = d->det_copy.p + (size_t)par * S.max_dets;
+    }
+    unsigned seq = 0;
+    HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, ((feat_here || ahead || d->want_mid) && !d->mid_by_predict) ? d->ev_mid : nullptr, &life,
+                        d->prov ? &emu : nullptr, &seq));
+    if (d->prov) { d->patch_owed = true; d->seq_last = seq; d->nD_last = nD; d->par_last = par; }
+    if (d->prov && ev) { int rc = dl_patch(c, d, nullptr); if (rc) return rc; }   // profiled frame: the chain's stage time includes the emulation, as without the overlap
     d->mid_valid = feat_here || ahead || d->want_mid; d->mid_by_predict = false;
     if (feat_here || ahead) HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
     if (feat_here) {
@@ -393,12 +481,22 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
 namespace mot_impl {
 // sticky device-side errors of the device-resident loop (the stream must be idle).  Also drains the side stream: a detection-feature
 // launch may still be reading the frame the caller is about to release.
+// every synchronisation point and read-back: a provisionally committed frame gets its patch step first (enqueued on the context's stream; it waits
+// for the emulation itself), so what the caller reads is the reference's state, never the provisional one
+int devloop_flush(mot_ctx* c)
+{
+    if (!c->devloop || !c->devloop->prov || !c->devloop->patch_owed) return MOT_OK;
+    return dl_patch(c, c->devloop, nullptr);
+}
 int devloop_check(mot_ctx* c)
 {
     if (!c->devloop) return MOT_OK;
+    if (c->devloop->patch_owed) { int rc = devloop_flush(c); if (rc) return rc; HIPCHK(hipStreamSynchronize(c->stream)); }
     if (c->devloop->side) HIPCHK(hipStreamSynchronize(c->devloop->side));
+    if (c->devloop->emu) HIPCHK(hipStreamSynchronize(c->devloop->emu));
     int err[8];
     HIPCHK(hipMemcpy(err, c->devloop->S.err, sizeof err, hipMemcpyDeviceToHost));
+    if (err[5]) return fail(MOT_ERR_DEVICE, "provisional commit of chain %d: the order-exact emulation returned neither of the two optima (internal inconsistency)", err[5]);
     if (err[4]) return fail(MOT_ERR_DEVICE, "Munkres helper workgroups timed out (hand-off %d); the frame was dropped", err[4]);
     if (err[3]) return fail(MOT_ERR_DEVICE, "all-gather segment overflow (%d)", err[3]);
     return MOT_OK;
@@ -591,7 +689,7 @@ int mot_debug_predict_timing(mot_ctx* c, int n_pairs)
     if (!c || n_pairs < 0) return fail(MOT_ERR_ARG, "bad argument");
     int rc = ensure_device(c); if (rc) return rc;
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     for (hipEvent_t e : d->pt) (void)hipEventDestroy(e);
     d->pt.assign((size_t)2 * n_pairs, nullptr); d->pt_used = 0;
     for (hipEvent_t& e : d->pt) HIPCHK(hipEventCreate(&e));
@@ -601,7 +699,7 @@ int mot_debug_predict_times(mot_ctx* c, float* out_ms, int cap, int* n)
 {
     if (!c || !c->devloop || !out_ms || !n) return fail(MOT_ERR_ARG, "bad argument");
     DevLoop* d = c->devloop;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     int k = 0;
     for (; k < d->pt_used && k < cap; k++) HIPCHK(hipEventElapsedTime(&out_ms[k], d->pt[2 * k], d->pt[2 * k + 1]));
     *n = k; d->pt_used = 0;
@@ -637,7 +735,7 @@ int mot_debug_profile_stages(mot_ctx* c, int enable, float* stage_ms4)
     DevLoop* d; rc = devloop_get(c, &d); if (rc) return rc;
     if (!d->ev_ok) { for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&d->ev[i])); d->ev_ok = true; }
     if (stage_ms4 && d->prof_two_call) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        MOT_SYNC_CTX(c);
         float ms;
         if (hipEventElapsedTime(&ms, d->ev[0], d->ev[1]) != hipSuccess) { (void)hipGetLastError(); return fail(MOT_ERR_STATE, "no profiled frame yet"); }
         stage_ms4[0] = ms;
@@ -653,7 +751,7 @@ int mot_live_count(mot_ctx* c, int* n_live)
 {
     if (!c || !n_live) return fail(MOT_ERR_ARG, "null argument");
     if (!c->devloop) { *n_live = (int)c->live.size(); return MOT_OK; }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     int rc = devloop_check(c); if (rc) return rc;
     HIPCHK(hipMemcpy(n_live, c->devloop->S.nlive, sizeof(int), hipMemcpyDeviceToHost));
     return MOT_OK;
@@ -676,7 +774,7 @@ int mot_live_response(mot_ctx* c, int live_index, float* out, int* f_rows, int* 
     const KcfPool& p = c->pools[c->devloop->pool]->dev;
     if (f_rows) *f_rows = p.hb; if (f_cols) *f_cols = p.wb;
     if (!out) return MOT_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     int n = 0, slot = -1;
     HIPCHK(hipMemcpy(&n, S.nlive, sizeof(int), hipMemcpyDeviceToHost));
     if (live_index < 0 || live_index >= n) return fail(MOT_ERR_ARG, "live index %d out of range (%d live tracks)", live_index, n);
@@ -692,7 +790,7 @@ int mot_live_model(mot_ctx* c, int live_index, float* xm_out, float* alpha_out, 
     const DLState& S = c->devloop->S;
     if (S.kind != MOT_TRACKER_KCF || S.ncls > 1) return fail(MOT_ERR_STATE, "mot_live_model: single-template KCF loop only");
     const KcfPool& p = c->pools[c->devloop->pool]->dev;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     int rc = devloop_check(c); if (rc) return rc;                      // drains the side stream too
     int n = 0, slot = -1;
     HIPCHK(hipMemcpy(&n, S.nlive, sizeof(int), hipMemcpyDeviceToHost));
@@ -748,7 +846,7 @@ int mot_debug_trace_read(mot_ctx* c, int* out, size_t cap_ints, size_t* n_ints)
     DevLoop* d = c->devloop;
     if (n_ints) *n_ints = d->trace.n;
     if (!out || !d->trace.p) return MOT_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     HIPCHK(hipMemcpy(out, d->trace.p, sizeof(int) * std::min(cap_ints, d->trace.n), hipMemcpyDeviceToHost));
     return MOT_OK;
 }
@@ -793,7 +891,7 @@ int state_parts(mot_ctx* c, DevLoop* d, std::vector<StatePart>& parts, StateHead
 int quiesce(mot_ctx* c, DevLoop* d)
 {
     if (d->begun) return fail(MOT_ERR_STATE, "state save / load between mot_step_begin_device and mot_step_finish_device");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     if (d->side) HIPCHK(hipStreamSynchronize(d->side));
     if (d->copy) HIPCHK(hipStreamSynchronize(d->copy));
     return devloop_check(c);
@@ -851,7 +949,7 @@ int mot_live_tracks(mot_ctx* c, bbox_t* boxes, unsigned* tids, int* ages, int* n
     }
     const DLState& S = c->devloop->S;
     int n = 0;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    MOT_SYNC_CTX(c);
     int rc = devloop_check(c); if (rc) return rc;
     HIPCHK(hipMemcpy(&n, S.nlive, sizeof(int), hipMemcpyDeviceToHost));
     if (n_live) *n_live = n;

@@ -33,6 +33,7 @@ struct EnvSwitches {
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
     int zc_async;            // MOT_ZC_ASYNC=0: per-object updates with a caller patch wait for their kernel before they return (round-5 default: they do not)
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
+    int prov;                // MOT_PROV=0: no provisional commits of two-row tie frames (round 6): the sparse emulation stays in the solver's launch and the frame waits for it
 };
 
 inline const EnvSwitches& env()
@@ -58,6 +59,7 @@ inline const EnvSwitches& env()
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
         s.zc_async = off("MOT_ZC_ASYNC") ? 0 : 1;
         s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
+        s.prov = off("MOT_PROV") ? 0 : 1;
         return s;
     }();
     return e;

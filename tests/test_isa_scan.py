@@ -90,7 +90,7 @@ def test_hot_kernels_keep_their_register_budget():
         by_name[pretty] = d
     hot = ["kcf_predict_kernel<7>", "kcf_features_kernel<7>", "kcf_predict_features_kernel<7, false>", "kcf_update_kernel<7>", "kcf_predict_multi_kernel<7>",
            "kcf_predict_kernel<1>", "kcf_features_kernel<1>", "kcf_update_kernel<1>", "kcf_predict_multi_kernel<1>", "kcf_predict_multi_kernel<3>", "kcf_update_multi_kernel<3>",
-           "lap_rowscan_kernel", "lap_solve_kernel", "lap_solve2_kernel<false>", "mk_sparse_kernel<false>", "munkres_kernel<false>", "lap_dense_kernel",
+           "lap_rowscan_kernel", "lap_solve_kernel", "lap_solve2_kernel<false>", "mk_sparse_kernel<false>", "mk_sparse_stream_kernel<false>", "munkres_kernel<false, false>", "lap_dense_kernel",
            "kalman_predict_kernel", "kalman_update_kernel"]
     for k in hot:
         assert k in by_name, f"{k} not in the library (have: {sorted(by_name)[:8]} ...)"
