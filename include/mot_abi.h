@@ -139,7 +139,7 @@ int mot_delete_batch(mot_ctx* ctx, const int* ids, int n);
  * `float* rgb` (trackers/kcf.cpp:455-476).  Used by the per-object drop-in layer.
  * Completion: every call copies the caller's patches and boxes before it returns.  A predict returns the boxes and therefore waits
  * for its kernel.  An UPDATE of at most 8 tracks returns with its launch queued on the context's stream (pinned, device-mapped staging
- * in two halves; MOT_ZC_ASYNC=0: it waits) -- the model is updated for every later call on this context, which the stream orders behind
+ * in two halves; the next call does not wait for it) -- the model is updated for every later call on this context, which the stream orders behind
  * it, and a device-side failure surfaces at the next call that waits (mot_ctx_sync, any predict).  td.cpp's update loop
  * (td.cpp:512-582: crop + resize on the host, then tracker_update, per object) thereby overlaps its host work with the previous
  * object's kernel. */

@@ -458,21 +458,29 @@ __device__ void prov_apply(const AssocArgs& a, const LifeArgs& life, const AT* a
     const ProvRec* rec = life.prov.rec;
     const DLState& D = life.S;
     const KcfPool& kp = life.kp;
-    const int rA = rec->rowA, rB = rec->rowB, cA = rec->colA, cB = rec->colB;
-    const int gA = (int)asg[rA], gB = (int)asg[rB];
-    const bool same = gA == cA && gB == cB, swapped = gA == cB && gB == cA;
-    bool bad = !(same || swapped);
-    if (tid < nR && tid != rA && tid != rB && (int)asg[tid] != (int)L.colOfRow[tid]) bad = true;   // every other row is forced
+    const int np = min(rec->npairs, MOT_PROV_PAIRS);
+    bool bad = false, in_pair = false; unsigned swapmask = 0;
+    for (int i = 0; i < np; i++) {
+        const ProvPair pr = rec->pr[i];
+        const int gA = (int)asg[pr.rowA], gB = (int)asg[pr.rowB];
+        const bool same = gA == pr.colA && gB == pr.colB, swapped = gA == pr.colB && gB == pr.colA;
+        if (!(same || swapped)) bad = true;
+        if (swapped) swapmask |= 1u << i;
+        if (tid == pr.rowA || tid == pr.rowB) in_pair = true;
+    }
+    if (tid < nR && !in_pair && (int)asg[tid] != (int)L.colOfRow[tid]) bad = true;   // every other row is forced
     const bool anybad = __syncthreads_or(bad) != 0;
-    if (swapped && !anybad) {
+    if (swapmask && !anybad) {
         const int tot = MOT_NCHAN * kp.nbins;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 2 * np; k++) {
+            if (!((swapmask >> (k >> 1)) & 1)) continue;
             const ProvTrack t = rec->t[k];
             if (t.sh < 0) continue;
             const float2* xs = kp.xm + (size_t)t.sh * tot; float2* xd = kp.xm + (size_t)t.slot * tot;
             for (int i = tid; i < tot; i += MK_THREADS) xd[i] = xs[i];
             for (int i = tid; i < kp.nbins; i += MK_THREADS) kp.alpha[(size_t)t.slot * kp.nbins + i] = kp.alpha[(size_t)t.sh * kp.nbins + i];
-            for (int i = tid; i < kp.nb; i += MK_THREADS) kp.response[(size_t)t.slot * kp.nb + i] = kp.response[(size_t)t.sh * kp.nb + i];
+            // the response map belongs to the last predict: the shadow has one only if a predict launch ran since the clone (else the track keeps its own)
+            if (pred_cur) for (int i = tid; i < kp.nb; i += MK_THREADS) kp.response[(size_t)t.slot * kp.nb + i] = kp.response[(size_t)t.sh * kp.nb + i];
             if (tid == 0) {
                 kp.pos[t.slot] = kp.pos[t.sh]; kp.scale[t.slot] = kp.scale[t.sh]; kp.first_update[t.slot] = kp.first_update[t.sh];
                 D.pend_det[t.slot] = D.pend_det[t.sh];
@@ -483,10 +491,10 @@ __device__ void prov_apply(const AssocArgs& a, const LifeArgs& life, const AT* a
     }
     if (tid == 0) {
         if (anybad) D.err[5] = rec->seq;                               // sticky: devloop_check reports it
-        for (int k = 0; k < 2; k++) if (rec->t[k].sh >= 0) D.pend_det[rec->t[k].sh] = -1;
+        for (int k = 0; k < 2 * np; k++) if (rec->t[k].sh >= 0) D.pend_det[rec->t[k].sh] = -1;
         *D.loc_count = rec->n_new;                                     // the shadow items leave the predict list
         L.hdr[LAP_H_PROV] = 0; L.hdr[LAP_H_PMODE] = 0;
-        if (swapped && !anybad) L.hdr[LAP_H_PSTAT + 1] += 1;
+        if (!anybad) L.hdr[LAP_H_PSTAT + 1] += __popc(swapmask);
         if (by_dense) { L.hdr[LAP_H_PSTAT + 2] += 1; L.hdr[LAP_H_LAST + 15] = 2; L.hdr[LAP_H_CUM + 9] += 1; } else L.hdr[LAP_H_CUM + 8] += 1;
     }
 }
@@ -530,7 +538,7 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
             if (spins > 50000000) { if (tid == 0) { life.S.err[5] = (int)a.seq; *life.S.loc_count = life.prov.rec->n_new; Lp.hdr[LAP_H_PROV] = 0; } return; }   // ("cannot happen")
             __builtin_amdgcn_s_sleep(8);
         }
-        if (Lp.hdr[LAP_H_PMODE] == 1) { prov_apply(a, life, Lp.spAssign, nR, reinterpret_cast<bbox_t*>(a.cost_only), false); return; }
+        if (Lp.hdr[LAP_H_PMODE] == 1 && !(want_cost & 8)) { prov_apply(a, life, Lp.spAssign, nR, reinterpret_cast<bbox_t*>(a.cost_only), false); return; }
         // the sparse emulation refused (an entry outside its candidate lists could have mattered): the dense emulation below decides the bit
     } else if ((lap_mode & 2) != 0 && (!HELP || blockIdx.x == 0)) {
         // Stream emulation, frame neither certified nor committed provisionally (verdict 2): the emulation's kernel decides -- and commits -- the
@@ -1244,13 +1252,13 @@ hipError_t launch_assoc(const AssocWs& ws, const bbox_t* trk, const int* nT_dev,
 hipError_t launch_prov_patch(const AssocWs& ws, const LifeArgs& life, const bbox_t* trk, const bbox_t* det, int nD, unsigned seq, bbox_t* pred_cur, hipStream_t s)
 {
     AssocArgs a{};
-    a.trk = trk; a.det = det; a.nT_dev = &life.prov.rec->pad; a.nT = life.S.cap; a.nD = nD;    // ProvRec::pad: the live count the frame was associated with
+    a.trk = trk; a.det = det; a.nT_dev = &life.prov.rec->nT; a.nT = life.S.cap; a.nD = nD;    // ProvRec::nT: the live count the frame was associated with
     a.ws = ws; a.linemin = ws.linemin; a.dims = ws.status + 4;
     a.cost_only = reinterpret_cast<double*>(pred_cur);                  // (patch mode: the slot carries the predicted boxes of the launch in between)
     a.seq = seq;
     hipError_t e = mot_impl::func_lds_once(reinterpret_cast<const void*>(munkres_kernel<false, true>), (int)sizeof(MkShared)); if (e != hipSuccess) return e;
     mot_impl::lds_poison(s);
-    hipLaunchKernelGGL((munkres_kernel<false, true>), dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, 4, life, 4);
+    hipLaunchKernelGGL((munkres_kernel<false, true>), dim3(1), dim3(MK_THREADS), sizeof(MkShared), s, a, 4 | (mot_impl::env().prov == 2 ? 8 : 0), life, 4);   // (bit 3: test hook MOT_PROV=2)
     return hipGetLastError();
 }
 

@@ -2070,7 +2070,7 @@ void kcf_pool_layout(KcfPool& p, bool allow_r1, bool allow_inplace)
 void kcf_pool_layout_r1(KcfPool& p, bool allow)
 {
     p.r1_lds = 0; p.offR1c = 0; p.offX = 0; p.offW = 0; p.tile_T = 0; p.stripe_k = 0;
-    if (!allow || p.use_lds || p.fft20 || p.hb > MOT_DFT_MFMA_MAX || p.wb > MOT_DFT_MFMA_MAX || !mot_impl::env().kcf_r1_lds) return;
+    if (!allow || p.use_lds || p.fft20 || p.hb > MOT_DFT_MFMA_MAX || p.wb > MOT_DFT_MFMA_MAX) return;
     const int xtl = (p.wb + 15) >> 4, ksr = (p.hb + 3) >> 2;
     if (!((xtl == 3 && (ksr == 9 || ksr == 10)) || (xtl == 2 && (ksr == 7 || ksr == 8 || ksr == 10)))) return;
     auto up4 = [](int v) { return (v + 3) & ~3; };

@@ -211,14 +211,15 @@ __device__ __forceinline__ double readlane_f64(double x, int src)   // src wave-
 // ---- provisional commit (round 6; mot_dev.h: ProvRec) ----------------------------------------------------------------------------
 // Called (workgroup-uniform) when lap_certify found a cycle among the near-tight edges.  ed[0, ne) is the edge list in LDS, alive[] what the
 // certificate's forward peel left (nodes with a path INTO a cycle).  Peeling from the other side as well (a node stays only if an alive node
-// has an edge into it) until nothing changes leaves the nodes that lie ON a cycle or between two cycles.  If that is exactly two rows A, B
-// with A -> B and B -> A, the cycle A <-> B is the only one: every assignment within eps of the optimum is M or M with the columns of A and
-// B exchanged (lap_certify.h: any other assignment differs from M along cycles of near-tight edges or costs at least eps - n tol more), so
-// the reference returns one of the two.  Both rows are matched in both, so the lifecycle step (td.cpp:472-644) sees the same counters,
-// deaths and spawns -- only the box / spectrum the two tracks adopt differs.  M is committed here; the two tracks are cloned into the pool's
-// shadow slots, which adopt the OTHER detection, and appended to the predict list: the next predict launch computes both alternatives and
-// prov_patch (assoc_kernels.hip) keeps the one the order-exact emulation names.  Refused (-> today's path, verdict 2) when the core is
-// anything else, when a free column is part of it, or when the emulation's kernel is not running yet (the patch step waits for it by
+// has an edge into it) until nothing changes leaves the nodes that lie ON a cycle or between two cycles.  If every one of them has exactly one
+// remaining target and is that row's only target in turn -- pairs A <-> B -- those two-row cycles are the only cycles: every assignment within
+// eps of the optimum is M with the columns of some of the pairs exchanged (lap_certify.h: any other assignment differs from M along cycles
+// of near-tight edges or costs at least eps - n tol more), so the reference returns one of those.  The rows are matched in all of them, so the
+// lifecycle step (td.cpp:472-644) sees the same counters, deaths and spawns -- only the box / spectrum the tracks of a pair adopt differs.
+// M is committed here; those tracks are cloned into the pool's shadow slots, which adopt the OTHER detection, and appended to the predict
+// list: the next predict launch computes both alternatives and prov_apply (assoc_kernels.hip) keeps, pair by pair, the one the order-exact
+// emulation names.  Refused (-> the frame waits for the emulation, verdict 2) when the core is anything else or has more than
+// MOT_PROV_PAIRS pairs, when a free column is part of it, or when the emulation's kernel is not running yet (the patch step waits for it by
 // polling: that is only safe for a kernel that is already resident).
 __device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, LapShared& S, LapFused& F, int nR, int nC, bool rowsTrk, int ne)
 {
@@ -227,6 +228,9 @@ __device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, La
     unsigned* ed = F.certify;
     unsigned char* alive = reinterpret_cast<unsigned char*>(ed + LAP_EDGES);
     unsigned char* mark = alive + MK_MAXN + 64;
+    int* tmin = reinterpret_cast<int*>(ed + 2048);                     // (ne <= 1024: the rest of the edge area is free) smallest / largest alive target of a row
+    int* tmax = reinterpret_cast<int*>(ed + 4096);
+    int* prow = reinterpret_cast<int*>(ed + 6144);                     // [2 * MOT_PROV_PAIRS]: the pairs, (lower row, its partner)
     if (tid < 64) {
         for (int guard = 0; guard < 4 * MK_MAXN; guard++) {
             bool ch = false;
@@ -239,28 +243,53 @@ __device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, La
             for (int e = lane; e < ne; e += 64) { const unsigned s = ed[e] >> 16; if (alive[s] && !mark[s]) { alive[s] = 0; ch = true; } }
             if (!__ballot(ch)) break;
         }
-        unsigned lo = 0xFFFFFFFFu, hi = 0;
-        for (int e = lane; e < ne; e += 64) { const unsigned s = ed[e] >> 16; if (alive[s]) { lo = s < lo ? s : lo; hi = s > hi ? s : hi; } }
-        lo = wave_min_u32_dpp(lo); hi = ~wave_min_u32_dpp(~hi);
-        bool other = false, e1 = false, e2 = false;
-        for (int e = lane; e < ne; e += 64) {
-            const unsigned x = ed[e], s = x >> 16, d = x & 0xFFFF;
-            if (alive[s] && s != lo && s != hi) other = true;
-            if (s == lo && d == hi) e1 = true;
-            if (s == hi && d == lo) e2 = true;
+        // what is left lies on a cycle or between two cycles.  Disjoint two-row cycles <=> every remaining row has exactly ONE remaining
+        // target, and is that row's only target in turn (then no other cycle exists among them: out-degree one)
+        for (int r = lane; r <= nR; r += 64) { tmin[r] = 0x7FFFFFFF; tmax[r] = -1; }
+        for (int e = lane; e < ne; e += 64) { const unsigned x = ed[e], s = x >> 16, d = x & 0xFFFF; if (alive[s] && alive[d]) { atomicMin(&tmin[s], (int)d); atomicMax(&tmax[s], (int)d); } }
+        int np = 0, code = 0, ncore = 0;                               // code: 0 fine so far, 2 a free column is part of the core, 3 too many pairs, 4 not disjoint two-row cycles
+        if (alive[nR]) code = 2;
+        for (int r0 = 0; r0 < nR; r0 += 64) {
+            const int r = r0 + lane;
+            const bool al = r < nR && alive[r];
+            int p = -1; bool good = false;
+            if (al) { p = tmin[r]; good = p == tmax[r] && p >= 0 && p < nR && p != r && alive[p] && tmin[p] == r && tmax[p] == r; }
+            if (__ballot(al && !good) && !code) code = 4;
+            const unsigned long long lead = __ballot(al && good && r < p);
+            ncore += __popcll(__ballot(al));
+            for (unsigned long long m = lead; m; m &= m - 1) {
+                const int src = __ffsll((long long)m) - 1;
+                const int rr = r0 + src, pp = __builtin_amdgcn_readlane(p, src);
+                if (np < MOT_PROV_PAIRS) { if (lane == 0) { prow[2 * np] = rr; prow[2 * np + 1] = pp; } }
+                else if (!code) code = 3;
+                np++;
+            }
         }
-        const bool ok = lo != 0xFFFFFFFFu && lo < hi && hi < (unsigned)nR && !__ballot(other) && __ballot(e1) && __ballot(e2);
+        if (!code && np == 0) code = 6;
         // the emulation's kernel must be resident already: the patch step polls for its end
         const int emu = tagged_value(__hip_atomic_load(&L.hdr[LAP_H_EMU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.seq, 0);
-        if (lane == 0) { S.flag[2] = (ok && emu == 1) ? 1 : 0; S.flag[3] = (int)lo; S.flag[4] = (int)hi; }
+        if (!code && emu != 1) code = 5;
+        if (lane == 0) {
+            S.flag[2] = code == 0 ? 1 : 0; S.flag[3] = np;
+            // (debug, mot_get_lap_stats()[31]) 1 committed provisionally, else why not (codes above; 5 the emulation's kernel had not started, 6 no core row) | core rows << 8 | pairs << 20
+            L.hdr[47] = (code ? code : 1) | (ncore << 8) | (np << 20);
+        }
     }
     __syncthreads();
     if (!S.flag[2]) return false;
     const DLState& D = life.S;
-    const int rA = S.flag[3], rB = S.flag[4], cA = S.colOfRow[rA], cB = S.colOfRow[rB];
-    const int T[2] = { rowsTrk ? rA : cA, rowsTrk ? rB : cB };         // the two tracks ...
-    const int Dm[2] = { rowsTrk ? cA : rA, rowsTrk ? cB : rB };        // ... and the detections they adopt in M; the alternative: each adopts the other's
-    const int slotT[2] = { D.slot[T[0]], D.slot[T[1]] };               // (live order of THIS frame: read before the lifecycle step compacts the list)
+    const int np = S.flag[3];
+    int T[2 * MOT_PROV_PAIRS], Dm[2 * MOT_PROV_PAIRS], slotT[2 * MOT_PROV_PAIRS];
+    ProvRec* rec = life.prov.rec;
+#pragma unroll
+    for (int i = 0; i < MOT_PROV_PAIRS; i++) {
+        if (i >= np) { T[2 * i] = T[2 * i + 1] = 0; Dm[2 * i] = Dm[2 * i + 1] = 0; slotT[2 * i] = slotT[2 * i + 1] = -2; continue; }
+        const int rA = prow[2 * i], rB = prow[2 * i + 1], cA = S.colOfRow[rA], cB = S.colOfRow[rB];
+        T[2 * i] = rowsTrk ? rA : cA; T[2 * i + 1] = rowsTrk ? rB : cB;          // the two tracks of the cycle ...
+        Dm[2 * i] = rowsTrk ? cA : rA; Dm[2 * i + 1] = rowsTrk ? cB : rB;        // ... and the detections they adopt in M; the alternative: each adopts the other's
+        slotT[2 * i] = D.slot[T[2 * i]]; slotT[2 * i + 1] = D.slot[T[2 * i + 1]];   // (live order of THIS frame: read before the lifecycle step compacts the list)
+        if (tid == 0) { rec->pr[i].rowA = rA; rec->pr[i].rowB = rB; rec->pr[i].colA = cA; rec->pr[i].colB = cB; }
+    }
     const int nT_now = *D.nlive;
     __syncthreads();
     if (tid < nR) a.ws.assignment[tid] = S.colOfRow[tid];
@@ -270,18 +299,22 @@ __device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, La
     __threadfence_block();
     __syncthreads();
     const int n_new = *D.nlive;
-    int* posn = S.wave_tot;                                            // [0], [1]: where the two tracks sit in the new live list (-1: the track died -- nothing to patch for it)
-    if (tid < 2) posn[tid] = -1;
+    int* posn = S.wave_tot;                                            // where the tracks sit in the new live list (-1: the track died -- nothing to patch for it)
+    if (tid < 2 * MOT_PROV_PAIRS) posn[tid] = -1;
     __syncthreads();
-    if (tid < n_new) { const int sl = D.slot[tid]; if (sl == slotT[0]) posn[0] = tid; if (sl == slotT[1]) posn[1] = tid; }
+    if (tid < n_new) {
+        const int sl = D.slot[tid];
+#pragma unroll
+        for (int k = 0; k < 2 * MOT_PROV_PAIRS; k++) if (sl == slotT[k]) posn[k] = tid;
+    }
     __syncthreads();
     const KcfPool& kp = life.kp;
     const int tot = MOT_NCHAN * kp.nbins;
     int nvalid = 0;
-    ProvRec* rec = life.prov.rec;
-    for (int k = 0; k < 2; k++) {
-        if (posn[k] < 0) { if (tid == 0) { rec->t[k].newpos = -1; rec->t[k].slot = slotT[k]; rec->t[k].sh = -1; rec->t[k].det_alt = Dm[k ^ 1]; } continue; }
-        const int sh = life.prov.sh_base + nvalid, sl = slotT[k], dalt = Dm[k ^ 1];
+    for (int k = 0; k < 2 * np; k++) {
+        const int dalt = Dm[k ^ 1];
+        if (posn[k] < 0) { if (tid == 0) { rec->t[k].newpos = -1; rec->t[k].slot = slotT[k]; rec->t[k].sh = -1; rec->t[k].det_alt = dalt; } continue; }
+        const int sh = life.prov.sh_base + nvalid, sl = slotT[k];
         // the clone: the model as it is BEFORE the pending blend (the lifecycle step only noted which spectrum the slot adopts)
         const float2* xs = kp.xm + (size_t)sl * tot; float2* xd = kp.xm + (size_t)sh * tot;
         for (int i = tid; i < tot; i += MK_THREADS) xd[i] = xs[i];
@@ -298,7 +331,7 @@ __device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, La
         nvalid++;
     }
     if (tid == 0) {
-        rec->seq = (int)a.seq; rec->rowA = rA; rec->rowB = rB; rec->colA = cA; rec->colB = cB; rec->nvalid = nvalid; rec->n_new = n_new; rec->pad = nT_now;
+        rec->seq = (int)a.seq; rec->npairs = np; rec->nvalid = nvalid; rec->n_new = n_new; rec->nT = nT_now;
         *D.loc_count = n_new + nvalid;
         L.hdr[LAP_H_PMODE] = 0; L.hdr[LAP_H_PROV] = (int)a.seq; L.hdr[LAP_H_PSTAT] += 1;
     }
@@ -313,6 +346,8 @@ __device__ bool lap_try_provisional(const AssocArgs& a, const LifeArgs& life, La
 // column.  Same arithmetic per examined entry as lap_verify_kernel (the dense pass stays for caller matrices and behind the
 // dense solver).
 // Returns (workgroup-uniform) 1 if the frame is certified here (and, in the device loop, committed), else 2.
+// PROV: provisional commits compiled in (the single-workgroup kernel of the stream-emulation chain; the two-workgroup launch never commits provisionally)
+template <bool PROV>
 __device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life, unsigned char* lap_raw)
 {
     LapShared& S = *reinterpret_cast<LapShared*>(lap_raw);
@@ -612,7 +647,7 @@ __device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life
     }
     if (reason != 0) {
         // a tie -- but if all that ties is ONE pair of rows that could swap their columns, the frame is committed now and the emulation only owes the swap bit
-        if (reason == 4 && life.enabled && life.prov.enabled && a.stream_emu && ne <= 16 * 64 && lap_try_provisional(a, life, S, F, nR, nC, rowsTrk, ne)) {
+        if (PROV && reason == 4 && life.enabled && life.prov.enabled && a.stream_emu && ne <= 16 * 64 && lap_try_provisional(a, life, S, F, nR, nC, rowsTrk, ne)) {
             if (tid == 0) { L.hdr[LAP_H_DONE] = 1; L.hdr[56] = (int)(wall_clock64() - t_tail); }
             return 3;
         }
@@ -631,7 +666,7 @@ __device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life
 __global__ void __launch_bounds__(MK_THREADS) lap_solve_kernel(AssocArgs a, int fused, LifeArgs life)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
-    const int verdict = lap_solve_run(a, fused, life, lap_raw);
+    const int verdict = lap_solve_run<true>(a, fused, life, lap_raw);
     if (!a.stream_emu) return;
     // stream emulation (round 6): the sparse emulation runs beside this kernel as a kernel of its own and learns the verdict from the same word
     __threadfence();
@@ -679,7 +714,7 @@ __global__ void __launch_bounds__(MK_THREADS) lap_solve2_kernel(AssocArgs a, Lif
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
     if (blockIdx.x == 1) { mk_sparse_run<true, TIMING>(a, mk_batch, 1, life, lap_raw); return; }
-    const int verdict = lap_solve_run(a, 1, life, lap_raw);
+    const int verdict = lap_solve_run<false>(a, 1, life, lap_raw);
     __threadfence();                                                   // everything this workgroup wrote (duals, header, lifecycle) before the verdict
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&a.ws.lap.hdr[LAP_H_VERDICT], tagged_word(a.seq, verdict), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

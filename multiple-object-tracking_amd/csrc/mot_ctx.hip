@@ -364,7 +364,7 @@ int run_batch(mot_ctx* c, bool predict, const int* ids, int n, const float* cons
         HIPCHK(hipStreamSynchronize(c->stream));                       // zero-copy: the kernel wrote the pinned buffer itself; its end-of-kernel release + this wait make it visible
         R.busy[0] = R.busy[1] = false;                                 // (the stream is drained)
         for (int q = 0; q < n; q++) boxes_out[g.order[q]] = st_boxes_b[q];
-    } else if (ring && !predict && mot_impl::env().zc_async) {
+    } else if (ring && !predict) {
         // an update through the ring: the caller's patch and box are copied, nothing comes back -- the call returns with its kernel queued; the
         // half is marked busy until its event has passed (every later use of this context is ordered behind the kernel on the stream)
         HIPCHK(hipEventRecord(R.ev[half], c->stream));

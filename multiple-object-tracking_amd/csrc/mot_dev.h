@@ -153,19 +153,23 @@ enum { LAP_H_SOLVE = 0,       // solver status of this launch: 0 ok, 1 gave up, 
        LAP_H_CUM = 32 };      // [32..36] cumulative certificate outcomes (0 certified, 1..4 reasons), [40] sparse emulation accepted, [41] refused -> dense
 
 // ---- provisional commit of a tie frame (round 6, lap_kernels.hip: lap_try_provisional) --------------------------------------------
-// When the certificate fails ONLY because of one two-row cycle of near-tight edges -- rows A, B could swap their columns at (almost) equal
-// cost, every other row is forced -- the reference returns the solver's matching M or M with that one swap, and nothing else depends on
-// which: both rows are assigned either way, so counters, deaths, spawns, track ids and the order of the live list are the same.  The
-// solver's workgroup then commits M at once (lifecycle step included) and clones the two tracks into SHADOW slots that adopt the other
-// detection; the next frame's predict launch computes both alternatives while the order-exact emulation (on a stream of its own) is still
-// running, and the patch step (prov_patch, assoc_kernels.hip) copies the shadows over the tracks iff the emulation says "swapped".
-#define MOT_SHADOW_SLOTS 2    /* extra slots at the end of a device-loop KCF pool / predict list / box segment */
+// When the certificate fails ONLY because of a few disjoint two-row cycles of near-tight edges -- rows A, B could swap their columns at
+// (almost) equal cost, every other row is forced -- the reference returns the solver's matching M with some of those swaps applied, and
+// nothing else depends on which: the rows are assigned either way, so counters, deaths, spawns, track ids and the order of the live list are
+// the same.  The solver's workgroup then commits M at once (lifecycle step included) and clones the tracks of the cycles into SHADOW slots
+// that adopt the other detection; the next frame's predict launch computes both alternatives while the order-exact emulation (on a stream
+// of its own) is still running, and the patch step (prov_apply, assoc_kernels.hip) copies the shadows over the tracks of every cycle the
+// emulation reports as swapped.
+#define MOT_PROV_PAIRS 3      /* disjoint two-row cycles one frame may be committed with (seen on the bench stream: 1 in ~77 %, 2 or 3 in the rest of the tie frames) */
+#define MOT_SHADOW_SLOTS (2 * MOT_PROV_PAIRS)   /* extra slots at the end of a device-loop KCF pool / predict list / box segment */
 struct ProvTrack { int newpos, slot, sh, det_alt; bbox_t box_alt; };   // live position after the lifecycle step (-1: the track died), pool slot, shadow slot, the detection the shadow adopts + its box
+struct ProvPair { int rowA, rowB, colA, colB; };   // one cycle in the orientation of the assignment problem: M[rowA] = colA, M[rowB] = colB; its tracks are t[2 i], t[2 i + 1]
 struct ProvRec {
     int seq;                  // chain sequence number of the frame (its own copy: LAP_H_PROV is the flag)
-    int rowA, rowB, colA, colB;   // the cycle in the orientation of the assignment problem: M[rowA] = colA, M[rowB] = colB
-    int nvalid, n_new, pad;   // shadow items appended to the predict list; live tracks after the lifecycle step
-    ProvTrack t[2];
+    int npairs, nvalid, n_new;   // cycles; shadow items appended to the predict list; live tracks after the lifecycle step
+    int nT, pad[3];           // live tracks the frame was associated with (the patch step's dense emulation rebuilds the problem)
+    ProvPair pr[MOT_PROV_PAIRS];
+    ProvTrack t[2 * MOT_PROV_PAIRS];
 };
 struct LapProv {
     int enabled;              // 0: no provisional commits (caller matrices, host API, sharded / Kalman / size-class loops, HBM-slab templates, MOT_PROV=0)

@@ -10,6 +10,12 @@
 
 namespace mot_impl {
 
+// Round 6 removed MOT_ZC_ASYNC (per-object updates that wait for their kernel: lost the A/B, profiles/r05_zc_async_ab.log) and MOT_KCF_R1LDS (the round-3
+// slab pipeline for sizes that have an R1-resident instance: 535 against 588 k updates/s at 148 px, round 5), and added MOT_PROV (0: frames wait for the
+// emulation as in rounds 3-5 -- the A/B and the bit-equality reference of the provisional commits; 2: test hook).  Kept although their off-variant is slower,
+// because each is the only way to FORCE a tier / structure the default path reaches rarely: MOT_LAP_TWO_BLOCK=0 (the sparse emulation as a launch of its
+// own behind the solver: the structure every stream with the dense solver armed takes), MOT_MK_LAZY=0 (the reference's full reset after every augmentation:
+// what the lazy reset falls back to when a step 5 queues more union requests than it holds, mk_sparse_body.h).
 // Round 5 removed the switches whose off-variant had lost every measurement of rounds 2-4 and was covered by no test: MOT_LAP_FUSED (chip-wide
 // dual / after-the-fact checks for box costs; caller matrices still take them), MOT_FEAT_BEFORE_ROWSCAN, MOT_H2D_MODE (hipMemcpyAsync uploads;
 // pageable host memory still falls back to them), MOT_MID_IN_LAUNCH.  What is left is exercised by tests/test_gpu_variants.py.
@@ -29,11 +35,10 @@ struct EnvSwitches {
     int k80;                 // MOT_KCF_K80: which kernels of an 80 x 80 px pool run with the geometry folded in (bit 0 predict, 1 feature, 2 update; default 7, 0: none);
                              // bit 3 (8; only in builds with -DMOT_KCF_SPARSE_VIEW=1, `make endcf`): the folded copy inside the out-of-line body of the sparse update
                              // kernel as well -- the instantiation hipcc miscompiles (register copies in front of a folded EXEC restore: kcf_update_sparse_run)
-    int kcf_r1_lds;          // MOT_KCF_R1LDS=0: HBM-slab templates keep R1 / Mq / bins in the slab (the round-3 pipeline)
     int defer_blend;         // MOT_DEFER_BLEND=0: blend launch of its own
-    int zc_async;            // MOT_ZC_ASYNC=0: per-object updates with a caller patch wait for their kernel before they return (round-5 default: they do not)
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
-    int prov;                // MOT_PROV=0: no provisional commits of two-row tie frames (round 6): the sparse emulation stays in the solver's launch and the frame waits for it
+    int prov;                // MOT_PROV=0: no provisional commits of two-row tie frames (round 6): the sparse emulation stays in the solver's launch and the frame waits for it;
+                             // =2 (test hook): the patch step ignores the sparse emulation's answer and lets its dense emulation decide the swap bits
 };
 
 inline const EnvSwitches& env()
@@ -53,13 +58,11 @@ inline const EnvSwitches& env()
         s.lookahead = off("MOT_LOOKAHEAD") ? 0 : 1;
         s.split_update = off("MOT_SPLIT_UPDATE") ? 0 : 1;
         s.dft_mfma = off("MOT_DFT_MFMA") ? 0 : 1;
-        s.kcf_r1_lds = off("MOT_KCF_R1LDS") ? 0 : 1;
         s.k80 = geti("MOT_KCF_K80", 7);                                  // bit 0 predict, 1 feature, 2 update kernels
         s.dft_inplace = off("MOT_DFT_INPLACE") ? 0 : 1;
         s.defer_blend = off("MOT_DEFER_BLEND") ? 0 : 1;
-        s.zc_async = off("MOT_ZC_ASYNC") ? 0 : 1;
         s.side_reserve = geti("MOT_SIDE_RESERVE", -1);
-        s.prov = off("MOT_PROV") ? 0 : 1;
+        s.prov = geti("MOT_PROV", 1);
         return s;
     }();
     return e;

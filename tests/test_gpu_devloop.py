@@ -616,3 +616,54 @@ def test_state_save_load_resumes_bit_for_bit(mot, oracle, kind, n, cap):
     with pytest.raises(mot.MotError):
         c.state_load(record)                                            # not a fresh context any more
     c.close()
+
+
+def test_provisional_commits_leave_the_bits_of_the_waiting_loop():
+    """Round 6 (mot_dev.h: ProvRec): a tie frame whose certificate fails only because of a few disjoint two-row cycles is committed
+    at once with the solver's optimum; the tracks of the cycles are cloned into shadow slots that adopt the other detection, the NEXT predict
+    launch computes both alternatives beside the order-exact emulation (a kernel of its own on the emulation stream), and the patch step copies
+    the shadows over the tracks of every pair the emulation reports as swapped.  The bench stream at 1024 tracks, 30 frames with one frame of
+    look-ahead and NOTHING synchronised or read back before the end (the path bench.py times: patch step behind the predict, shadow items'
+    predicted boxes taken over), and the same stream read back after every frame (the patch step runs at the synchronisation point, before the
+    predict): live list, ids, ages and every live track's model, alpha, position, scale, flags and response map must be the bits MOT_PROV=0
+    leaves -- the loop that waits for the emulation inside the frame, as rounds 3-5 did.  (Both are held to the oracle elsewhere in this file.)"""
+    args = (1024, 1024, 0, 0, 30, 0, "--ahead", "--final-only")
+    import subprocess, sys
+    def run(env_extra, a):
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "state_dump.py")] + [str(x) for x in a],
+                             env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        frames = [ln for ln in out.stdout.splitlines() if ln.startswith("frame ")]
+        stats = dict(zip(*[iter([ln for ln in out.stdout.splitlines() if ln.startswith("stats ")][0].split()[1:])] * 2))
+        return frames, {k: int(v) for k, v in stats.items()}
+    f1, s1 = run({"MOT_PROV": "1"}, args)
+    f0, s0 = run({"MOT_PROV": "0"}, args)
+    assert len(f1) == 1 and f1 == f0, (f1, f0)
+    assert s0["provisional"] == 0 and s1["tie"] == s0["tie"] and s1["tie"] >= 8
+    assert s1["provisional"] >= 8 and s1["swaps"] >= 3 and s1["dense_bits"] == 0, s1     # this stream: every tie frame is a set of disjoint pairs, about half of them swapped
+    # ... and frame by frame through the synchronisation points (patch step before the predict, no shadow boxes to take over)
+    args2 = (1024, 1024, 0, 0, 12, 0, "--ahead")
+    g1, t1 = run({"MOT_PROV": "1"}, args2)
+    g0, _ = run({"MOT_PROV": "0"}, args2)
+    assert len(g1) == 12 and g1 == g0
+    assert t1["provisional"] >= 3
+
+
+def test_provisional_commit_bit_decided_by_the_dense_emulation():
+    """... and the rare leg: the sparse emulation of a provisionally committed frame REFUSES (an entry outside its candidate lists could have mattered),
+    so the dense order-exact emulation inside the patch step decides the swap bits from the frame's own copies of the predicted boxes and the detection
+    list.  Forced through the test hook MOT_PROV=2 (the patch step ignores the sparse emulation's answer); same bits as the waiting loop, unsynchronised
+    and through the synchronisation points.  (tests/test_gpu_variants.py holds the same hook to the oracle under other switch combinations.)"""
+    import subprocess, sys
+    def run(env_extra, a):
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "state_dump.py")] + [str(x) for x in a],
+                             env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        frames = [ln for ln in out.stdout.splitlines() if ln.startswith("frame ")]
+        stats = dict(zip(*[iter([ln for ln in out.stdout.splitlines() if ln.startswith("stats ")][0].split()[1:])] * 2))
+        return frames, {k: int(v) for k, v in stats.items()}
+    for a in ((1024, 1024, 0, 0, 14, 0, "--ahead", "--final-only"), (1024, 1024, 0, 0, 10, 0, "--ahead")):
+        f2, s2 = run({"MOT_PROV": "2"}, a)
+        f0, _ = run({"MOT_PROV": "0"}, a)
+        assert f2 == f0 and len(f2) >= 1, a
+        assert s2["provisional"] >= 3 and s2["dense_bits"] == s2["provisional"], s2

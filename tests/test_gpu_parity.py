@@ -196,15 +196,6 @@ def test_mixed_template_sizes_with_caller_patches_in_one_batch(mot, oracle):
         c.close()
 
 
-def test_patch_updates_that_wait_for_their_kernel():
-    """the off-variant of the switch (MOT_ZC_ASYNC=0, read once per process): the same test in a process of its own"""
-    import subprocess, sys
-    env = dict(os.environ, MOT_ZC_ASYNC="0")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_back_to_back_patch_updates_through_the_staging_ring"],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-
-
 @pytest.mark.parametrize("rows,cols", [(120, 164), (164, 124), (148, 100), (100, 156)])
 def test_kcf_nonsquare_templates_vs_oracle(mot, oracle, rows, cols):
     """non-square templates, most of them beyond the LDS limit (HBM-slab kernels, MFMA DFT with hb != wb): predict / update of a few
@@ -743,12 +734,3 @@ def test_step_frame_chain_entry_point(mot, oracle):
     m.close(); c.close()
 
 
-def test_kcf_hbm_slab_pipeline_subprocess():
-    """MOT_KCF_R1LDS=0: templates of 104..164 px run round 3's pipeline (patch, gradient planes, R1 and spectra in the per-workgroup HBM slab,
-    dft2_mfma_fixed) instead of the R1-resident one -- the same parity tests at those sizes, in a child process with the switch set."""
-    import subprocess, sys
-    env = dict(os.environ, MOT_KCF_R1LDS="0")
-    sel = "kcf_seq_148 or (test_fhog_vs_oracle_bit_exact and 148) or (test_fhog_vs_oracle_bit_exact and 150) or test_kcf_nonsquare_templates_vs_oracle"
-    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", sel, "-p", "no:cacheprovider"],
-                         cwd=orc.ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -19,7 +19,6 @@ MOT_MK_LAZY=0 python bench.py --no-cpu-baseline --h2d 0 > $O/bench_n1024_full_re
 for sz in 164 168 200; do python bench.py --tracks 64 --size $sz --steps 40 --warmup 10 --steady 0 --h2d 0 --no-cpu-baseline --profile-frames 10 > $O/bench_n64_s$sz.json 2>/dev/null; done
 python tools/kcf_probe.py --frames 8 > $O/kcf_probe_n1024.log 2>&1
 MOT_DBG_EXTRA=1 python tools/kcf_probe.py --frames 8 --tracks 256 --size 148 --det-sizes 120 180 > $O/kcf_probe_n256_s148.log 2>&1
-MOT_KCF_R1LDS=0 python bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline > $O/bench_n256_s148_multiscale_slab_pipeline.json 2>/dev/null
 python tools/assoc_probe.py 1024 30 > $O/assoc_probe_n1024.log 2>&1
 python tools/assoc_trace.py 1024 23 8 > $O/assoc_trace_n1024_frame23.log 2>&1
 python tools/assoc_trace.py 1024 7 8 > $O/assoc_trace_n1024_frame7.log 2>&1

@@ -26,6 +26,19 @@ fb, db = frames[0].numel(), dd[0].numel()
 def step(f):
     nxt = (frames.data_ptr() + (f + 1) * fb, dd.data_ptr() + (f + 1) * db, len(dets[f + 1])) if f + 1 < nf else (0, 0, 0)
     c.step_frame_device_ahead(frames.data_ptr() + f * fb, dd.data_ptr() + f * db, len(dets[f]), *nxt)
+if os.environ.get("PROV_PROBE_PER_FRAME"):
+    # one synchronisation per frame: which tier decided, and why a tie frame was (not) committed provisionally (mot_get_lap_stats()[31])
+    why = {0: "-", 1: "provisional", 2: "free column in the core", 3: "too many pairs", 4: "not disjoint two-row cycles", 5: "emulation not started", 6: "no core row"}
+    prev = np.zeros(32, np.int64)
+    for f in range(nf):
+        step(f); c.sync()
+        l = c.lap_stats().astype(np.int64)
+        tie = l[20] - prev[20]
+        w = int(l[31])
+        reason = "-" if not tie else str(why.get(w & 0xFF, w & 0xFF)) + " (core rows %d, pairs %d)" % ((w >> 8) & 0xFFF, w >> 20)
+        print(f"f{f}: used={int(l[15])} tie={int(tie)} edges={int(l[5])} why={reason} aug={int(l[9])} s5={int(l[10])} provisional_total={int(l[21])} swaps={int(l[22])}")
+        prev = l
+    sys.exit(0)
 for f in range(warm + 1):
     step(f)
 c.sync(); torch.cuda.synchronize()
