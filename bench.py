@@ -459,6 +459,15 @@ def main():
                     print("kcf predict phases us", (np.diff(pa) / 100.0).round(1).tolist(), "update", (np.diff(ub) / 100.0).round(1).tolist(), file=sys.stderr)
                 f += 1
             stage = acc / n_prof
+        # round 6: tie frames whose certificate fails only on a few disjoint two-row cycles are committed at once; the emulation (on a stream of its own,
+        # beside the next predict) only names the swapped pairs.  Cumulative counters of this context over everything it has stepped so far.
+        prov_stats = None
+        if world == 1:
+            ls_ = ctx.lap_stats()
+            prov_stats = {"tie_frames": int(ls_[20]), "committed_provisionally": int(ls_[21]), "pairs_swapped": int(ls_[22]), "bits_by_dense_emulation": int(ls_[23]),
+                          "certified_frames": int(ls_[16]), "switch": os.environ.get("MOT_PROV", "1"),
+                          "note": "in the timed windows the emulation of a provisionally committed frame runs beside the next frame's predict launch; the profile frames behind "
+                                  "them (ms_* above) are synchronised per frame, so their chain time includes the whole emulation as it did in rounds 3-5"}
 
         # third timed window: the frame and its detections arrive from pinned host memory INSIDE the timed region (SURVEY 8d:
         # "frame-level costs (H2D of the frame ...) are included in wall time").  Copy stream + three device buffers: the upload of
@@ -559,6 +568,7 @@ def main():
                                     "share_of_frame": float((stage[1] + stage[3]) / tot), "ms_mean": float(am.mean()), "ms_p50": float(np.percentile(am, 50)),
                                     "ms_p90": float(np.percentile(am, 90)), "ms_max": float(am.max()),
                                     "decided_by": {"certificate": used_by[0], "sparse_emulation": used_by[1], "dense_emulation": used_by[2]},
+                                    "provisional_commits": prov_stats,
                                     "frames": len(assoc_ms), "first_frame": 1 + args.warmup + args.steps + args.steady + n_inloop}
             out["kernel_ms"] = {k: float(v) for k, v in kern.items()}
             out["hbm_frac_whole_frame"] = (ab["predict"] + ab["update"]) * n_live / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -1,8 +1,8 @@
-# evidence run of a round (GPU box; ROUND=r05 by default): bench lines, rocprofv3 kernel statistics, PMC passes, association probes.
-# usage: [ROUND=r05] bash tools/collect_profiles.sh     (writes gpurun_out/$ROUND/final/; tools/install_profiles.sh copies the summaries into profiles/)
+# evidence run of a round (GPU box; ROUND=r06 by default): bench lines, rocprofv3 kernel statistics, PMC passes, association probes.
+# usage: [ROUND=r06] bash tools/collect_profiles.sh     (writes gpurun_out/$ROUND/final/; tools/install_profiles.sh copies the summaries into profiles/)
 # Every rocprofv3 run gets a directory of its own, so each holds exactly one result set (no "newest file" guessing).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 O=gpurun_out/$ROUND/final; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_n1024.json 2> $O/bench_n1024.err
 python bench.py --steps 20 --warmup 5 > $O/bench_n1024_driver.json 2>/dev/null
@@ -23,10 +23,12 @@ python tools/assoc_probe.py 1024 30 > $O/assoc_probe_n1024.log 2>&1
 python tools/assoc_trace.py 1024 23 8 > $O/assoc_trace_n1024_frame23.log 2>&1
 python tools/assoc_trace.py 1024 7 8 > $O/assoc_trace_n1024_frame7.log 2>&1
 ./tools/ubench_latency > $O/ubench_latency.log 2>&1
-# round 5: what each phase costs the predict LAUNCH (probe build), two workgroups per CU against one; small-frame histogram A/B; event-scope probe
-python tools/kcf_ablate.py --reps 8 > $O/kcf_ablate_n1024.log 2>&1
-MOT_KCF_ONE_PER_CU=1 python tools/kcf_ablate.py --reps 6 --only-base > $O/kcf_ablate_n1024_one_per_cu.log 2>&1
-./tools/event_scope_probe 50000 56 1 > $O/event_scope_probe.log 2>&1
+# round 6: provisional commits on / off (same stream, unsynchronised loop), the host-fed loop behind a resident context, a timeline of tie frames
+python tools/prov_probe.py 1024 221 20 > $O/prov_probe_n1024.log 2>&1; MOT_PROV=0 python tools/prov_probe.py 1024 221 20 > $O/prov_probe_n1024_off.log 2>&1
+python tools/prov_probe.py 1024 26 5 > $O/prov_probe_driver.log 2>&1; MOT_PROV=0 python tools/prov_probe.py 1024 26 5 > $O/prov_probe_driver_off.log 2>&1
+(python tools/hostfed_probe.py 1024 221 20 1; MOT_PROV=0 python tools/hostfed_probe.py 1024 221 20 1; python tools/hostfed_probe.py 1024 26 5 1) > $O/hostfed_probe.log 2>&1
+MOT_PROV=0 python bench.py --no-cpu-baseline > $O/bench_n1024_prov_off.json 2>/dev/null; MOT_PROV=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_n1024_driver_prov_off.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $O/ktrace_prov -- python3 tools/prov_probe.py 1024 60 5 > /dev/null 2>&1; python tools/trace_timeline.py $O/ktrace_prov/* 0.7 80 > $O/timeline_prov.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_default -- python3 bench.py --no-cpu-baseline --h2d 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_driver -- python3 bench.py --steps 20 --warmup 5 --steady 0 --h2d 0 --profile-frames 0 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_s148 -- python3 bench.py --tracks 256 --size 148 --det-sizes 120 180 --no-cpu-baseline --h2d 0 > /dev/null 2>&1
