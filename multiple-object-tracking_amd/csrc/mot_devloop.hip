@@ -283,6 +283,12 @@ int devloop_get(mot_ctx* c, DevLoop** out)
     return MOT_OK;
 }
 
+#define MOT_PROV_MIN_DETS 600
+int prov_min_dets()
+{
+    static const int v = [] { const char* e = getenv("MOT_PROV_MIN_DETS"); return e ? atoi(e) : MOT_PROV_MIN_DETS; }();   // (A/B: the detection count from which a frame takes the stream-emulation chain)
+    return v;
+}
 int split_early_max()
 {
     const int v = mot_impl::env().split_early_max;
@@ -419,16 +425,21 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     // the lifecycle step rides in the tail of the Munkres kernel (one launch and one dispatch gap fewer per frame)
     LifeArgs life{}; life.enabled = 1; life.S = S; life.kp = kp; life.kal = c->kal; life.trk_pred = trk; life.dets = dets; life.nD = nD;
     AssocEmu emu{}; const int par = (int)(d->frame_no & 1);
-    if (d->prov) {
+    // Frame by frame: the stream-emulation chain (and with it a provisional commit) only where it pays.  Its fixed costs -- the patch step's launch behind the
+    // predict (7 us even as a no-op) and the completion event the row scan carries for the emulation stream (~5.6 us of idle stream behind it) -- are 12 us per
+    // frame; what it saves is a predict launch per TIE frame, and ties grow with the square of the density: 1024 detections + 14 %, 768 + 10 %, 640 + 2 %, 512 - 5 %, 256 - 11 %
+    // (profiles/r06_prov_threshold.log).  Below MOT_PROV_MIN_DETS detections the frame takes the two-workgroup launch.
+    const bool prov_now = d->prov && nD >= prov_min_dets();
+    if (prov_now) {
         if (d->patch_owed) { int rc = dl_patch(c, d, nullptr); if (rc) return rc; }   // (two-call form without a predict in between: cannot happen, but never two frames owed)
         life.prov.enabled = 1; life.prov.sh_base = S.cap; life.prov.rec = d->prov_rec.p;
         emu.stream = d->emu; emu.ev_rowscan = d->ev_rs; emu.det_copy = d->det_copy.p + (size_t)par * S.max_dets;
     }
     unsigned seq = 0;
     HIPCHK(launch_assoc(c->assoc, trk, S.nlive, S.cap, dets, nD, nullptr, 0, 0, 0, c->stream, ((feat_here || ahead || d->want_mid) && !d->mid_by_predict) ? d->ev_mid : nullptr, &life,
-                        d->prov ? &emu : nullptr, &seq));
-    if (d->prov) { d->patch_owed = true; d->seq_last = seq; d->nD_last = nD; d->par_last = par; }
-    if (d->prov && ev) { int rc = dl_patch(c, d, nullptr); if (rc) return rc; }   // profiled frame: the chain's stage time includes the emulation, as without the overlap
+                        prov_now ? &emu : nullptr, &seq));
+    if (prov_now) { d->patch_owed = true; d->seq_last = seq; d->nD_last = nD; d->par_last = par; }
+    if (prov_now && ev) { int rc = dl_patch(c, d, nullptr); if (rc) return rc; }   // profiled frame: the chain's stage time includes the emulation, as without the overlap
     d->mid_valid = feat_here || ahead || d->want_mid; d->mid_by_predict = false;
     if (feat_here || ahead) HIPCHK(hipStreamWaitEvent(d->side, d->ev_mid, 0));
     if (feat_here) {

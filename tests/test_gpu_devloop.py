@@ -618,6 +618,57 @@ def test_state_save_load_resumes_bit_for_bit(mot, oracle, kind, n, cap):
     c.close()
 
 
+def test_state_save_load_sharded_two_ranks(mot, oracle):
+    """... and with the tracks sharded over two ranks (two contexts on one GPU, the all-gather emulated by copies): each rank's record holds the
+    replicated live list WITH the owner of every track and this rank's segment bookkeeping; both ranks are checkpointed after frame 4 under track
+    churn (owners no longer round-robin), resumed in fresh contexts, and frames 5..8 must give the oracle's live lists on both.  (Round-5 advisor
+    finding: the bit-for-bit test covered world == 1 only.  The association workspace -- solver statistics, the dense solver's arming hint -- is
+    deliberately not part of a record: it steers which tier runs, never a result.)"""
+    from multiple_object_tracking_amd import synth
+    hip = C.CDLL("libamdhip64.so")
+    n, cap = 90, 128
+    scene = synth.Scene(n, 80, stream_id=37, miss_pct=6, fp_pct=4)
+    items = list(scene.frames(9))
+    frames = [f for f, _ in items]; dets = [d[:cap] for _, d in items]
+    fd, dd, da = _dev(frames, dets, mot)
+    m = orc.OracleMot(oracle, 0, 0, cap)
+    refs = [m.step(frames[f], dets[f]) for f in range(9)]
+    m.close()
+
+    def run(ranks, f0, f1):
+        for f in range(f0, f1):
+            segs = [c.step_begin_device(fd[f].data_ptr()) for c in ranks]
+            spr = segs[0][1]
+            for c in ranks:
+                c.sync()
+            bases = [segs[r][0] - r * spr * 24 for r in range(2)]
+            for dst in range(2):
+                for src in range(2):
+                    if src != dst:
+                        assert hip.hipMemcpy(C.c_void_p(bases[dst] + src * spr * 24), C.c_void_p(segs[src][0]), spr * 24, 3) == 0
+            for r, c in enumerate(ranks):
+                c.step_finish_device(bases[r], dd[f].data_ptr(), len(dets[f]))
+            for r, c in enumerate(ranks):
+                boxes, tids, _ = c.live_tracks()
+                assert np.array_equal(tids, refs[f]["tids"]) and np.array_equal(bnp(boxes), bnp(refs[f]["live"])), f"frame {f} rank {r}"
+    a = [mot.MotContext(max_tracks=cap, max_dets=cap, rank=r, world=2) for r in range(2)]
+    run(a, 0, 5)
+    records = [c.state_save() for c in a]
+    for c in a:
+        c.close()
+    b = [mot.MotContext(max_tracks=cap, max_dets=cap, rank=r, world=2) for r in range(2)]
+    for c, rec in zip(b, records):
+        c.state_load(rec)
+    run(b, 5, 9)
+    # a record belongs to its rank: the other rank's context refuses it
+    fresh = mot.MotContext(max_tracks=cap, max_dets=cap, rank=0, world=2)
+    with pytest.raises(mot.MotError):
+        fresh.state_load(records[1])
+    fresh.close()
+    for c in b:
+        c.close()
+
+
 def test_provisional_commits_leave_the_bits_of_the_waiting_loop():
     """Round 6 (mot_dev.h: ProvRec): a tie frame whose certificate fails only because of a few disjoint two-row cycles is committed
     at once with the solver's optimum; the tracks of the cycles are cloned into shadow slots that adopt the other detection, the NEXT predict

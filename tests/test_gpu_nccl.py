@@ -95,6 +95,26 @@ def test_bench_sharded_branch_two_ranks_one_gpu():
     assert all(r[k] > 0 for r in rows for k in ("predict_ms", "gather_ms", "chain_ms")) and all(r["update_ms"] >= 0 for r in rows)
 
 
+def test_bench_streams_mode_two_ranks_one_gpu():
+    """BASELINE configs[4]'s shape -- one independent camera stream per rank, replicas only, no collective (`--mode streams`, weak scaling) -- with
+    two ranks on ONE GPU under the launcher, 148 x 148 px templates fed by 120-180 px detections (the multi-scale leg of that configuration).  The
+    gloo smoke backend only carries the barrier and the max-over-ranks reduction here: the data path has nothing to exchange.  Round-5 verdict item
+    9: the first SCALE run of either mode must not fail on plumbing."""
+    import json
+    import subprocess
+    env = dict(os.environ, MOT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "streams", "--steps", "4", "--warmup", "2",
+           "--tracks", "40", "--size", "148", "--det-sizes", "120", "180", "--steady", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["tracks_total"] == 80 and j["config"]["tracks_per_gpu"] == 40 and "no collective" in j["config"]["parallelism"]
+    assert "per_rank_stage_ms" not in j or j["per_rank_stage_ms"] is None        # nothing is sharded: no all-gather / replicated-chain rows
+
+
 @pytest.mark.gpu
 def test_bench_eight_ranks_one_gpu():
     """BASELINE configs[3]'s shape -- 1024 tracks sharded 128 per rank over EIGHT ranks -- through bench.py's own launcher on one GPU
