@@ -107,4 +107,12 @@ def test_no_null_stream_fills_in_the_product():
             code = line.split("//")[0]
             if re.search(r"\bhipMemset\s*\(", code) and "poison_byte()" not in code:
                 offenders.append(f"{fn}:{ln}")
+            # round-5 verdict: the same hazard under other names -- the synchronous-looking fill variants (they run on the null stream too), and any
+            # *Async fill / copy / launch that names the null stream explicitly (stream argument 0, nullptr, hipStreamDefault / hipStreamLegacy)
+            if re.search(r"\bhipMemset(D8|D16|D32|2D|3D)\s*\(", code):
+                offenders.append(f"{fn}:{ln} (null-stream fill variant)")
+            if re.search(r"\bhipMem(set|cpy)\w*Async\s*\(.*,\s*(0|nullptr|NULL|hipStreamDefault|hipStreamLegacy)\s*\)\s*\)?\s*;", code):
+                offenders.append(f"{fn}:{ln} (async operation on the null stream)")
+            if re.search(r"hipLaunchKernelGGL\s*\([^;]*,\s*(0|nullptr|NULL)\s*,\s*[a-zA-Z_]", code) and re.search(r"dim3\([^)]*\)\s*,\s*dim3\([^)]*\)\s*,\s*[^,]+,\s*(0|nullptr|NULL)\s*,", code):
+                offenders.append(f"{fn}:{ln} (kernel launch on the null stream)")
     assert not offenders, offenders

@@ -497,6 +497,18 @@ def test_folded_geometry_kernels_bit_equal_general_kernels(args):
             "direct update kernel: folded <7> differs from the general <1>"
 
 
+@pytest.mark.parametrize("size", [72, 76])
+def test_inplace_transforms_bit_equal_the_ping_pong_form(size):
+    """Round-5 verdict (measurement hygiene): kernel mode 5 -- LDS-resident templates whose direct transforms run IN PLACE (72 / 76 px single pools: region T
+    leaves the layout, two workgroups per CU) -- against the same kernels with the second buffer (MOT_DFT_INPLACE=0): the in-place passes hold a thread's
+    outputs back across a barrier and write them over its inputs, same sums in the same order, so model, alpha, response map and boxes of every live track
+    must be the same bits after every frame of a noisy stream (tracks die, spawn and keep their predicted boxes).  One process per variant."""
+    args = (40, 64, 6, 4, 6, 23, "--size", size)
+    inplace = _state_hashes({"MOT_DFT_INPLACE": "1"}, args)
+    assert len(inplace) == 6
+    assert _state_hashes({"MOT_DFT_INPLACE": "0"}, args) == inplace
+
+
 def test_sparse_view_miscompile_and_its_fix():
     """Round-4 advisor finding, closed in round 5: the sparse update body with the FOLDED descriptor (MOT_KCF_K80 bit 3, compiled only into the
     demonstration libraries of `make endcf`) writes a wrong model because hipcc places register copies in front of a folded EXEC restore

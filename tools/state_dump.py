@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Prints one sha256 per frame over the complete device state of every live track of the device-resident loop (model, alpha, pos, scale, flags,
 response map; boxes, ids) for a seeded noisy stream -- two builds / kernel variants / runs are equal iff their outputs are (GPU box).
-usage: state_dump.py N CAP MISS FP FRAMES [STREAM_ID] [--ahead] [--final-only]   (--final-only: nothing is read back -- or synchronised -- before the last frame)"""
+usage: state_dump.py N CAP MISS FP FRAMES [STREAM_ID] [--ahead] [--final-only] [--size S]   (--final-only: nothing is read back -- or synchronised -- before the last frame)"""
 import hashlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +15,9 @@ sid = int(sys.argv[6]) if len(sys.argv) > 6 and not sys.argv[6].startswith("-") 
 ahead = "--ahead" in sys.argv
 final_only = "--final-only" in sys.argv
 npz = sys.argv[sys.argv.index("--npz") + 1] if "--npz" in sys.argv else None
+size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 80
 full = {}
-scene = synth.Scene(n, 80, stream_id=sid, miss_pct=miss, fp_pct=fp)
+scene = synth.Scene(n, size, stream_id=sid, miss_pct=miss, fp_pct=fp)
 items = list(scene.frames(nframes))
 frames = [f for f, _ in items]; dets = [d[:cap] for _, d in items]
 fd = torch.from_numpy(np.stack(frames)).cuda()
@@ -25,7 +26,7 @@ da = np.zeros((nframes, max(nmax, 1)), mot_amd.BBOX_DTYPE)
 for i, d in enumerate(dets):
     da[i, :len(d)] = mot_amd.boxes_array(d)
 dd = torch.from_numpy(da.view(np.uint8).reshape(nframes, -1)).cuda()
-c = mot_amd.MotContext(max_tracks=cap, max_dets=cap)
+c = mot_amd.MotContext(max_tracks=cap, max_dets=cap, dev_size=size) if size != 80 else mot_amd.MotContext(max_tracks=cap, max_dets=cap)
 for f in range(nframes):
     if ahead and f + 1 < nframes:
         c.step_frame_device_ahead(fd[f].data_ptr(), dd[f].data_ptr(), len(dets[f]), fd[f + 1].data_ptr(), dd[f + 1].data_ptr(), len(dets[f + 1]))
