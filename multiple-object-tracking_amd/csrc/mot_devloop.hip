@@ -773,6 +773,7 @@ int mot_overlay_live(mot_ctx* c, void* frame_dev)
     if (!c || !frame_dev) return fail(MOT_ERR_ARG, "null argument");
     if (!c->devloop) return fail(MOT_ERR_STATE, "mot_overlay_live needs the device-resident loop (host-orchestrated contexts: mot_overlay_draw)");
     int rc = ensure_device(c); if (rc) return rc;
+    rc = devloop_flush(c); if (rc) return rc;                           // the live boxes of a provisionally committed frame are final only behind its patch step
     const DLState& S = c->devloop->S;
     return overlay_run(c, frame_dev, S.bbox, S.tid, S.nlive, S.cap);
 }
@@ -827,6 +828,7 @@ int mot_debug_snapshot(mot_ctx* c, void* dst_dev, size_t* bytes)
     if (!c) return fail(MOT_ERR_ARG, "null ctx");
     int rc0 = ensure_device(c); if (rc0) return rc0;
     DevLoop* d; rc0 = devloop_get(c, &d); if (rc0) return rc0;
+    if (dst_dev) { rc0 = devloop_flush(c); if (rc0) return rc0; }       // (stream-ordered, like the copies below)
     const DLState& S = d->S;
     const size_t cap = (size_t)S.cap;
     const size_t total = 4 * (4 + cap + 6 * cap + 6 * cap + cap + 6 * cap + cap + cap + 64 + 64 + 64);
