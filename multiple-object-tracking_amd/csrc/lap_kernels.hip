@@ -699,7 +699,14 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_stream_kernel(AssocArgs 
     mk_sparse_run<true, TIMING>(b, mk_batch, 1, lf, lap_raw);
     __threadfence();                                                   // whatever the run published (results, or a whole committed frame) before "finished"
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ew, tagged_word(a.seq, 2), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // "finished" replaces THIS chain's "started" and nothing else (a compare-and-swap, release).  With several contexts on the shared emulation stream a
+    // kernel can start so late that its chain's final kernel has long moved on and the NEXT chain's final kernel has claimed its frame in this word: a plain
+    // store would wipe that claim out, the next chain's emulation kernel would start after all, and two workgroups would commit one frame (seen in the
+    // two-context soak as a memory fault after ~2,000 repetitions: profiles/r06_prov_soak.log)
+    if (threadIdx.x == 0) {
+        int expect = tagged_word(a.seq, 1);
+        (void)__hip_atomic_compare_exchange_strong(ew, &expect, tagged_word(a.seq, 2), __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Two workgroups, one launch (box costs, device loop or host API): workgroup 0 is the solver with its fused tail, workgroup 1 the sparse

@@ -610,7 +610,7 @@ def _full_state(c):
     return b"".join(parts)
 
 
-@pytest.mark.parametrize("kind,n,cap", [(0, 120, 256), (0, 300, 1024), (1, 60, 128)])
+@pytest.mark.parametrize("kind,n,cap", [(0, 120, 256), (0, 300, 1024), (1, 60, 128), (0, 800, 1024)])   # 800 tracks: frames committed provisionally around the checkpoint (round 6)
 def test_state_save_load_resumes_bit_for_bit(mot, oracle, kind, n, cap):
     """mot_state_save / mot_state_load (state dump / load): a stream is run for 5 frames, checkpointed into a host record and
     resumed in a FRESH context; frames 5..9 of the resumed loop must give the oracle's live lists, and -- KCF -- leave the same bits in device memory
