@@ -357,7 +357,15 @@ __device__ int lap_solve_run(const AssocArgs& a, int fused, const LifeArgs& life
     const long long t_begin = wall_clock64();
     if (nR <= 0 || nC <= 0 || nR > nC) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return 2; }
     if (L.hdr[LAP_H_BAD]) { if (tid == 0) L.hdr[LAP_H_SOLVE] = 5; return 2; }
-    for (int i = tid; i < nR * LAP_K; i += MK_THREADS) { S.cc[i] = L.ccost[i]; S.cj[i] = L.ccol[i]; }
+    {   // the candidate lists into LDS: nR * LAP_K <= LAP_K * MK_THREADS entries, all of a thread's loads issued before its first store (the rolled loop
+        // waited for global memory once per iteration: 8 round trips at 1024 rows)
+        double c8[LAP_K]; unsigned short j8[LAP_K];
+        const int ntot = nR * LAP_K;
+#pragma unroll
+        for (int q = 0; q < LAP_K; q++) { const int i = tid + q * MK_THREADS; const bool in = i < ntot; c8[q] = in ? L.ccost[i] : 0.0; j8[q] = in ? L.ccol[i] : (unsigned short)0xFFFF; }
+#pragma unroll
+        for (int q = 0; q < LAP_K; q++) { const int i = tid + q * MK_THREADS; if (i < ntot) { S.cc[i] = c8[q]; S.cj[i] = j8[q]; } }
+    }
     {   // largest cost of the matrix from the row maxima the row scan left in L.u
         const double rm = wave_min_f64_dpp(tid < nR ? -L.u[tid] : 0.0);
         if (lane == 0) S.red[wave] = -rm;

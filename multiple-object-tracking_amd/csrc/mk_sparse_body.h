@@ -140,11 +140,15 @@ __device__ void mk_sparse_run(const AssocArgs& a, int mk_batch, int post_fused, 
 #pragma unroll
     for (int k = 0; k < SPK; k++) { dv[k] = DBL_MAX; myc[k] = 0xFFFF; }
     if (r < nR) {
-        const double rmin = L.ccost[(size_t)r * SPK];
+        // the row's record: all sixteen loads issued before the first use (inside the per-candidate test each cost load waited for its own round trip to HBM:
+        // eight dependent latencies, most of the set-up's time); an absent candidate's cost slot holds DBL_MAX and is never used
+        double cst[SPK];
+#pragma unroll
+        for (int k = 0; k < SPK; k++) { myc[k] = L.ccol[(size_t)r * SPK + k]; cst[k] = L.ccost[(size_t)r * SPK + k]; }
+        const double rmin = cst[0];
 #pragma unroll
         for (int k = 0; k < SPK; k++) {
-            myc[k] = L.ccol[(size_t)r * SPK + k];
-            if (myc[k] != 0xFFFF) { dv[k] = L.ccost[(size_t)r * SPK + k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
+            if (myc[k] != 0xFFFF) { dv[k] = cst[k] - rmin; atomicAdd(&S.cnt[myc[k]], 1); if (fabs(dv[k]) < DBL_EPSILON) zm |= 1u << k; }
         }
     }
 #pragma unroll

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                   ["1024", "0", "0", "400", "--sparse-checks", "--hammer", "--frames", "3"],
                                   # round 6: tie frames committed provisionally, two contexts on the shared emulation stream (the configuration in which a late
                                   # emulation kernel once wiped out the next chain's claim: profiles/r06_prov_soak.log -- that needed ~2,000 repetitions, this is a tripwire)
-                                  ["1024", "0", "0", "600", "--sparse-checks", "--hammer", "--frames", "12"]],
+                                  ["1024", "0", "0", "400", "--sparse-checks", "--hammer", "--frames", "12"]],
                          ids=["48-tracks-9-frames-unsynchronised", "300-tracks-state-compare", "1024-tracks-3-frames-unsynchronised", "1024-tracks-12-frames-provisional-two-contexts"])
 def test_lookahead_soak(args, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lookahead_soak.py")] + args + ["--dump", str(tmp_path)], capture_output=True, text=True, timeout=900)

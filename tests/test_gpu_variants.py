@@ -27,14 +27,11 @@ COMBOS = [
     {'MOT_LAP_DENSE': '1', 'MOT_MK_LAZY': '0', 'MOT_MUNKRES_HELPERS': '1', 'MOT_JOINED_LAUNCH': '0', 'MOT_LOOKAHEAD': '0', 'MOT_SPLIT_UPDATE': '0', 'MOT_KCF_K80': '0'},
     # round 6: provisional commits off (frames wait for the emulation) / their swap bits decided by the patch step's dense emulation (test hook), against the
     # switches they can meet (with MOT_LAP_TWO_BLOCK=0, MOT_DEFER_BLEND=0 or MOT_SPLIT_UPDATE=0 there are no provisional commits at all)
-    {'MOT_PROV': '0'},
     {'MOT_PROV': '0', 'MOT_MK_BATCH': '0', 'MOT_MK_LAZY': '0', 'MOT_JOINED_LAUNCH': '0', 'MOT_SIDE_RESERVE': '0'},
     {'MOT_PROV': '2', 'MOT_MK_LAZY': '0', 'MOT_LOOKAHEAD': '0', 'MOT_KCF_K80': '0'},
     {'MOT_PROV': '2', 'MOT_MK_BATCH': '0', 'MOT_JOINED_LAUNCH': '0', 'MOT_LAP_DENSE': '0'},
-    {'MOT_PROV': '1', 'MOT_LAP_DENSE': '1', 'MOT_MUNKRES_HELPERS': '1'},
     # ... and with the stream-emulation chain on EVERY frame (by default only frames with >= 600 detections take it): small problems, the joined
     # predict + feature launch with shadow items, noisy streams whose emulation commits the frame itself or hands it to the dense emulation
-    {'MOT_PROV_MIN_DETS': '0'},
     {'MOT_PROV_MIN_DETS': '0', 'MOT_PROV': '2', 'MOT_MK_LAZY': '0'},
     {'MOT_PROV_MIN_DETS': '0', 'MOT_JOINED_LAUNCH': '0', 'MOT_LOOKAHEAD': '0', 'MOT_MK_BATCH': '0'},
 ]
