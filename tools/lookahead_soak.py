@@ -142,6 +142,8 @@ bad = []
 state0 = {}
 t_start = time.time()
 for rep in range(a.reps):
+    if rep % 100 == 0:
+        print(f"rep {rep} ({time.time() - t_start:.0f} s)", file=sys.stderr, flush=True)   # (a crash leaves no result line: where it happened)
     if a.dirty:
         # recycle device memory with garbage in it: the context's allocations below come from pages this process has used before
         g = torch.empty(96 << 20, dtype=torch.int32, device="cuda"); g.random_(-2**31, 2**31 - 1); torch.cuda.synchronize(); del g; torch.cuda.empty_cache()
