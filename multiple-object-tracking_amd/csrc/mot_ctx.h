@@ -16,6 +16,7 @@ namespace mot_impl {
 int fail(int code, const char* fmt, ...);
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mot_impl::fail(MOT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+inline bool debug_alloc() { static const bool v = getenv("MOT_DEBUG_ALLOC") != nullptr; return v; }
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
     hipError_t alloc(size_t count)
@@ -23,6 +24,7 @@ template <typename T> struct DevBuf {
         release(); n = count;
         if (!count) return hipSuccess;
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess && debug_alloc()) fprintf(stderr, "mot alloc %p .. %p  %zu bytes (%zu x %zu)\n", (void*)p, (void*)((char*)p + count * sizeof(T)), count * sizeof(T), count, sizeof(T));   // (debug) MOT_DEBUG_ALLOC=1: maps a fault address to a buffer
         if (e == hipSuccess && poison_byte() >= 0) { e = hipMemset(p, poison_byte(), count * sizeof(T)); if (e == hipSuccess) e = hipDeviceSynchronize(); }   // (debug) MOT_POISON, mot_env.h
         return e;
     }

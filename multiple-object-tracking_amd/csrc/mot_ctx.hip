@@ -500,6 +500,11 @@ int mot_ctx_destroy(mot_ctx* c)
     if (!c) return MOT_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // A device loop enqueues on streams it SHARES with the other contexts of this device (side and emulation streams, mot_devloop.hip: AuxStreams): before
+    // anything of this context is destroyed or freed the whole device is idle, not just this context's own queues.  (Round 6: with the per-stream waits
+    // alone the two-context soak with provisional commits died of a memory access fault once in ~2,400 context life cycles -- an access to a just-freed
+    // buffer of the closed context; 8,000 life cycles clean with the device-wide wait, profiles/r06_prov_soak.log.  Closing a context is not a hot path.)
+    if (c->devloop) (void)hipDeviceSynchronize();
     if (c->devloop) devloop_destroy(c->devloop);                        // (drains its side and copy streams before anything is freed)
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);

@@ -432,7 +432,7 @@ int dl_finish(mot_ctx* c, DevLoop* d, const void* gathered, const void* dets_dev
     const bool prov_now = d->prov && nD >= prov_min_dets();
     if (prov_now) {
         if (d->patch_owed) { int rc = dl_patch(c, d, nullptr); if (rc) return rc; }   // (two-call form without a predict in between: cannot happen, but never two frames owed)
-        life.prov.enabled = 1; life.prov.sh_base = S.cap; life.prov.rec = d->prov_rec.p;
+        life.prov.enabled = mot_impl::env().prov == 4 ? 0 : 1; life.prov.sh_base = S.cap; life.prov.rec = d->prov_rec.p;   // (MOT_PROV=4, bisecting aid: the stream-emulation chain without provisional commits)
         emu.stream = d->emu; emu.ev_rowscan = d->ev_rs; emu.det_copy = d->det_copy.p + (size_t)par * S.max_dets;
     }
     unsigned seq = 0;
