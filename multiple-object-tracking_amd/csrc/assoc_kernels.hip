@@ -58,7 +58,13 @@ __global__ void __launch_bounds__(256) assoc_min_kernel(AssocArgs a)
 __global__ void __launch_bounds__(256) assoc_sub_kernel(AssocArgs a, int lazy)
 {
     __shared__ unsigned int zr_lo[64], zr_hi[64];
-    if (lazy) { const int mode = a.ws.lap.hdr[LAP_H_MODE]; if (mode == 0 || (mode == 1 && !a.ws.lap.hdr[LAP_H_SPVIOL])) return; }
+    if (lazy) {
+        // stream emulation (round 6): the emulation's kernel may be publishing MODE / SPVIOL while this launch runs (MODE = 1 is stored before the
+        // post-check's SPVIOL): only a COMMITTED frame (DONE, which never goes back) is skipped; a launch that straddles the commit prepares a
+        // matrix nobody reads
+        if (a.stream_emu) { if (a.ws.lap.hdr[LAP_H_DONE]) return; }
+        else { const int mode = a.ws.lap.hdr[LAP_H_MODE]; if (mode == 0 || (mode == 1 && !a.ws.lap.hdr[LAP_H_SPVIOL])) return; }
+    }
     int nR, nC; bool rowsTrk; resolve_dims(a, nR, nC, rowsTrk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + lane, c0 = blockIdx.y * 64;
@@ -563,7 +569,20 @@ __global__ void __launch_bounds__(MK_THREADS) munkres_kernel(AssocArgs a, int wa
         }
     }
     const bool committed = (lap_mode & 1) && a.ws.lap.hdr[LAP_H_DONE] != 0;
-    if (HELP && blockIdx.x > 0) { if (blockIdx.x % MK_XCDS == 0 && nR > 0 && nC > 0 && !committed) mk_helper_loop(a, S, nR, nC, (want_cost >> 3) & 1); return; }
+    if (HELP && blockIdx.x > 0) {
+        if (blockIdx.x % MK_XCDS != 0) return;
+        // ONE decision per helper workgroup.  With the emulation a kernel of its own (lap_mode bit 1) the frame can be committed -- DONE set, the live count
+        // behind nR / nC changed -- while this workgroup starts: waves that had read DONE on either side of that store disagreed, wave 0 left, the barriers
+        // of the helper loop released without it and the others ran on the LDS contents of whoever held the CU before (round 6: the memory fault of
+        // the two-context soak, profiles/r06_prov_soak.log).  Thread 0's reading counts; a helper that goes ahead on the stale side is released by the
+        // controller's EXIT granules and has written nothing by then.
+        if (tid == 0) { S.flag[0] = committed ? 1 : 0; S.flag[1] = nR; S.flag[4] = nC; }
+        __syncthreads();
+        const int h_done = S.flag[0], hR = S.flag[1], hC = S.flag[4];
+        __syncthreads();
+        if (hR > 0 && hC > 0 && !h_done) mk_helper_loop(a, S, hR, hC, (want_cost >> 3) & 1);
+        return;
+    }
     if (committed) {
         const int mode = a.ws.lap.hdr[LAP_H_MODE];
         __syncthreads();

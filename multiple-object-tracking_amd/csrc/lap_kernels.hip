@@ -689,9 +689,12 @@ template <bool TIMING>
 __global__ void __launch_bounds__(MK_THREADS) mk_sparse_stream_kernel(AssocArgs a, LifeArgs life, int mk_batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lap_raw[];
-    __shared__ int go;
+    __shared__ int go, nT_now;
     int* ew = &a.ws.lap.hdr[LAP_H_EMU];
     if (threadIdx.x == 0) {
+        // the live count, read ONCE for the workgroup: the solver's workgroup (main stream) may be committing this frame -- and changing the count -- right now;
+        // waves with different ideas of the problem's dimensions would part ways at the first size test (the run itself is then told to stop by the verdict)
+        nT_now = a.nT_dev ? *a.nT_dev : a.nT;
         int old = __hip_atomic_load(ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
             if (tagged_value(old, a.seq, 3) == 3) { go = 0; break; }   // the final kernel took the frame before this kernel started (or a later chain is running): nothing to do
@@ -703,6 +706,7 @@ __global__ void __launch_bounds__(MK_THREADS) mk_sparse_stream_kernel(AssocArgs 
     __syncthreads();
     if (!go) return;
     AssocArgs b = a; LifeArgs lf = life;
+    b.nT_dev = nullptr; b.nT = nT_now;
     if (a.det_copy) { b.det = a.det_copy; lf.dets = a.det_copy; }
     mk_sparse_run<true, TIMING>(b, mk_batch, 1, lf, lap_raw);
     __threadfence();                                                   // whatever the run published (results, or a whole committed frame) before "finished"

@@ -501,9 +501,9 @@ int mot_ctx_destroy(mot_ctx* c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     // A device loop enqueues on streams it SHARES with the other contexts of this device (side and emulation streams, mot_devloop.hip: AuxStreams): before
-    // anything of this context is destroyed or freed the whole device is idle, not just this context's own queues.  (Round 6: with the per-stream waits
-    // alone the two-context soak with provisional commits died of a memory access fault once in ~2,400 context life cycles -- an access to a just-freed
-    // buffer of the closed context; 8,000 life cycles clean with the device-wide wait, profiles/r06_prov_soak.log.  Closing a context is not a hot path.)
+    // anything of this context is destroyed or freed the whole device is idle, not just this context's own queues.  Closing a context is not a hot path.
+    // (Round 6: this wait was first believed to cure the two-context soak's memory fault; it did not -- that was a helper workgroup of the final kernel
+    // whose waves disagreed about DONE, assoc_kernels.hip -- but a device loop must not free buffers a kernel on a shared stream may still touch.)
     if (c->devloop) (void)hipDeviceSynchronize();
     if (c->devloop) devloop_destroy(c->devloop);                        // (drains its side and copy streams before anything is freed)
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
