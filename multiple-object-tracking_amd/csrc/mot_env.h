@@ -39,6 +39,7 @@ struct EnvSwitches {
     int side_reserve;        // MOT_SIDE_RESERVE: CUs the side stream may not use (-1: default by template size)
     int prov;                // MOT_PROV=0: no provisional commits of two-row tie frames (round 6): the sparse emulation stays in the solver's launch and the frame waits for it;
                              // =2 (test hook): the patch step ignores the sparse emulation's answer and lets its dense emulation decide the swap bits
+                             // =4 (bisecting aid): the stream-emulation chain without provisional commits -- every tie frame is decided and committed by the emulation's kernel
 };
 
 inline const EnvSwitches& env()
