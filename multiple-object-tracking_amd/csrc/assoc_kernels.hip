@@ -477,22 +477,41 @@ __device__ void prov_apply(const AssocArgs& a, const LifeArgs& life, const AT* a
     if (tid < nR && !in_pair && (int)asg[tid] != (int)L.colOfRow[tid]) bad = true;   // every other row is forced
     const bool anybad = __syncthreads_or(bad) != 0;
     if (swapmask && !anybad) {
+        // This copy sits between the emulation's end and the next row scan.  Its first form walked the tracks one by one -- record, model, scalars, each a chain of
+        // dependent global round trips of ~1 us -- and cost 10 us per exchanged pair (profiles/r06_timeline_prov.txt: the patch step ended 5 us after the emulation
+        // without an exchange, 16 / 26 us with one / two).  Now: lane k moves track k's scalars (all tracks at once), and every
+        // track's model loads are in flight before its first store.
         const int tot = MOT_NCHAN * kp.nbins;
-        for (int k = 0; k < 2 * np; k++) {
-            if (!((swapmask >> (k >> 1)) & 1)) continue;
-            const ProvTrack t = rec->t[k];
-            if (t.sh < 0) continue;
-            const float2* xs = kp.xm + (size_t)t.sh * tot; float2* xd = kp.xm + (size_t)t.slot * tot;
-            for (int i = tid; i < tot; i += MK_THREADS) xd[i] = xs[i];
-            for (int i = tid; i < kp.nbins; i += MK_THREADS) kp.alpha[(size_t)t.slot * kp.nbins + i] = kp.alpha[(size_t)t.sh * kp.nbins + i];
-            // the response map belongs to the last predict: the shadow has one only if a predict launch ran since the clone (else the track keeps its own)
-            if (pred_cur) for (int i = tid; i < kp.nb; i += MK_THREADS) kp.response[(size_t)t.slot * kp.nb + i] = kp.response[(size_t)t.sh * kp.nb + i];
-            if (tid == 0) {
+        if (tid < 2 * np && ((swapmask >> (tid >> 1)) & 1)) {
+            const ProvTrack t = rec->t[tid];
+            if (t.sh >= 0) {
                 kp.pos[t.slot] = kp.pos[t.sh]; kp.scale[t.slot] = kp.scale[t.sh]; kp.first_update[t.slot] = kp.first_update[t.sh];
                 D.pend_det[t.slot] = D.pend_det[t.sh];
                 D.bbox[t.newpos] = t.box_alt;                          // tracker_info.bbox = the adopted detection (td.cpp:519-521)
                 if (pred_cur) pred_cur[t.newpos] = pred_cur[rec->n_new + (t.sh - life.prov.sh_base)];
             }
+        }
+#pragma unroll 1
+        for (int k = 0; k < 2 * np; k++) {
+            if (!((swapmask >> (k >> 1)) & 1)) continue;
+            const int shk = rec->t[k].sh, slk = rec->t[k].slot;
+            if (shk < 0) continue;
+            const float2* xs = kp.xm + (size_t)shk * tot; float2* xd = kp.xm + (size_t)slk * tot;
+            const float* as = kp.alpha + (size_t)shk * kp.nbins; const float* rs = kp.response + (size_t)shk * kp.nb;
+            for (int i0 = 0; i0 < tot; i0 += 8 * MK_THREADS) {
+                float2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { const int i = i0 + q * MK_THREADS + tid; if (i < tot) v[q] = xs[i]; }
+                const float av = (i0 == 0 && tid < kp.nbins) ? as[tid] : 0.f;
+                // the response map belongs to the last predict: the shadow has one only if a predict launch ran since the clone (else the track keeps its own)
+                const float rv = (i0 == 0 && pred_cur && tid < kp.nb) ? rs[tid] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; q++) { const int i = i0 + q * MK_THREADS + tid; if (i < tot) xd[i] = v[q]; }
+                if (i0 == 0 && tid < kp.nbins) kp.alpha[(size_t)slk * kp.nbins + tid] = av;
+                if (i0 == 0 && pred_cur && tid < kp.nb) kp.response[(size_t)slk * kp.nb + tid] = rv;
+            }
+            for (int i = tid + MK_THREADS; i < kp.nbins; i += MK_THREADS) kp.alpha[(size_t)slk * kp.nbins + i] = as[i];          // (templates beyond 1024 bins / cells)
+            if (pred_cur) for (int i = tid + MK_THREADS; i < kp.nb; i += MK_THREADS) kp.response[(size_t)slk * kp.nb + i] = rs[i];
         }
     }
     if (tid == 0) {
