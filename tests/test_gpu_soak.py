@@ -26,3 +26,19 @@ def test_lookahead_soak(args, tmp_path):
     assert out.returncode == 0 and lines, out.stdout[-3000:] + out.stderr[-3000:]
     j = json.loads(lines[-1])
     assert j["mismatches"] == 0 and j["reps"] == int(args[3])
+
+
+def test_helper_grid_beside_the_emulation_stream_soak(tmp_path):
+    """Round 6's second memory fault (profiles/r06_prov_soak.log): with the sparse emulation a kernel of its own, LAP_H_DONE could be set between the
+    reads of two waves of one HELPER workgroup of the final kernel; wave 0 left, the helper loop's barriers released without it and the rest indexed the
+    working matrix with stale LDS.  On the default path the helper grid only runs while the dense-emulation hint is set (one fault in several thousand context
+    life cycles); MOT_MUNKRES_HELPERS=1 puts it behind EVERY frame: the library before the fix dies within 0-300 repetitions of this run, three of three
+    (profiles/r06_prefix_tripwire.log), the fixed one ran 2,000."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MOT_")}
+    env["MOT_MUNKRES_HELPERS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lookahead_soak.py"), "1024", "0", "0", "500", "--sparse-checks", "--hammer", "--frames", "12", "--dirty",
+                          "--dump", str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-3000:] + out.stderr[-3000:]
+    j = json.loads(lines[-1])
+    assert j["mismatches"] == 0 and j["reps"] == 500
