@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) lap_rowscan_kernel(AssocArgs a)
         a.dims[0] = nR; a.dims[1] = nC; a.dims[2] = rowsTrk; a.dims[3] = nR <= nC;
         // first kernel of the chain: the per-frame protocol words start from zero whatever the previous launch left (its final kernel
         // re-arms them, but not on its early-out for an empty side)
-        a.ws.lap.hdr[LAP_H_VERDICT] = 0; a.ws.lap.hdr[LAP_H_DONE] = 0; a.ws.lap.hdr[LAP_H_CERT] = 0;
+        // (the verdict word as THIS chain's "pending": an untagged 0 reads as a newer chain's word to chain 0x3FFFFFFF -- tests/test_emu_protocol_model.py)
+        a.ws.lap.hdr[LAP_H_VERDICT] = tagged_word(a.seq, 0); a.ws.lap.hdr[LAP_H_DONE] = 0; a.ws.lap.hdr[LAP_H_CERT] = 0;
     }
     if (a.det_copy && !a.user) {                                       // stream emulation: its kernel reads a private copy of the detection list (24-byte boxes as 4-byte words)
         const int g = blockIdx.x * 256 + threadIdx.x;
