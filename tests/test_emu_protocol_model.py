@@ -25,14 +25,15 @@ class Violation(Exception):
 
 
 def explore(seqs, truth, plain_store, tagged_rearm=True):
-    """seqs: the two chains' sequence numbers; truth[i]: what chain i's solver finds (1 certified, 2 tie it cannot commit, 3 tie of the provisional shape).
+    """seqs: the consecutive chains' sequence numbers; truth[i]: what chain i's solver finds (1 certified, 2 tie it cannot commit, 3 tie of the provisional shape).
     State: (emu word, verdict word, main pc, emu pc, per-chain commit counts, per-chain flags).  Main stream program per chain: ROWSCAN, SOLVE, FINAL, PATCH;
     emulation stream program per chain: START, RUN, FINISH (lap_kernels.hip: mk_sparse_stream_kernel)."""
-    MAIN = [(c, op) for c in range(2) for op in ("rowscan", "solve", "final", "patch")] + [(None, "end")]
-    EMU = [(c, op) for c in range(2) for op in ("start", "run", "finish")] + [(None, "end")]
+    n = len(seqs)
+    MAIN = [(c, op) for c in range(n) for op in ("rowscan", "solve", "final", "patch")] + [(None, "end")]
+    EMU = [(c, op) for c in range(n) for op in ("start", "run", "finish")] + [(None, "end")]
     # the words as the previous chain left them (a fresh context: zero); flags per chain: (verdict published by the solver, emulation's kernel skipped, provisional)
     prev = (seqs[0] - 1) & 0x3FFFFFFF
-    init = (tagged_word(prev, 2) if prev else 0, tagged_word(prev, 1) if prev else 0, 0, 0, (0, 0), ((0, 0, 0), (0, 0, 0)))
+    init = (tagged_word(prev, 2) if prev else 0, tagged_word(prev, 1) if prev else 0, 0, 0, (0,) * n, ((0, 0, 0),) * n)
     seen, stack, finals, writers = set(), [init], 0, set()
 
     def commit(have, who):                                  # who: 1 the solver's workgroup, 2 the emulation's kernel, 3 the final kernel after its claim, 4 the final kernel behind a run that ended without committing
@@ -142,3 +143,13 @@ def test_untagged_rearm_costs_chain_0x3fffffff_its_sparse_emulation():
     _, _, tagged = explore(seqs, truth, plain_store=False, tagged_rearm=True)
     assert {w[0] for w in untagged} == {2, 3, 4}                         # 4: the run read the re-armed 0 as "a newer chain's verdict" and gave up
     assert {w[0] for w in tagged} == {2, 3}                              # the emulation's kernel when it started in time, the final kernel's claim otherwise
+
+
+def test_three_chains():
+    """a kernel of the emulation stream can be two chains late (both certified: nobody waits for it)"""
+    for truth in itertools.product((1, 2, 3), repeat=3):
+        _, finals, writers = explore((7, 8, 9), truth, plain_store=False)
+        assert finals > 0 and all(4 not in w for w in writers), (truth, writers)
+    with pytest.raises(Violation, match="committed twice"):
+        for truth in itertools.product((1, 2, 3), repeat=3):
+            explore((7, 8, 9), truth, plain_store=True)
